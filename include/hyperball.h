@@ -1,0 +1,219 @@
+/*
+ * hyperball.h - C ABI of the MI355X-native HyperBall harmonic-centrality library.
+ *
+ * Drop-in boundary.  The reference call site is
+ *
+ *     crates/core/src/entrypoint/centrality.rs:46-53
+ *         let graph = WebgraphBuilder::new(path, 0).open();
+ *         let hc    = HarmonicCentrality::calculate(&graph);          // harmonic.rs:292
+ *         store_harmonic(hc.iter().map(|(n, c)| (*n, c)), out);       // centrality/mod.rs:72
+ *
+ * A Rust shim keeps `pub struct HarmonicCentrality(BTreeMap<NodeID,f64>)`
+ * (harmonic.rs:289-311) and replaces the body of `calculate` by:
+ *     hb_create -> hb_load_edges(graph.host_nodes(), graph.host_edges()) -> hb_run
+ *     -> hb_result_count / hb_result_copy -> BTreeMap -> hb_destroy.
+ * Everything upstream (Webgraph loader) and downstream (speedy_kv centrality store
+ * writer) is untouched.
+ *
+ * All functions are extern "C", never unwind, keep no global state.  One host thread
+ * per context; calls on one context are not re-entrant.  Return value: 0 = HB_OK,
+ * negative = error (message via hb_last_error).  The library needs a gfx950 GPU; there
+ * is NO CPU fallback - every entry point that computes fails with HB_ERR_NO_DEVICE
+ * when no device is present.
+ */
+#ifndef HYPERBALL_H
+#define HYPERBALL_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HB_ABI_VERSION 1
+
+/* ---- error codes -------------------------------------------------------------- */
+#define HB_OK 0
+#define HB_ERR_INVALID   (-1) /* bad argument / call order                         */
+#define HB_ERR_NO_DEVICE (-2) /* no HIP device, or not gfx950                      */
+#define HB_ERR_HIP       (-3) /* a HIP runtime call failed                         */
+#define HB_ERR_NOMEM     (-4) /* host or device allocation failed                  */
+#define HB_ERR_RCCL      (-5) /* an RCCL call failed                               */
+#define HB_ERR_LIMIT     (-6) /* n >= 2^32-2^20 nodes, or max_passes exceeded       */
+
+/* ---- plain data ---------------------------------------------------------------- */
+
+/* Rust `u128` <-> two little-endian u64 halves.  NodeID(u128): webgraph/node.rs:37.
+ * Ordering everywhere is the numeric u128 order (hi first, then lo). */
+typedef struct hb_u128 {
+    uint64_t lo;
+    uint64_t hi;
+} hb_u128;
+
+/* SmallEdge { from: NodeID, to: NodeID, rel_flags: RelFlags(u64) }, webgraph/edge.rs:31-35;
+ * 40 bytes, #[repr(C)] on the Rust side. */
+typedef struct hb_edge {
+    hb_u128 from;
+    hb_u128 to;
+    uint64_t rel_flags;
+} hb_edge;
+
+/* Edges with rel_flags & HB_SKIPPED_REL_MASK != 0 are dropped (after first-occurrence
+ * de-duplication): SKIPPED_REL, harmonic.rs:36-49, bit values
+ * webpage/html/links.rs:114-141. */
+#define HB_SKIPPED_REL_MASK 0x6FED00ull
+
+/* ---- options ------------------------------------------------------------------- */
+#define HB_FLAG_NO_FRONTIER   0x01u /* never skip unchanged sources (debug; same results)          */
+#define HB_FLAG_NO_REORDER    0x02u /* keep ascending-NodeID order as the device order            */
+#define HB_FLAG_UNFUSED       0x04u /* run merge and estimator/Kahan as two kernels even on 1 GPU  */
+#define HB_FLAG_PASS_STATS    0x08u /* also count active edges / touched rows per pass (A_t, V_t)  */
+#define HB_FLAG_NO_LDS_HOT    0x10u /* do not stage the hottest counters in LDS                    */
+#define HB_FLAG_NO_XCD_MAP    0x20u /* plain blockIdx -> work mapping                              */
+#define HB_FLAG_NO_RCCL       0x40u /* world_size > 1 bookkeeping without a communicator: the caller
+                                       performs the exchange (hb_debug_merge_pending; tests)       */
+#define HB_FLAG_RCCL_SELF     0x80u /* world_size == 1 but still create a 1-rank communicator and run
+                                       the collectives (exercises the RCCL call path on one GPU)   */
+
+typedef struct hb_options {
+    uint32_t struct_size;   /* = sizeof(hb_options); 0 is accepted as "this version"       */
+    int32_t  device;        /* HIP device ordinal; < 0 = current device                     */
+    uint32_t flags;         /* HB_FLAG_*                                                   */
+    uint32_t chunk;         /* max sources per work row (hub rows are split); 0 = default  */
+    uint32_t max_passes;    /* safety bound on passes; 0 = 4096                            */
+    int32_t  rank;          /* edge-partition mode: this process' rank ...                 */
+    int32_t  world_size;    /* ... of world_size (<= 1: single GPU, no collective)         */
+    uint8_t  rccl_id[128];  /* ncclUniqueId from hb_rccl_unique_id() of rank 0             */
+    uint32_t tune[8];       /* kernel tuning knobs, 0 = default            */
+} hb_options;
+
+typedef struct hb_ctx hb_ctx;
+
+/* ---- statistics ------------------------------------------------------------------ */
+typedef struct hb_stats {
+    uint64_t n;             /* |V| (harmonic.rs:58-72)                                     */
+    uint64_t m_input;       /* edge records received                                       */
+    uint64_t m_unique;      /* unique (from,to) pairs (store.rs:313)                        */
+    uint64_t m_eff;         /* ... surviving the rel-flag filter (harmonic.rs:131)          */
+    uint64_t passes;        /* T, including the final no-change pass (harmonic.rs:237-240)  */
+    uint64_t results;       /* nodes with centrality > 0                                    */
+    double   ms_ingest;     /* host: dedup / remap / CSR build                              */
+    double   ms_plan;       /* host: device ordering, hub-row splitting                     */
+    double   ms_h2d;        /* graph upload + state initialisation                          */
+    double   ms_loop;       /* wall time of the iteration loop (the timed quantity)         */
+    double   ms_loop_gpu;   /* sum of per-pass GPU time (HIP events on the ctx stream)      */
+    double   ms_collective; /* part of ms_loop_gpu spent in RCCL collectives                */
+    double   ms_d2h;        /* result download + id mapping                                 */
+    uint64_t work_rows;     /* real + virtual (hub-chunk) rows                              */
+    uint64_t virtual_rows;
+    uint64_t device_bytes;  /* device memory held by the context                            */
+} hb_stats;
+
+typedef struct hb_pass_stats {
+    uint64_t pass;          /* t                                                            */
+    uint64_t changed;       /* nodes whose counter changed in pass t                        */
+    uint64_t active_edges;  /* A_t (only with HB_FLAG_PASS_STATS, else 0)                   */
+    uint64_t touched;       /* V_t (only with HB_FLAG_PASS_STATS, else 0)                   */
+    uint32_t mode;          /* 0 = dense (no frontier test), 1 = frontier                   */
+    float    ms_gpu;        /* GPU time of the pass (all its launches + collective)         */
+    float    ms_main;       /* GPU time of the dominant launch (real rows)                  */
+    float    ms_collective;
+} hb_pass_stats;
+
+/* ---- lifecycle --------------------------------------------------------------------- */
+int  hb_abi_version(void);
+/* opt may be NULL (defaults, current device). */
+int  hb_create(const hb_options *opt, hb_ctx **out);
+void hb_destroy(hb_ctx *ctx);
+/* Message of the last failing call on ctx (or of hb_create when ctx == NULL). */
+const char *hb_last_error(const hb_ctx *ctx);
+
+/* ---- graph input --------------------------------------------------------------------- */
+/* Replaces the per-pass `graph.host_nodes()` / `graph.host_edges()` streaming
+ * (webgraph/mod.rs:157,192 -> store.rs:297-357) by one hand-over.
+ *   node_ids: graph.host_nodes() in any order, duplicates allowed; NULL/n = 0 -> the node
+ *             set is derived from the endpoints of ALL edge records, flagged ones included
+ *             (store.rs:338-357).
+ *   edges:    graph.host_edges() order matters: the FIRST record of each (from,to) pair
+ *             wins (itertools::unique_by, store.rs:313), THEN records with
+ *             rel_flags & HB_SKIPPED_REL_MASK are dropped (harmonic.rs:131).  Records whose
+ *             endpoint is not in the node set are ignored (harmonic.rs:135).
+ * Buffers are copied; the caller may free them on return.  In edge-partition mode every
+ * rank passes the full node set and its own subset of the records; all records of one
+ * (from,to) pair must go to the same rank, in stream order. */
+int hb_load_edges(hb_ctx *ctx, const hb_u128 *node_ids, uint64_t n, const hb_edge *edges,
+                  uint64_t m);
+/* Chunked variant for callers that cannot hold all records: append any number of times,
+ * then finalize (node_ids as above). */
+int hb_append_edges(hb_ctx *ctx, const hb_edge *edges, uint64_t m);
+int hb_finalize(hb_ctx *ctx, const hb_u128 *node_ids, uint64_t n);
+
+/* Pre-reduced input (bench / large synthetic graphs): sorted_ids strictly ascending;
+ * in-edges of node v (the v-th smallest id) are src[row_ptr[v] .. row_ptr[v+1]), already
+ * unique and flag-filtered.  In edge-partition mode: full id list, local edge subset. */
+int hb_load_dense(hb_ctx *ctx, const hb_u128 *sorted_ids, uint64_t n, const uint64_t *row_ptr,
+                  const uint32_t *src, uint64_t m_eff);
+
+/* ---- compute ----------------------------------------------------------------------------- */
+/* Replaces calculate_centrality (harmonic.rs:215-287): runs passes until one changes
+ * nothing, then normalises.  Blocking.  stats may be NULL. */
+int hb_run(hb_ctx *ctx, hb_stats *stats);
+
+/* Step-wise form of the same loop (parity tests, multi-rank drivers):
+ *   hb_begin        initialize (harmonic.rs:53-73,219-235): counters, Kahan sums, t = 0
+ *   hb_step         one loop body (harmonic.rs:237-280); *has_changes as in the reference
+ *   hb_finish       normalize_centralities (harmonic.rs:178-195, :282)
+ * hb_run == hb_begin; while (has_changes) hb_step; hb_finish. */
+int hb_begin(hb_ctx *ctx);
+int hb_step(hb_ctx *ctx, int *has_changes);
+int hb_finish(hb_ctx *ctx);
+
+int hb_get_stats(const hb_ctx *ctx, hb_stats *out);
+/* Stats of pass t (0 <= t < passes). */
+int hb_get_pass_stats(const hb_ctx *ctx, uint64_t t, hb_pass_stats *out);
+
+/* ---- results: HarmonicCentrality::iter / len (harmonic.rs:296-311) ---------------------- */
+/* Number of nodes with centrality > 0 (absent key <=> centrality <= 0). */
+int hb_result_count(hb_ctx *ctx, uint64_t *count);
+/* Ascending NodeID, only centrality > 0, value = sum / (n-1) (non-finite -> 0.0).
+ * Writes min(count, cap) entries; ids or vals may be NULL. */
+int hb_result_copy(hb_ctx *ctx, hb_u128 *ids, double *vals, uint64_t cap);
+
+/* ---- multi-GPU (one process per GPU, RCCL over xGMI) -------------------------------------- */
+/* Rank 0 calls this and distributes the 128 bytes (e.g. torch.distributed broadcast);
+ * every rank puts them in hb_options.rccl_id. */
+int hb_rccl_unique_id(uint8_t out[128]);
+
+/* ---- device helpers for harnesses -------------------------------------------------------- */
+int hb_device_count(int *count);
+/* Fills name (NUL-terminated, <= cap) with the gcnArchName of the ctx device. */
+int hb_device_name(const hb_ctx *ctx, char *name, uint64_t cap);
+int hb_device_synchronize(hb_ctx *ctx);
+
+/* ---- test / bench-only exports (NOT part of the drop-in contract) ------------------------- */
+/* Current counters, one 64-byte register block per node, in ascending-NodeID order
+ * (HyperLogLog::registers, hyperloglog.rs:4544).  Valid after hb_begin / any hb_step. */
+int hb_debug_copy_registers(hb_ctx *ctx, uint8_t *out /* n*64 */);
+/* KahanSum state per node, ascending-NodeID order (kahan_sum.rs:30-33). */
+int hb_debug_copy_kahan(hb_ctx *ctx, double *sum, double *err);
+/* Cached HyperLogLog::size() of the current counter per node. */
+int hb_debug_copy_sizes(hb_ctx *ctx, uint64_t *out);
+/* Runs the device estimator (HyperLogLog::size, hyperloglog.rs:4484-4516) on `count`
+ * arbitrary 64-byte register blocks. */
+int hb_debug_hll_size(hb_ctx *ctx, const uint8_t *regs, uint64_t count, uint64_t *out);
+/* Reduced graph as the library sees it after ingest (ascending-NodeID indexing):
+ * any pointer may be NULL; row_ptr has n+1 entries, src has m_eff. */
+int hb_debug_copy_graph(hb_ctx *ctx, hb_u128 *ids, uint64_t *row_ptr, uint32_t *src);
+/* Element-wise max of ctx's pending ("new") counters with those of `other` (same n):
+ * emulates the all-reduce(max) between logical ranks living on one device. Only valid
+ * between hb_step_local and hb_step_finish. */
+int hb_debug_merge_pending(hb_ctx *ctx, hb_ctx *other);
+/* Two halves of hb_step for HB_FLAG_UNFUSED contexts: local merge into the pending
+ * counters; [collective or hb_debug_merge_pending]; estimator/Kahan/changed detection. */
+int hb_step_local(hb_ctx *ctx);
+int hb_step_finish(hb_ctx *ctx, int *has_changes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HYPERBALL_H */

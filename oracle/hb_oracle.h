@@ -1,0 +1,136 @@
+/*
+ * hb_oracle.h - CPU restatement of Stract's harmonic-centrality (HyperBall) path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under stract_amd/ (the product) may include,
+ * link or call this.  Allowed users: tests/, __graft_entry__.smoke(), and the
+ * cpu_baseline leg of bench.py - as the checker / the reported CPU baseline.
+ *
+ * PARITY STATUS: "parity unpinned" for numeric centrality values.  The reference
+ * (Rust) cannot be built in this image (no rustc/cargo, ~600 un-vendored crates)
+ * and its own tests pin only ordering / idempotence / flag filtering
+ * (harmonic.rs:358-578) plus one exact float for KahanSum (kahan_sum.rs:104,124).
+ * Every function below cites the reference lines it restates; the behavioural
+ * tests and the Kahan known answer are reproduced in tests/test_oracle.py.
+ *
+ * Reference files (all under /root/reference/crates/):
+ *   core/src/webgraph/centrality/harmonic.rs   the iteration
+ *   core/src/hyperloglog.rs                    HyperLogLog<64, FastHasher>
+ *   core/src/kahan_sum.rs                      KahanSum
+ *   bloom/src/lib.rs                           U64BloomFilter (faithful mode only)
+ *   core/src/webgraph/store.rs:297-357         node / edge set semantics
+ */
+#ifndef HB_ORACLE_H
+#define HB_ORACLE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- HyperLogLog<64, FastHasher>  (hyperloglog.rs:4331-4547) ------------------- */
+
+/* hyperloglog.rs:4385-4396 (add) + :4311-4313 (FastHasher) + :4398-4400 (add_u128
+ * keeps only the low 64 bits). */
+void hbo_hll_add(uint8_t reg[64], uint64_t item_low64);
+
+/* hyperloglog.rs:4531-4535 */
+void hbo_hll_merge(uint8_t dst[64], const uint8_t src[64]);
+
+/* Which std `binary_search_by` the estimator's nearest-neighbour lookup uses
+ * (hyperloglog.rs:4413).  0 = Rust >= 1.82 (branchless "halve size, keep base";
+ * stable at the reference snapshot date was 1.83), 1 = the classic
+ * left/right/early-return loop of Rust 1.52..1.81.  The lookup table is unsorted at
+ * two places, so the variant is part of the specification. */
+#define HBO_BSEARCH_RUST_1_82 0
+#define HBO_BSEARCH_CLASSIC   1
+
+/* hyperloglog.rs:4484-4516 (size), :4407-4470 (estimate_bias), :4472-4476
+ * (linear_counting), :4366-4378 (am), :4478-4480 (threshold). */
+uint64_t hbo_hll_size(const uint8_t reg[64]);
+/* Same with explicit search variant; optionally reports raw e and e_star. */
+uint64_t hbo_hll_size_ex(const uint8_t reg[64], int bsearch_variant, double *e_out,
+                         double *e_star_out);
+/* estimate_bias alone (hyperloglog.rs:4407-4470) for a given raw estimate. */
+double hbo_hll_estimate_bias(double e, int bsearch_variant);
+/* Index returned for idx_left by the binary-search step (for variant studies). */
+int hbo_hll_bias_first_index(double e, int bsearch_variant);
+
+/* ---- KahanSum  (kahan_sum.rs:47-54) -------------------------------------------- */
+void hbo_kahan_add(double *sum, double *err, double rhs);
+
+/* ---- SKIPPED_REL (harmonic.rs:36-49; bit values webpage/html/links.rs:114-141) -- */
+#define HBO_SKIPPED_REL_MASK 0x6FED00ull
+
+/* ---- dense HyperBall (same arithmetic, index-remapped arrays + CSR by destination)
+ *
+ * Restates calculate_centrality (harmonic.rs:215-287) on a graph that has already
+ * been reduced to the reference's node set (store.rs:338-357) and edge set
+ * (store.rs:297-314 then harmonic.rs:131), with node i = i-th smallest NodeID.
+ */
+typedef struct hbo_dense hbo_dense;
+
+typedef struct {
+    uint64_t pass;         /* t of the pass just executed (0-based)                      */
+    uint64_t active_edges; /* A_t: edges whose source changed in pass t-1 (all at t=0)   */
+    uint64_t touched;      /* V_t: destinations with >= 1 active in-edge                 */
+    uint64_t changed;      /* nodes whose counter changed in this pass                   */
+    int has_changes;
+} hbo_pass_stats;
+
+/* id_low64[i] = low 64 bits of the i-th NodeID (hyperloglog.rs:4398-4400);
+ * row_ptr[n+1], src[m]: in-edges of node v are src[row_ptr[v] .. row_ptr[v+1]).
+ * threads <= 0 -> all OpenMP threads.  Arrays are borrowed, not copied. */
+hbo_dense *hbo_dense_create(uint64_t n, const uint64_t *id_low64, const uint64_t *row_ptr,
+                            const uint32_t *src, int threads);
+void hbo_dense_destroy(hbo_dense *);
+/* flags for hbo_dense_step */
+#define HBO_FRONTIER 1 /* skip sources that did not change in the previous pass (App. C-1)  */
+#define HBO_LITERAL  2 /* evaluate size(new) and size(old) afresh for every node, as
+                          update_centralities does (harmonic.rs:159-176); default caches  */
+/* One pass of the loop body harmonic.rs:237-275: update counters, update
+ * centralities, step, t += 1.  Returns has_changes. */
+int hbo_dense_step(hbo_dense *, int flags, hbo_pass_stats *stats);
+/* Loop until a pass changes nothing (harmonic.rs:237-240).  Returns T = passes
+ * executed (including the final no-change pass). */
+uint64_t hbo_dense_run(hbo_dense *, int flags);
+const uint8_t *hbo_dense_registers(const hbo_dense *); /* n*64, state after last step */
+const double *hbo_dense_kahan_sum(const hbo_dense *);
+const double *hbo_dense_kahan_err(const hbo_dense *);
+const uint64_t *hbo_dense_sizes(const hbo_dense *);
+uint64_t hbo_dense_passes(const hbo_dense *);
+/* normalize_centralities (harmonic.rs:178-195): out[i] = sum_i/(n-1) if sum_i > 0
+ * (non-finite -> 0.0), keep[i] = sum_i > 0.  Returns number kept. */
+uint64_t hbo_dense_finish(const hbo_dense *, double *out, uint8_t *keep);
+void hbo_dense_set_bsearch(hbo_dense *, int variant);
+
+/* ---- structure-faithful single-thread path ("what `stract centrality harmonic`
+ *      does"): id-keyed ordered lookups, per-pass edge re-dedup, per-pass clone of the
+ *      counter map, bloom changed-set, sqrt(n) exact-counting tail.  Timing context
+ *      and an independent statement of the node/edge set semantics. ------------------ */
+typedef struct { uint64_t lo, hi; } hbo_u128;
+typedef struct { hbo_u128 from, to; uint64_t rel_flags; } hbo_edge; /* SmallEdge, edge.rs:31-35 */
+
+typedef struct {
+    uint64_t n;           /* |V| (harmonic.rs:58-72)                                  */
+    uint64_t m_unique;    /* unique (from,to) pairs (store.rs:313)                     */
+    uint64_t m_eff;       /* ... that survive the rel-flag filter (harmonic.rs:131)    */
+    uint64_t passes;      /* T                                                        */
+    uint64_t passes_exact;/* passes that took update_changed_counters (harmonic.rs:244) */
+    double seconds_loop;  /* wall time of the loop harmonic.rs:237-280                 */
+} hbo_faithful_stats;
+
+/* Runs the whole of calculate_centrality on raw edges.  Results: ascending NodeID,
+ * only centrality > 0 (harmonic.rs:178-195).  out_ids/out_vals may be NULL to just
+ * count; returns the number of results, or (uint64_t)-1 if cap is too small. */
+uint64_t hbo_faithful_run(const hbo_edge *edges, uint64_t m, hbo_u128 *out_ids,
+                          double *out_vals, uint64_t cap, hbo_faithful_stats *stats);
+
+/* U64BloomFilter pieces exposed for tests (bloom/src/lib.rs:36-41,108-123). */
+uint64_t hbo_bloom_num_bits(uint64_t estimated_items, double fp);
+uint64_t hbo_bloom_estimate_card(uint64_t num_bits, uint64_t num_ones);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

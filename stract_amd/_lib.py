@@ -1,0 +1,337 @@
+"""ctypes binding of the C ABI declared in include/hyperball.h.
+
+The shared library is built in-tree (stract_amd/lib/libhyperball.so) by
+`__graft_entry__.build()` / `make -C stract_amd/csrc`.  There is no Python or CPU
+fallback: if the library is missing, or no gfx950 device is present, calls raise.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libhyperball.so")
+
+HB_OK = 0
+HB_ERR_INVALID, HB_ERR_NO_DEVICE, HB_ERR_HIP, HB_ERR_NOMEM, HB_ERR_RCCL, HB_ERR_LIMIT = -1, -2, -3, -4, -5, -6
+HB_SKIPPED_REL_MASK = 0x6FED00
+
+HB_FLAG_NO_FRONTIER = 0x01
+HB_FLAG_NO_REORDER = 0x02
+HB_FLAG_UNFUSED = 0x04
+HB_FLAG_PASS_STATS = 0x08
+HB_FLAG_NO_LDS_HOT = 0x10
+HB_FLAG_NO_XCD_MAP = 0x20
+HB_FLAG_NO_RCCL = 0x40
+HB_FLAG_RCCL_SELF = 0x80
+
+# numpy views of the plain-data structs
+U128 = np.dtype([("lo", "<u8"), ("hi", "<u8")])
+EDGE = np.dtype([("from", U128), ("to", U128), ("rel_flags", "<u8")])
+assert U128.itemsize == 16 and EDGE.itemsize == 40
+
+
+class HbOptions(ctypes.Structure):
+    _fields_ = [
+        ("struct_size", ctypes.c_uint32),
+        ("device", ctypes.c_int32),
+        ("flags", ctypes.c_uint32),
+        ("chunk", ctypes.c_uint32),
+        ("max_passes", ctypes.c_uint32),
+        ("rank", ctypes.c_int32),
+        ("world_size", ctypes.c_int32),
+        ("rccl_id", ctypes.c_uint8 * 128),
+        ("tune", ctypes.c_uint32 * 8),
+    ]
+
+
+class HbStats(ctypes.Structure):
+    _fields_ = [
+        ("n", ctypes.c_uint64),
+        ("m_input", ctypes.c_uint64),
+        ("m_unique", ctypes.c_uint64),
+        ("m_eff", ctypes.c_uint64),
+        ("passes", ctypes.c_uint64),
+        ("results", ctypes.c_uint64),
+        ("ms_ingest", ctypes.c_double),
+        ("ms_plan", ctypes.c_double),
+        ("ms_h2d", ctypes.c_double),
+        ("ms_loop", ctypes.c_double),
+        ("ms_loop_gpu", ctypes.c_double),
+        ("ms_collective", ctypes.c_double),
+        ("ms_d2h", ctypes.c_double),
+        ("work_rows", ctypes.c_uint64),
+        ("virtual_rows", ctypes.c_uint64),
+        ("device_bytes", ctypes.c_uint64),
+    ]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+class HbPassStats(ctypes.Structure):
+    _fields_ = [
+        ("pass_", ctypes.c_uint64),
+        ("changed", ctypes.c_uint64),
+        ("active_edges", ctypes.c_uint64),
+        ("touched", ctypes.c_uint64),
+        ("mode", ctypes.c_uint32),
+        ("ms_gpu", ctypes.c_float),
+        ("ms_main", ctypes.c_float),
+        ("ms_collective", ctypes.c_float),
+    ]
+
+    def as_dict(self):
+        d = {k: getattr(self, k) for k, _ in self._fields_}
+        d["pass"] = d.pop("pass_")
+        return d
+
+
+# every symbol include/hyperball.h declares: (name, restype, argtypes)
+_P = ctypes.c_void_p
+_U64 = ctypes.c_uint64
+_SIGNATURES = [
+    ("hb_abi_version", ctypes.c_int, []),
+    ("hb_create", ctypes.c_int, [ctypes.POINTER(HbOptions), ctypes.POINTER(_P)]),
+    ("hb_destroy", None, [_P]),
+    ("hb_last_error", ctypes.c_char_p, [_P]),
+    ("hb_load_edges", ctypes.c_int, [_P, _P, _U64, _P, _U64]),
+    ("hb_append_edges", ctypes.c_int, [_P, _P, _U64]),
+    ("hb_finalize", ctypes.c_int, [_P, _P, _U64]),
+    ("hb_load_dense", ctypes.c_int, [_P, _P, _U64, _P, _P, _U64]),
+    ("hb_run", ctypes.c_int, [_P, ctypes.POINTER(HbStats)]),
+    ("hb_begin", ctypes.c_int, [_P]),
+    ("hb_step", ctypes.c_int, [_P, ctypes.POINTER(ctypes.c_int)]),
+    ("hb_finish", ctypes.c_int, [_P]),
+    ("hb_get_stats", ctypes.c_int, [_P, ctypes.POINTER(HbStats)]),
+    ("hb_get_pass_stats", ctypes.c_int, [_P, _U64, ctypes.POINTER(HbPassStats)]),
+    ("hb_result_count", ctypes.c_int, [_P, ctypes.POINTER(_U64)]),
+    ("hb_result_copy", ctypes.c_int, [_P, _P, _P, _U64]),
+    ("hb_rccl_unique_id", ctypes.c_int, [_P]),
+    ("hb_device_count", ctypes.c_int, [ctypes.POINTER(ctypes.c_int)]),
+    ("hb_device_name", ctypes.c_int, [_P, ctypes.c_char_p, _U64]),
+    ("hb_device_synchronize", ctypes.c_int, [_P]),
+    ("hb_debug_copy_registers", ctypes.c_int, [_P, _P]),
+    ("hb_debug_copy_kahan", ctypes.c_int, [_P, _P, _P]),
+    ("hb_debug_copy_sizes", ctypes.c_int, [_P, _P]),
+    ("hb_debug_hll_size", ctypes.c_int, [_P, _P, _U64, _P]),
+    ("hb_debug_copy_graph", ctypes.c_int, [_P, _P, _P, _P]),
+    ("hb_debug_merge_pending", ctypes.c_int, [_P, _P]),
+    ("hb_step_local", ctypes.c_int, [_P]),
+    ("hb_step_finish", ctypes.c_int, [_P, ctypes.POINTER(ctypes.c_int)]),
+]
+SYMBOLS = [s[0] for s in _SIGNATURES]
+
+_lib = None
+
+
+class HyperballError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("hyperball error %d: %s" % (code, msg))
+        self.code = code
+
+
+def load():
+    """Load libhyperball.so (once).  Raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise HyperballError(HB_ERR_INVALID,
+                             "%s not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                             "or `make -C stract_amd/csrc` (there is no CPU fallback)" % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, res, args in _SIGNATURES:
+        fn = getattr(lib, name)  # AttributeError if the ABI lost a symbol
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def device_count():
+    n = ctypes.c_int(0)
+    load().hb_device_count(ctypes.byref(n))
+    return n.value
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(ctypes.c_void_p)
+
+
+class Context:
+    """Thin owner of an hb_ctx*; methods map 1:1 onto the C entry points."""
+
+    def __init__(self, device=-1, flags=0, chunk=0, max_passes=0, rank=0, world_size=1, rccl_id=None, tune=()):
+        self.lib = load()
+        opt = HbOptions()
+        opt.struct_size = ctypes.sizeof(HbOptions)
+        opt.device = device
+        opt.flags = flags
+        opt.chunk = chunk
+        opt.max_passes = max_passes
+        opt.rank = rank
+        opt.world_size = world_size
+        if rccl_id is not None:
+            ctypes.memmove(opt.rccl_id, bytes(rccl_id), 128)
+        for i, v in enumerate(tune):
+            opt.tune[i] = int(v)
+        h = ctypes.c_void_p()
+        rc = self.lib.hb_create(ctypes.byref(opt), ctypes.byref(h))
+        if rc != HB_OK:
+            raise HyperballError(rc, (self.lib.hb_last_error(None) or b"").decode())
+        self.h = h
+        self._keep = []
+
+    # -- plumbing
+    def _check(self, rc):
+        if rc != HB_OK:
+            raise HyperballError(rc, (self.lib.hb_last_error(self.h) or b"").decode())
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.hb_destroy(self.h)
+            self.h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- input
+    def load_edges(self, edges, node_ids=None):
+        edges = np.ascontiguousarray(edges, dtype=EDGE)
+        n = 0
+        if node_ids is not None:
+            node_ids = np.ascontiguousarray(node_ids, dtype=U128)
+            n = len(node_ids)
+        self._check(self.lib.hb_load_edges(self.h, _ptr(node_ids), n, _ptr(edges), len(edges)))
+
+    def append_edges(self, edges):
+        edges = np.ascontiguousarray(edges, dtype=EDGE)
+        self._check(self.lib.hb_append_edges(self.h, _ptr(edges), len(edges)))
+
+    def finalize(self, node_ids=None):
+        n = 0
+        if node_ids is not None:
+            node_ids = np.ascontiguousarray(node_ids, dtype=U128)
+            n = len(node_ids)
+        self._check(self.lib.hb_finalize(self.h, _ptr(node_ids), n))
+
+    def load_dense(self, sorted_ids, row_ptr, src):
+        sorted_ids = np.ascontiguousarray(sorted_ids, dtype=U128)
+        row_ptr = np.ascontiguousarray(row_ptr, dtype=np.uint64)
+        src = np.ascontiguousarray(src, dtype=np.uint32)
+        assert len(row_ptr) == len(sorted_ids) + 1
+        self._check(self.lib.hb_load_dense(self.h, _ptr(sorted_ids), len(sorted_ids), _ptr(row_ptr), _ptr(src), len(src)))
+
+    # -- compute
+    def run(self):
+        st = HbStats()
+        self._check(self.lib.hb_run(self.h, ctypes.byref(st)))
+        return st.as_dict()
+
+    def begin(self):
+        self._check(self.lib.hb_begin(self.h))
+
+    def step(self):
+        has = ctypes.c_int(0)
+        self._check(self.lib.hb_step(self.h, ctypes.byref(has)))
+        return bool(has.value)
+
+    def step_local(self):
+        self._check(self.lib.hb_step_local(self.h))
+
+    def step_finish(self):
+        has = ctypes.c_int(0)
+        self._check(self.lib.hb_step_finish(self.h, ctypes.byref(has)))
+        return bool(has.value)
+
+    def merge_pending(self, other):
+        self._check(self.lib.hb_debug_merge_pending(self.h, other.h))
+
+    def finish(self):
+        self._check(self.lib.hb_finish(self.h))
+
+    def stats(self):
+        st = HbStats()
+        self._check(self.lib.hb_get_stats(self.h, ctypes.byref(st)))
+        return st.as_dict()
+
+    def pass_stats(self):
+        out = []
+        t = 0
+        while True:
+            ps = HbPassStats()
+            if self.lib.hb_get_pass_stats(self.h, t, ctypes.byref(ps)) != HB_OK:
+                break
+            out.append(ps.as_dict())
+            t += 1
+        return out
+
+    def synchronize(self):
+        self._check(self.lib.hb_device_synchronize(self.h))
+
+    def device_name(self):
+        buf = ctypes.create_string_buffer(64)
+        self._check(self.lib.hb_device_name(self.h, buf, 64))
+        return buf.value.decode()
+
+    # -- results
+    def results(self):
+        k = ctypes.c_uint64(0)
+        self._check(self.lib.hb_result_count(self.h, ctypes.byref(k)))
+        ids = np.zeros(k.value, dtype=U128)
+        vals = np.zeros(k.value, dtype=np.float64)
+        self._check(self.lib.hb_result_copy(self.h, _ptr(ids), _ptr(vals), k.value))
+        return ids, vals
+
+    # -- debug exports
+    def n(self):
+        return self.stats()["n"]
+
+    def registers(self):
+        out = np.zeros((self.n(), 64), dtype=np.uint8)
+        self._check(self.lib.hb_debug_copy_registers(self.h, _ptr(out)))
+        return out
+
+    def kahan(self):
+        n = self.n()
+        s = np.zeros(n, dtype=np.float64)
+        e = np.zeros(n, dtype=np.float64)
+        self._check(self.lib.hb_debug_copy_kahan(self.h, _ptr(s), _ptr(e)))
+        return s, e
+
+    def sizes(self):
+        out = np.zeros(self.n(), dtype=np.uint64)
+        self._check(self.lib.hb_debug_copy_sizes(self.h, _ptr(out)))
+        return out
+
+    def hll_size(self, regs):
+        regs = np.ascontiguousarray(regs, dtype=np.uint8).reshape(-1, 64)
+        out = np.zeros(len(regs), dtype=np.uint64)
+        self._check(self.lib.hb_debug_hll_size(self.h, _ptr(regs), len(regs), _ptr(out)))
+        return out
+
+    def graph(self):
+        st = self.stats()
+        ids = np.zeros(st["n"], dtype=U128)
+        row_ptr = np.zeros(st["n"] + 1, dtype=np.uint64)
+        src = np.zeros(st["m_eff"], dtype=np.uint32)
+        self._check(self.lib.hb_debug_copy_graph(self.h, _ptr(ids), _ptr(row_ptr), _ptr(src)))
+        return ids, row_ptr, src
+
+
+def rccl_unique_id():
+    buf = (ctypes.c_uint8 * 128)()
+    rc = load().hb_rccl_unique_id(buf)
+    if rc != HB_OK:
+        raise HyperballError(rc, (load().hb_last_error(None) or b"").decode())
+    return bytes(buf)

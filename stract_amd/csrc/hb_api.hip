@@ -1,0 +1,846 @@
+// hb_api.hip - C ABI (include/hyperball.h) + pass driver of the HyperBall library.
+//
+// Replaces HarmonicCentrality::calculate / calculate_centrality
+// (crates/core/src/webgraph/centrality/harmonic.rs:215-287,292) behind a C boundary.
+// Host orchestration only: every arithmetic step of the path runs in the gfx950 kernels
+// of hb_kernels.hip.h.  There is no CPU fallback.
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "hb_internal.h"
+#include "hb_kernels.hip.h"
+#include "hll64_tables.inc"
+
+using namespace hb;
+
+namespace {
+thread_local std::string g_create_error;
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t bytes = 0;
+};
+} // namespace
+
+struct hb_ctx {
+    hb_options opt{};
+    int device = 0;
+    int num_cu = 256;
+    hipStream_t stream = nullptr;
+    ncclComm_t comm = nullptr;
+    std::string err;
+    std::string arch;
+
+    // host-side graph / plan
+    std::vector<hb_edge> pending;  // hb_append_edges
+    DenseGraph g;                  // ids kept; row_ptr/src kept only for hb_debug_copy_graph
+    Plan plan;
+    bool loaded = false, begun = false, finished = false;
+
+    // device
+    std::vector<DevBuf> allocs;
+    uint64_t *d_row_ptr = nullptr;
+    uint32_t *d_src = nullptr;
+    uint4 *d_regs[2] = {nullptr, nullptr};
+    uint4 *d_part = nullptr;
+    uint32_t *d_bits[2] = {nullptr, nullptr};
+    uint32_t *d_kdirty = nullptr;
+    double *d_ksum = nullptr, *d_kerr = nullptr;
+    uint64_t *d_size = nullptr;
+    uint64_t *d_idlow = nullptr;
+    uint32_t *d_dev_of = nullptr;
+    unsigned long long *d_counters = nullptr; // max_passes * 4
+    double *d_raw = nullptr, *d_bias = nullptr;
+    uint8_t *d_lc = nullptr;
+    unsigned long long *h_counters = nullptr; // pinned, 4 words
+    uint64_t bits_words = 0;
+    uint64_t ksum_len = 0; // entries allocated for ksum (world * slice in RCCL mode)
+    uint64_t slice_rows = 0;
+
+    // loop state
+    uint64_t t = 0;
+    int cur = 0; // d_regs[cur] = "old"
+    bool has_changes = false;
+    bool pending_local = false; // between hb_step_local and hb_step_finish
+    uint64_t last_changed = 0;
+    uint32_t max_passes = 4096;
+    std::vector<hb_pass_stats> pstats;
+    hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    uint32_t cur_mode = 0;
+
+    hb_stats stats{};
+    std::vector<hb_u128> res_ids;
+    std::vector<double> res_vals;
+};
+
+namespace {
+
+int fail(hb_ctx *c, int code, const std::string &msg)
+{
+    if (c) c->err = msg;
+    else g_create_error = msg;
+    return code;
+}
+
+#define HB_HIP(call)                                                                              \
+    do {                                                                                          \
+        hipError_t e_ = (call);                                                                   \
+        if (e_ != hipSuccess)                                                                     \
+            return fail(c, HB_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_));        \
+    } while (0)
+
+#define HB_NCCL(call)                                                                             \
+    do {                                                                                          \
+        ncclResult_t r_ = (call);                                                                 \
+        if (r_ != ncclSuccess)                                                                    \
+            return fail(c, HB_ERR_RCCL, std::string(#call) + ": " + ncclGetErrorString(r_));      \
+    } while (0)
+
+template <typename T>
+int dev_alloc(hb_ctx *c, T **out, size_t count)
+{
+    size_t bytes = std::max<size_t>(count * sizeof(T), 256);
+    void *p = nullptr;
+    hipError_t e = hipMalloc(&p, bytes);
+    if (e != hipSuccess)
+        return fail(c, HB_ERR_NOMEM, "hipMalloc(" + std::to_string(bytes) + " bytes): " + hipGetErrorString(e));
+    c->allocs.push_back({p, bytes});
+    c->stats.device_bytes += bytes;
+    *out = (T *)p;
+    return HB_OK;
+}
+
+void free_graph_buffers(hb_ctx *c)
+{
+    for (auto &b : c->allocs) (void)hipFree(b.p);
+    c->allocs.clear();
+    c->stats.device_bytes = 0;
+    c->d_row_ptr = nullptr;
+    c->d_src = nullptr;
+    c->d_regs[0] = c->d_regs[1] = nullptr;
+    c->d_part = nullptr;
+    c->d_bits[0] = c->d_bits[1] = nullptr;
+    c->d_kdirty = nullptr;
+    c->d_ksum = c->d_kerr = nullptr;
+    c->d_size = nullptr;
+    c->d_idlow = nullptr;
+    c->d_dev_of = nullptr;
+    c->d_counters = nullptr;
+    c->d_raw = c->d_bias = nullptr;
+    c->d_lc = nullptr;
+}
+
+bool edge_partitioned(const hb_ctx *c) { return c->opt.world_size > 1; }
+bool unfused(const hb_ctx *c) { return edge_partitioned(c) || (c->opt.flags & HB_FLAG_UNFUSED); }
+
+// ---- plan + upload (common tail of every load entry point) -------------------------------
+int plan_and_upload(hb_ctx *c)
+{
+    const uint64_t n = c->g.ids.size();
+    c->loaded = false;
+    c->begun = c->finished = false;
+    free_graph_buffers(c);
+    c->stats.n = n;
+    c->stats.m_input = c->g.m_input;
+    c->stats.m_unique = c->g.m_unique;
+    c->stats.m_eff = n ? c->g.row_ptr[n] : 0;
+    double t0 = now_ms();
+    // global out-degree (device order must be identical on every rank)
+    std::vector<uint32_t> outdeg;
+    bool reorder = !(c->opt.flags & HB_FLAG_NO_REORDER);
+    if (edge_partitioned(c) && !c->comm) reorder = false; // logical ranks without a communicator
+    if (reorder) {
+        count_out_degree(c->g.row_ptr.data(), c->g.src.data(), n, &outdeg);
+        if (c->comm && n) {
+            uint32_t *d_deg = nullptr;
+            HB_HIP(hipMalloc((void **)&d_deg, n * sizeof(uint32_t)));
+            hipError_t e = hipMemcpyAsync(d_deg, outdeg.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream);
+            ncclResult_t r = ncclSuccess;
+            if (e == hipSuccess) r = ncclAllReduce(d_deg, d_deg, n, ncclUint32, ncclSum, c->comm, c->stream);
+            if (e == hipSuccess && r == ncclSuccess)
+                e = hipMemcpyAsync(outdeg.data(), d_deg, n * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+            (void)hipFree(d_deg);
+            if (r != ncclSuccess) return fail(c, HB_ERR_RCCL, std::string("out-degree all-reduce: ") + ncclGetErrorString(r));
+            if (e != hipSuccess) return fail(c, HB_ERR_HIP, std::string("out-degree all-reduce: ") + hipGetErrorString(e));
+        }
+    }
+    uint32_t chunk = c->opt.chunk ? c->opt.chunk : kDefaultChunk;
+    std::string perr = build_plan(n, c->g.row_ptr.data(), c->g.src.data(), outdeg, reorder, chunk, &c->plan);
+    if (!perr.empty()) return fail(c, perr.find("memory") != std::string::npos ? HB_ERR_NOMEM : HB_ERR_LIMIT, perr);
+    c->stats.ms_plan = now_ms() - t0;
+    const Plan &p = c->plan;
+    c->stats.work_rows = p.n_pad + p.nv;
+    c->stats.virtual_rows = p.nv;
+
+    // ---- device memory
+    t0 = now_ms();
+    const uint64_t rows_total = p.n_pad + p.nv;
+    c->bits_words = (rows_total + 31) / 32 + 2;
+    int rc;
+    if ((rc = dev_alloc(c, &c->d_row_ptr, rows_total + 1))) return rc;
+    if ((rc = dev_alloc(c, &c->d_src, p.src.size() + 4))) return rc;
+    if ((rc = dev_alloc(c, &c->d_regs[0], p.n_pad * 4))) return rc;
+    if ((rc = dev_alloc(c, &c->d_regs[1], p.n_pad * 4))) return rc;
+    if ((rc = dev_alloc(c, &c->d_part, p.nv * 4))) return rc;
+    if ((rc = dev_alloc(c, &c->d_bits[0], c->bits_words))) return rc;
+    if ((rc = dev_alloc(c, &c->d_bits[1], c->bits_words))) return rc;
+    if ((rc = dev_alloc(c, &c->d_kdirty, p.n_pad / 32 + 2))) return rc;
+    // Kahan ownership: one contiguous slice of rows per rank (multiple of 64 rows)
+    const uint64_t world = c->comm ? (uint64_t)c->opt.world_size : 1;
+    c->slice_rows = ((p.n_pad + world - 1) / world + 63) / 64 * 64;
+    c->ksum_len = std::max<uint64_t>(c->slice_rows * world, p.n_pad);
+    if ((rc = dev_alloc(c, &c->d_ksum, c->ksum_len))) return rc;
+    if ((rc = dev_alloc(c, &c->d_kerr, p.n_pad))) return rc;
+    if ((rc = dev_alloc(c, &c->d_size, p.n_pad))) return rc;
+    if ((rc = dev_alloc(c, &c->d_idlow, p.n_pad))) return rc;
+    if ((rc = dev_alloc(c, &c->d_dev_of, n))) return rc;
+    if ((rc = dev_alloc(c, &c->d_counters, (size_t)c->max_passes * 4))) return rc;
+    if ((rc = dev_alloc(c, &c->d_raw, HLL64_TABLE_LEN))) return rc;
+    if ((rc = dev_alloc(c, &c->d_bias, HLL64_TABLE_LEN))) return rc;
+    if ((rc = dev_alloc(c, &c->d_lc, 68))) return rc;
+
+    uint8_t lc[68];
+    if (!build_lc_table(lc)) return fail(c, HB_ERR_INVALID, "host libm log() too close to a rounding boundary for the linear-counting table");
+    HB_HIP(hipMemcpyAsync(c->d_raw, HLL64_RAW_ESTIMATE, sizeof(HLL64_RAW_ESTIMATE), hipMemcpyHostToDevice, c->stream));
+    HB_HIP(hipMemcpyAsync(c->d_bias, HLL64_BIAS, sizeof(HLL64_BIAS), hipMemcpyHostToDevice, c->stream));
+    HB_HIP(hipMemcpyAsync(c->d_lc, lc, 68, hipMemcpyHostToDevice, c->stream));
+    HB_HIP(hipMemcpyAsync(c->d_row_ptr, p.row_ptr.data(), (rows_total + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
+    if (!p.src.empty())
+        HB_HIP(hipMemcpyAsync(c->d_src, p.src.data(), p.src.size() * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+    std::vector<uint64_t> idlow(p.n_pad, 0);
+    for (uint64_t d = 0; d < n; d++) idlow[d] = c->g.ids[p.order[d]].lo;
+    HB_HIP(hipMemcpyAsync(c->d_idlow, idlow.data(), p.n_pad * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
+    if (n) HB_HIP(hipMemcpyAsync(c->d_dev_of, p.dev_of.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+    HB_HIP(hipStreamSynchronize(c->stream));
+    // the plan's big host arrays are no longer needed
+    std::vector<uint64_t>().swap(c->plan.row_ptr);
+    std::vector<uint32_t>().swap(c->plan.src);
+    c->stats.ms_h2d = now_ms() - t0;
+    c->loaded = true;
+    return HB_OK;
+}
+
+// ---- kernel dispatch ----------------------------------------------------------------------
+template <bool REAL, bool FRONTIER, bool FUSED>
+void launch_pass_u(hb_ctx *c, const hbk::PassParams &pp, bool stats, int unroll, dim3 grid)
+{
+    hipStream_t s = c->stream;
+#define HB_LAUNCH(ST, UN) hipLaunchKernelGGL((hbk::pass_kernel<REAL, FRONTIER, FUSED, ST, UN>), grid, dim3(256), 0, s, pp)
+    if (stats) {
+        if (unroll == 1) HB_LAUNCH(true, 1);
+        else if (unroll == 2) HB_LAUNCH(true, 2);
+        else HB_LAUNCH(true, 4);
+    } else {
+        if (unroll == 1) HB_LAUNCH(false, 1);
+        else if (unroll == 2) HB_LAUNCH(false, 2);
+        else HB_LAUNCH(false, 4);
+    }
+#undef HB_LAUNCH
+}
+
+void launch_pass(hb_ctx *c, const hbk::PassParams &pp, bool real, bool frontier, bool fused)
+{
+    const bool stats = (c->opt.flags & HB_FLAG_PASS_STATS) != 0;
+    int unroll = (int)c->opt.tune[1];
+    if (unroll != 1 && unroll != 2 && unroll != 4) unroll = 2;
+    const uint64_t ntiles = (pp.row_hi - pp.row_lo + 63) / 64;
+    if (ntiles == 0) return;
+    uint32_t bpc = c->opt.tune[0] ? c->opt.tune[0] : 8;
+    uint64_t blocks = std::min<uint64_t>(ntiles, (uint64_t)c->num_cu * bpc);
+    dim3 grid((unsigned)blocks);
+    if (real) {
+        if (frontier) {
+            if (fused) launch_pass_u<true, true, true>(c, pp, stats, unroll, grid);
+            else launch_pass_u<true, true, false>(c, pp, stats, unroll, grid);
+        } else {
+            if (fused) launch_pass_u<true, false, true>(c, pp, stats, unroll, grid);
+            else launch_pass_u<true, false, false>(c, pp, stats, unroll, grid);
+        }
+    } else {
+        if (frontier) launch_pass_u<false, true, false>(c, pp, stats, unroll, grid);
+        else launch_pass_u<false, false, false>(c, pp, stats, unroll, grid);
+    }
+}
+
+hbk::PassParams make_params(hb_ctx *c)
+{
+    const Plan &p = c->plan;
+    hbk::PassParams pp{};
+    pp.row_ptr = c->d_row_ptr;
+    pp.src = c->d_src;
+    pp.rd = c->d_regs[c->cur];
+    pp.wr = c->d_regs[c->cur ^ 1];
+    pp.part = c->d_part;
+    pp.bits_rd = c->d_bits[c->cur];
+    pp.bits_wr = c->d_bits[c->cur ^ 1];
+    pp.kdirty = c->d_kdirty;
+    pp.ksum = c->d_ksum;
+    pp.kerr = c->d_kerr;
+    pp.size = c->d_size;
+    pp.counters = c->d_counters + 4 * c->t;
+    pp.raw = c->d_raw;
+    pp.bias = c->d_bias;
+    pp.lc = c->d_lc;
+    pp.n = p.n;
+    pp.n_pad = p.n_pad;
+    if (c->comm) {
+        pp.slice_lo = (uint64_t)c->opt.rank * c->slice_rows;
+        pp.slice_hi = std::min<uint64_t>(pp.slice_lo + c->slice_rows, p.n_pad);
+    } else {
+        pp.slice_lo = 0;
+        pp.slice_hi = p.n_pad;
+    }
+    pp.t_plus_1 = (double)(c->t + 1);
+    return pp;
+}
+
+int step_local(hb_ctx *c)
+{
+    if (!c->begun || c->finished) return fail(c, HB_ERR_INVALID, "hb_step*: call hb_begin first");
+    if (c->pending_local) return fail(c, HB_ERR_INVALID, "hb_step_local called twice");
+    if (c->t >= c->max_passes) return fail(c, HB_ERR_LIMIT, "max_passes exceeded");
+    const Plan &p = c->plan;
+    // mode: dense while most nodes still change (the frontier test would only cost), frontier after
+    uint32_t thr = c->opt.tune[2] ? c->opt.tune[2] : 25; // percent of nodes changed in the previous pass
+    bool frontier = !(c->opt.flags & HB_FLAG_NO_FRONTIER) && c->t > 0 &&
+                    (c->last_changed * 100ull < (uint64_t)thr * p.n);
+    c->cur_mode = frontier ? 1 : 0;
+    const bool fused = !unfused(c);
+    hbk::PassParams pp = make_params(c);
+    HB_HIP(hipEventRecord(c->ev[0], c->stream));
+    for (size_t l = 0; l + 1 < p.level_begin.size(); l++) {
+        pp.row_lo = p.level_begin[l];
+        pp.row_hi = p.level_begin[l + 1];
+        launch_pass(c, pp, false, frontier, false);
+    }
+    HB_HIP(hipEventRecord(c->ev[1], c->stream));
+    pp.row_lo = 0;
+    pp.row_hi = p.n_pad;
+    launch_pass(c, pp, true, frontier, fused);
+    HB_HIP(hipEventRecord(c->ev[2], c->stream));
+    HB_HIP(hipGetLastError());
+    c->pending_local = true;
+    return HB_OK;
+}
+
+int step_finish(hb_ctx *c, int *has_changes)
+{
+    if (!c->pending_local) return fail(c, HB_ERR_INVALID, "hb_step_finish without hb_step_local");
+    const Plan &p = c->plan;
+    float ms_coll = 0.f;
+    if (unfused(c)) {
+        hbk::PassParams pp = make_params(c);
+        pp.row_lo = 0;
+        pp.row_hi = p.n_pad;
+        if (c->comm) {
+            HB_NCCL(ncclAllReduce(pp.wr, pp.wr, p.n_pad * 64, ncclUint8, ncclMax, c->comm, c->stream));
+        }
+        HB_HIP(hipEventRecord(c->ev[3], c->stream));
+        const uint64_t ntiles = p.n_pad / 64;
+        if (ntiles) {
+            uint32_t bpc = c->opt.tune[0] ? c->opt.tune[0] : 8;
+            uint64_t blocks = std::min<uint64_t>(ntiles, (uint64_t)c->num_cu * bpc);
+            hipLaunchKernelGGL(hbk::epilogue_kernel, dim3((unsigned)blocks), dim3(256), 0, c->stream, pp);
+        }
+        HB_HIP(hipGetLastError());
+    }
+    hipEvent_t ev_end = c->ev[2];
+    if (unfused(c)) {
+        // events: [0] start, [1] after virtual levels, [2] after local merge, [3] after collective,
+        // [4] after the epilogue
+        HB_HIP(hipEventRecord(c->ev[4], c->stream));
+        ev_end = c->ev[4];
+    }
+    HB_HIP(hipMemcpyAsync(c->h_counters, c->d_counters + 4 * c->t, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+    HB_HIP(hipStreamSynchronize(c->stream));
+    if (unfused(c)) HB_HIP(hipEventElapsedTime(&ms_coll, c->ev[2], c->ev[3]));
+    hb_pass_stats ps{};
+    ps.pass = c->t;
+    ps.changed = c->h_counters[0];
+    ps.active_edges = c->h_counters[1];
+    ps.touched = c->h_counters[2];
+    ps.mode = c->cur_mode;
+    float ms_all = 0.f, ms_main = 0.f;
+    HB_HIP(hipEventElapsedTime(&ms_all, c->ev[0], ev_end));
+    HB_HIP(hipEventElapsedTime(&ms_main, c->ev[1], c->ev[2]));
+    ps.ms_gpu = ms_all;
+    ps.ms_main = ms_main;
+    ps.ms_collective = c->comm ? ms_coll : 0.f;
+    c->pstats.push_back(ps);
+    // counters.step(); changed_nodes = new_changed_nodes; t += 1 (harmonic.rs:273-275)
+    c->last_changed = ps.changed;
+    c->has_changes = ps.changed != 0;
+    c->cur ^= 1;
+    c->t += 1;
+    c->pending_local = false;
+    if (has_changes) *has_changes = c->has_changes ? 1 : 0;
+    return HB_OK;
+}
+
+int set_device(hb_ctx *c)
+{
+    HB_HIP(hipSetDevice(c->device));
+    return HB_OK;
+}
+
+} // namespace
+
+// =============================================================================================
+extern "C" {
+
+int hb_abi_version(void) { return HB_ABI_VERSION; }
+
+const char *hb_last_error(const hb_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+int hb_device_count(int *count)
+{
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) n = 0;
+    if (count) *count = n;
+    return HB_OK;
+}
+
+int hb_rccl_unique_id(uint8_t out[128])
+{
+    hb_ctx *c = nullptr;
+    if (!out) return fail(c, HB_ERR_INVALID, "out == NULL");
+    static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId size");
+    ncclUniqueId id;
+    HB_NCCL(ncclGetUniqueId(&id));
+    std::memcpy(out, &id, 128);
+    return HB_OK;
+}
+
+int hb_create(const hb_options *opt, hb_ctx **out)
+{
+    hb_ctx *c = nullptr; // errors before the ctx exists go to the thread-local slot
+    if (!out) return fail(c, HB_ERR_INVALID, "out == NULL");
+    *out = nullptr;
+    hb_options o{};
+    if (opt) {
+        size_t sz = opt->struct_size ? std::min<size_t>(opt->struct_size, sizeof(hb_options)) : sizeof(hb_options);
+        std::memcpy(&o, opt, sz);
+    } else {
+        o.device = -1;
+    }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(c, HB_ERR_NO_DEVICE, "no HIP device visible: this library has no CPU fallback");
+    int dev = o.device;
+    if (dev < 0) {
+        if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+    }
+    if (dev >= ndev) return fail(c, HB_ERR_INVALID, "device ordinal out of range");
+    hipDeviceProp_t prop;
+    HB_HIP(hipGetDeviceProperties(&prop, dev));
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(c, HB_ERR_NO_DEVICE, std::string("device is ") + prop.gcnArchName + ", kernels are built for gfx950 only");
+    if (o.world_size > 1 && (o.rank < 0 || o.rank >= o.world_size)) return fail(c, HB_ERR_INVALID, "rank out of range");
+    hb_ctx *ctx = new (std::nothrow) hb_ctx();
+    if (!ctx) return fail(c, HB_ERR_NOMEM, "out of host memory");
+    ctx->opt = o;
+    ctx->device = dev;
+    ctx->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    ctx->arch = prop.gcnArchName;
+    ctx->max_passes = o.max_passes ? o.max_passes : 4096;
+    c = ctx;
+    auto bail = [&](int code) {
+        std::string m = ctx->err;
+        hb_destroy(ctx);
+        g_create_error = m;
+        return code;
+    };
+    if (hipSetDevice(dev) != hipSuccess) { ctx->err = "hipSetDevice failed"; return bail(HB_ERR_HIP); }
+    if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { ctx->err = "hipStreamCreate failed"; return bail(HB_ERR_HIP); }
+    for (int i = 0; i < 5; i++)
+        if (hipEventCreate(&ctx->ev[i]) != hipSuccess) { ctx->err = "hipEventCreate failed"; return bail(HB_ERR_HIP); }
+    if (hipHostMalloc((void **)&ctx->h_counters, 4 * sizeof(unsigned long long)) != hipSuccess) { ctx->err = "hipHostMalloc failed"; return bail(HB_ERR_NOMEM); }
+    if (o.world_size > 1 && !(o.flags & HB_FLAG_NO_RCCL)) {
+        ncclUniqueId id;
+        std::memcpy(&id, o.rccl_id, 128);
+        ncclResult_t r = ncclCommInitRank(&ctx->comm, o.world_size, id, o.rank);
+        if (r != ncclSuccess) { ctx->err = std::string("ncclCommInitRank: ") + ncclGetErrorString(r); ctx->comm = nullptr; return bail(HB_ERR_RCCL); }
+    } else if (o.world_size == 1 && (o.flags & HB_FLAG_RCCL_SELF)) {
+        ncclUniqueId id;
+        std::memcpy(&id, o.rccl_id, 128);
+        ncclResult_t r = ncclCommInitRank(&ctx->comm, 1, id, 0);
+        if (r != ncclSuccess) { ctx->err = std::string("ncclCommInitRank: ") + ncclGetErrorString(r); ctx->comm = nullptr; return bail(HB_ERR_RCCL); }
+    }
+    *out = ctx;
+    return HB_OK;
+}
+
+void hb_destroy(hb_ctx *ctx)
+{
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->comm) (void)ncclCommDestroy(ctx->comm);
+    free_graph_buffers(ctx);
+    if (ctx->h_counters) (void)hipHostFree(ctx->h_counters);
+    for (int i = 0; i < 5; i++)
+        if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+int hb_device_name(const hb_ctx *ctx, char *name, uint64_t cap)
+{
+    if (!ctx || !name || !cap) return HB_ERR_INVALID;
+    std::snprintf(name, (size_t)cap, "%s", ctx->arch.c_str());
+    return HB_OK;
+}
+
+int hb_device_synchronize(hb_ctx *c)
+{
+    if (!c) return HB_ERR_INVALID;
+    int rc = set_device(c);
+    if (rc) return rc;
+    HB_HIP(hipStreamSynchronize(c->stream));
+    return HB_OK;
+}
+
+// ---- input --------------------------------------------------------------------------------
+int hb_load_edges(hb_ctx *c, const hb_u128 *node_ids, uint64_t n, const hb_edge *edges, uint64_t m)
+{
+    if (!c) return HB_ERR_INVALID;
+    int rc = set_device(c);
+    if (rc) return rc;
+    c->stats = hb_stats{};
+    double t0 = now_ms();
+    std::string e = ingest_edges(node_ids, n, edges, m, &c->g);
+    if (!e.empty()) return fail(c, e.find("memory") != std::string::npos ? HB_ERR_NOMEM : HB_ERR_LIMIT, e);
+    c->stats.ms_ingest = now_ms() - t0;
+    double ing = c->stats.ms_ingest;
+    rc = plan_and_upload(c);
+    c->stats.ms_ingest = ing;
+    return rc;
+}
+
+int hb_append_edges(hb_ctx *c, const hb_edge *edges, uint64_t m)
+{
+    if (!c || (m && !edges)) return c ? fail(c, HB_ERR_INVALID, "edges == NULL") : HB_ERR_INVALID;
+    try {
+        c->pending.insert(c->pending.end(), edges, edges + m);
+    } catch (const std::bad_alloc &) {
+        return fail(c, HB_ERR_NOMEM, "out of host memory buffering edges");
+    }
+    return HB_OK;
+}
+
+int hb_finalize(hb_ctx *c, const hb_u128 *node_ids, uint64_t n)
+{
+    if (!c) return HB_ERR_INVALID;
+    int rc = hb_load_edges(c, node_ids, n, c->pending.data(), c->pending.size());
+    std::vector<hb_edge>().swap(c->pending);
+    return rc;
+}
+
+int hb_load_dense(hb_ctx *c, const hb_u128 *sorted_ids, uint64_t n, const uint64_t *row_ptr, const uint32_t *src,
+                  uint64_t m_eff)
+{
+    if (!c) return HB_ERR_INVALID;
+    int rc = set_device(c);
+    if (rc) return rc;
+    c->stats = hb_stats{};
+    double t0 = now_ms();
+    std::string e = check_dense(sorted_ids, n, row_ptr, src, m_eff);
+    if (!e.empty()) return fail(c, e.find("too many") != std::string::npos ? HB_ERR_LIMIT : HB_ERR_INVALID, e);
+    try {
+        c->g.ids.assign(sorted_ids, sorted_ids + n);
+        c->g.row_ptr.assign(row_ptr, row_ptr + n + 1);
+        if (n == 0) c->g.row_ptr.assign(1, 0);
+        c->g.src.assign(src, src + m_eff);
+    } catch (const std::bad_alloc &) {
+        return fail(c, HB_ERR_NOMEM, "out of host memory copying the graph");
+    }
+    c->g.m_input = m_eff;
+    c->g.m_unique = m_eff;
+    double ing = now_ms() - t0;
+    rc = plan_and_upload(c);
+    c->stats.ms_ingest = ing;
+    return rc;
+}
+
+// ---- compute ------------------------------------------------------------------------------
+int hb_begin(hb_ctx *c)
+{
+    if (!c) return HB_ERR_INVALID;
+    if (!c->loaded) return fail(c, HB_ERR_INVALID, "hb_begin: no graph loaded");
+    int rc = set_device(c);
+    if (rc) return rc;
+    const Plan &p = c->plan;
+    HB_HIP(hipMemsetAsync(c->d_part, 0, std::max<size_t>(p.nv * 64, 256), c->stream));
+    HB_HIP(hipMemsetAsync(c->d_bits[0], 0, c->bits_words * 4, c->stream));
+    HB_HIP(hipMemsetAsync(c->d_bits[1], 0, c->bits_words * 4, c->stream));
+    HB_HIP(hipMemsetAsync(c->d_counters, 0, (size_t)c->max_passes * 4 * sizeof(unsigned long long), c->stream));
+    HB_HIP(hipMemsetAsync(c->d_ksum, 0, c->ksum_len * sizeof(double), c->stream));
+    if (p.n_pad) {
+        unsigned blocks = (unsigned)((p.n_pad * 4 + 255) / 256);
+        hipLaunchKernelGGL(hbk::init_kernel, dim3(blocks), dim3(256), 0, c->stream, c->d_idlow, p.n, p.n_pad,
+                           c->d_regs[0], c->d_regs[1], c->d_ksum, c->d_kerr, c->d_size, c->d_bits[0], c->d_kdirty,
+                           c->d_raw, c->d_bias, c->d_lc);
+        HB_HIP(hipGetLastError());
+    }
+    HB_HIP(hipStreamSynchronize(c->stream));
+    c->t = 0;
+    c->cur = 0;
+    c->has_changes = true; // harmonic.rs:232
+    c->last_changed = p.n;
+    c->pending_local = false;
+    c->pstats.clear();
+    c->begun = true;
+    c->finished = false;
+    c->res_ids.clear();
+    c->res_vals.clear();
+    return HB_OK;
+}
+
+int hb_step_local(hb_ctx *c)
+{
+    if (!c) return HB_ERR_INVALID;
+    int rc = set_device(c);
+    if (rc) return rc;
+    return step_local(c);
+}
+
+int hb_step_finish(hb_ctx *c, int *has_changes)
+{
+    if (!c) return HB_ERR_INVALID;
+    int rc = set_device(c);
+    if (rc) return rc;
+    return step_finish(c, has_changes);
+}
+
+int hb_step(hb_ctx *c, int *has_changes)
+{
+    if (!c) return HB_ERR_INVALID;
+    int rc = set_device(c);
+    if (rc) return rc;
+    if ((rc = step_local(c))) return rc;
+    return step_finish(c, has_changes);
+}
+
+int hb_finish(hb_ctx *c)
+{
+    if (!c) return HB_ERR_INVALID;
+    if (!c->begun) return fail(c, HB_ERR_INVALID, "hb_finish: call hb_begin first");
+    int rc = set_device(c);
+    if (rc) return rc;
+    const Plan &p = c->plan;
+    double t0 = now_ms();
+    if (c->comm && p.n_pad) {
+        // every rank ends with all Kahan sums: in-place all-gather of the owned slices
+        HB_NCCL(ncclAllGather(c->d_ksum + (uint64_t)c->opt.rank * c->slice_rows, c->d_ksum, c->slice_rows, ncclDouble,
+                              c->comm, c->stream));
+    }
+    std::vector<double> ksum(p.n_pad ? p.n_pad : 1);
+    if (p.n_pad) HB_HIP(hipMemcpyAsync(ksum.data(), c->d_ksum, p.n_pad * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HB_HIP(hipStreamSynchronize(c->stream));
+    // normalize_centralities (harmonic.rs:178-195); norm_factor = (num_nodes - 1) as f64 (:229)
+    c->res_ids.clear();
+    c->res_vals.clear();
+    const double norm = (double)(p.n ? p.n - 1 : 0);
+    try {
+        for (uint64_t sid = 0; sid < p.n; sid++) {
+            double s = ksum[p.dev_of[sid]]; // f64::from(KahanSum) = sum (kahan_sum.rs:35-39)
+            if (!(s > 0.0)) continue;
+            double v = s / norm;
+            if (!std::isfinite(v)) v = 0.0;
+            c->res_ids.push_back(c->g.ids[sid]);
+            c->res_vals.push_back(v);
+        }
+    } catch (const std::bad_alloc &) {
+        return fail(c, HB_ERR_NOMEM, "out of host memory collecting results");
+    }
+    c->stats.ms_d2h = now_ms() - t0;
+    c->stats.results = c->res_ids.size();
+    c->stats.passes = c->t;
+    double g = 0, coll = 0;
+    for (auto &ps : c->pstats) { g += ps.ms_gpu; coll += ps.ms_collective; }
+    c->stats.ms_loop_gpu = g;
+    c->stats.ms_collective = coll;
+    c->finished = true;
+    return HB_OK;
+}
+
+int hb_run(hb_ctx *c, hb_stats *stats)
+{
+    if (!c) return HB_ERR_INVALID;
+    int rc = hb_begin(c);
+    if (rc) return rc;
+    double t0 = now_ms();
+    int has = 1;
+    // harmonic.rs:237-240: loop { if !has_changes { break } ... }
+    while (has) {
+        if ((rc = hb_step(c, &has))) return rc;
+    }
+    c->stats.ms_loop = now_ms() - t0;
+    if ((rc = hb_finish(c))) return rc;
+    if (stats) *stats = c->stats;
+    return HB_OK;
+}
+
+int hb_get_stats(const hb_ctx *c, hb_stats *out)
+{
+    if (!c || !out) return HB_ERR_INVALID;
+    *out = c->stats;
+    out->passes = c->t;
+    return HB_OK;
+}
+
+int hb_get_pass_stats(const hb_ctx *c, uint64_t t, hb_pass_stats *out)
+{
+    if (!c || !out || t >= c->pstats.size()) return HB_ERR_INVALID;
+    *out = c->pstats[t];
+    return HB_OK;
+}
+
+// ---- results ------------------------------------------------------------------------------
+int hb_result_count(hb_ctx *c, uint64_t *count)
+{
+    if (!c || !count) return HB_ERR_INVALID;
+    if (!c->finished) return fail(c, HB_ERR_INVALID, "no results: hb_run / hb_finish not called");
+    *count = c->res_ids.size();
+    return HB_OK;
+}
+
+int hb_result_copy(hb_ctx *c, hb_u128 *ids, double *vals, uint64_t cap)
+{
+    if (!c) return HB_ERR_INVALID;
+    if (!c->finished) return fail(c, HB_ERR_INVALID, "no results: hb_run / hb_finish not called");
+    uint64_t k = std::min<uint64_t>(cap, c->res_ids.size());
+    if (ids && k) std::memcpy(ids, c->res_ids.data(), k * sizeof(hb_u128));
+    if (vals && k) std::memcpy(vals, c->res_vals.data(), k * sizeof(double));
+    return HB_OK;
+}
+
+// ---- debug exports ------------------------------------------------------------------------
+int hb_debug_copy_registers(hb_ctx *c, uint8_t *out)
+{
+    if (!c || !out) return HB_ERR_INVALID;
+    if (!c->begun) return fail(c, HB_ERR_INVALID, "call hb_begin first");
+    int rc = set_device(c);
+    if (rc) return rc;
+    const uint64_t n = c->plan.n;
+    if (!n) return HB_OK;
+    uint4 *tmp = nullptr;
+    HB_HIP(hipMalloc((void **)&tmp, n * 64));
+    unsigned blocks = (unsigned)((n * 4 + 255) / 256);
+    hipLaunchKernelGGL(hbk::gather_rows_kernel, dim3(blocks), dim3(256), 0, c->stream, (const uint4 *)c->d_regs[c->cur],
+                       (const uint32_t *)c->d_dev_of, n, tmp);
+    hipError_t e = hipMemcpyAsync(out, tmp, n * 64, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    (void)hipFree(tmp);
+    if (e != hipSuccess) return fail(c, HB_ERR_HIP, hipGetErrorString(e));
+    return HB_OK;
+}
+
+int hb_debug_copy_kahan(hb_ctx *c, double *sum, double *err)
+{
+    if (!c) return HB_ERR_INVALID;
+    if (!c->begun) return fail(c, HB_ERR_INVALID, "call hb_begin first");
+    int rc = set_device(c);
+    if (rc) return rc;
+    const Plan &p = c->plan;
+    std::vector<double> tmp(p.n_pad ? p.n_pad : 1);
+    for (int k = 0; k < 2; k++) {
+        double *dst = k ? err : sum;
+        if (!dst || !p.n_pad) continue;
+        HB_HIP(hipMemcpyAsync(tmp.data(), k ? c->d_kerr : c->d_ksum, p.n_pad * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        HB_HIP(hipStreamSynchronize(c->stream));
+        for (uint64_t sid = 0; sid < p.n; sid++) dst[sid] = tmp[p.dev_of[sid]];
+    }
+    return HB_OK;
+}
+
+int hb_debug_copy_sizes(hb_ctx *c, uint64_t *out)
+{
+    if (!c || !out) return HB_ERR_INVALID;
+    if (!c->begun) return fail(c, HB_ERR_INVALID, "call hb_begin first");
+    int rc = set_device(c);
+    if (rc) return rc;
+    const Plan &p = c->plan;
+    if (!p.n_pad) return HB_OK;
+    std::vector<uint64_t> tmp(p.n_pad);
+    HB_HIP(hipMemcpyAsync(tmp.data(), c->d_size, p.n_pad * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+    HB_HIP(hipStreamSynchronize(c->stream));
+    for (uint64_t sid = 0; sid < p.n; sid++) out[sid] = tmp[p.dev_of[sid]];
+    return HB_OK;
+}
+
+int hb_debug_hll_size(hb_ctx *c, const uint8_t *regs, uint64_t count, uint64_t *out)
+{
+    if (!c || (count && (!regs || !out))) return HB_ERR_INVALID;
+    int rc = set_device(c);
+    if (rc) return rc;
+    if (!count) return HB_OK;
+    // tables may not be on the device yet (no graph loaded): stage private copies
+    double *d_raw = nullptr, *d_bias = nullptr;
+    uint8_t *d_lc = nullptr, *d_regs = nullptr;
+    uint64_t *d_out = nullptr;
+    uint8_t lc[68];
+    if (!build_lc_table(lc)) return fail(c, HB_ERR_INVALID, "linear-counting table not robust on this libm");
+    const uint64_t rows_pad = (count + 15) & ~15ull;
+    hipError_t e = hipMalloc((void **)&d_raw, sizeof(HLL64_RAW_ESTIMATE));
+    if (e == hipSuccess) e = hipMalloc((void **)&d_bias, sizeof(HLL64_BIAS));
+    if (e == hipSuccess) e = hipMalloc((void **)&d_lc, 256);
+    if (e == hipSuccess) e = hipMalloc((void **)&d_regs, rows_pad * 64);
+    if (e == hipSuccess) e = hipMalloc((void **)&d_out, rows_pad * 8);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_raw, HLL64_RAW_ESTIMATE, sizeof(HLL64_RAW_ESTIMATE), hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_bias, HLL64_BIAS, sizeof(HLL64_BIAS), hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_lc, lc, 68, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_regs, regs, count * 64, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) {
+        unsigned blocks = (unsigned)((rows_pad * 4 + 255) / 256);
+        hipLaunchKernelGGL(hbk::hll_size_kernel, dim3(blocks), dim3(256), 0, c->stream, (const uint4 *)d_regs, count, d_out,
+                           (const double *)d_raw, (const double *)d_bias, (const uint8_t *)d_lc);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(out, d_out, count * 8, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    (void)hipFree(d_raw); (void)hipFree(d_bias); (void)hipFree(d_lc); (void)hipFree(d_regs); (void)hipFree(d_out);
+    if (e != hipSuccess) return fail(c, HB_ERR_HIP, hipGetErrorString(e));
+    return HB_OK;
+}
+
+int hb_debug_copy_graph(hb_ctx *c, hb_u128 *ids, uint64_t *row_ptr, uint32_t *src)
+{
+    if (!c) return HB_ERR_INVALID;
+    if (!c->loaded) return fail(c, HB_ERR_INVALID, "no graph loaded");
+    const uint64_t n = c->g.ids.size();
+    if (ids && n) std::memcpy(ids, c->g.ids.data(), n * sizeof(hb_u128));
+    if (row_ptr) std::memcpy(row_ptr, c->g.row_ptr.data(), (n + 1) * sizeof(uint64_t));
+    if (src && !c->g.src.empty()) std::memcpy(src, c->g.src.data(), c->g.src.size() * sizeof(uint32_t));
+    return HB_OK;
+}
+
+int hb_debug_merge_pending(hb_ctx *c, hb_ctx *other)
+{
+    if (!c || !other) return HB_ERR_INVALID;
+    if (!c->pending_local || !other->pending_local) return fail(c, HB_ERR_INVALID, "both contexts must be between hb_step_local and hb_step_finish");
+    if (c->plan.n_pad != other->plan.n_pad || c->device != other->device) return fail(c, HB_ERR_INVALID, "contexts differ in size or device");
+    int rc = set_device(c);
+    if (rc) return rc;
+    HB_HIP(hipStreamSynchronize(other->stream));
+    HB_HIP(hipStreamSynchronize(c->stream));
+    const uint64_t count4 = c->plan.n_pad * 4;
+    if (count4) {
+        hipLaunchKernelGGL(hbk::merge_max_kernel, dim3(2048), dim3(256), 0, c->stream, c->d_regs[c->cur ^ 1],
+                           (const uint4 *)other->d_regs[other->cur ^ 1], count4);
+        HB_HIP(hipGetLastError());
+    }
+    HB_HIP(hipStreamSynchronize(c->stream));
+    return HB_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,359 @@
+// hb_host.cpp - host side of the HyperBall library: ingest (reference node/edge-set
+// semantics) and the device work-layout planner.  No GPU code here.
+//
+// Reference semantics restated (nothing is copied from it):
+//   node set   = every from_host_id / to_host_id of every record, flagged ones included
+//                (crates/core/src/webgraph/store.rs:338-357)
+//   edge set   = first record of each (from,to) pair in stream order
+//                (itertools::unique_by, store.rs:313), THEN dropped when
+//                rel_flags & SKIPPED_REL != 0 (harmonic.rs:36-49,131)
+//   node order = numeric u128 order (BTreeMap<NodeID,_>, node.rs:33-37)
+#include "hb_internal.h"
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstring>
+#include <numeric>
+
+#ifdef _OPENMP
+#include <omp.h>
+#include <parallel/algorithm>
+#define HB_SORT(b, e) __gnu_parallel::sort((b), (e))
+#define HB_SORT_CMP(b, e, c) __gnu_parallel::sort((b), (e), (c))
+#else
+#define HB_SORT(b, e) std::sort((b), (e))
+#define HB_SORT_CMP(b, e, c) std::sort((b), (e), (c))
+#endif
+
+namespace hb {
+
+double now_ms()
+{
+    using namespace std::chrono;
+    return duration<double, std::milli>(steady_clock::now().time_since_epoch()).count();
+}
+
+static inline uint64_t mix64(uint64_t x)
+{
+    x ^= x >> 33;
+    x *= 0xff51afd7ed558ccdull;
+    x ^= x >> 33;
+    x *= 0xc4ceb9fe1a85ec53ull;
+    x ^= x >> 33;
+    return x;
+}
+
+namespace {
+struct IdLess {
+    bool operator()(const hb_u128 &a, const hb_u128 &b) const { return u128_less(a, b); }
+};
+
+// id -> sid lookup (open addressing over the sorted id array)
+struct IdIndex {
+    const hb_u128 *ids = nullptr;
+    std::vector<uint32_t> slot; // sid + 1, 0 = empty
+    uint64_t mask = 0;
+    void build(const hb_u128 *a, uint64_t n)
+    {
+        ids = a;
+        uint64_t cap = 16;
+        while (cap < 2 * n + 2) cap <<= 1;
+        slot.assign(cap, 0);
+        mask = cap - 1;
+        for (uint64_t i = 0; i < n; i++) {
+            uint64_t h = mix64(a[i].lo ^ mix64(a[i].hi)) & mask;
+            while (slot[h]) h = (h + 1) & mask;
+            slot[h] = (uint32_t)i + 1;
+        }
+    }
+    inline int64_t find(const hb_u128 &k) const
+    {
+        uint64_t h = mix64(k.lo ^ mix64(k.hi)) & mask;
+        while (slot[h]) {
+            uint32_t s = slot[h] - 1;
+            if (u128_eq(ids[s], k)) return (int64_t)s;
+            h = (h + 1) & mask;
+        }
+        return -1;
+    }
+};
+
+struct KeyPos {
+    uint64_t key; // (to_sid << 32) | from_sid
+    uint64_t pos; // stream position
+    bool operator<(const KeyPos &o) const { return key != o.key ? key < o.key : pos < o.pos; }
+};
+} // namespace
+
+std::string ingest_edges(const hb_u128 *node_ids, uint64_t n_in, const hb_edge *edges, uint64_t m,
+                         DenseGraph *out)
+{
+    out->ids.clear();
+    out->row_ptr.clear();
+    out->src.clear();
+    out->m_input = m;
+    out->m_unique = 0;
+    if (m && !edges) return "edges == NULL with m > 0";
+    // ---- node set
+    std::vector<hb_u128> &ids = out->ids;
+    try {
+        if (node_ids && n_in) {
+            ids.assign(node_ids, node_ids + n_in);
+        } else {
+            ids.resize(2 * m);
+#pragma omp parallel for schedule(static)
+            for (int64_t i = 0; i < (int64_t)m; i++) {
+                ids[2 * i] = edges[i].from;
+                ids[2 * i + 1] = edges[i].to;
+            }
+        }
+        HB_SORT_CMP(ids.begin(), ids.end(), IdLess());
+        ids.erase(std::unique(ids.begin(), ids.end(), u128_eq), ids.end());
+    } catch (const std::bad_alloc &) {
+        return "out of host memory building the node set";
+    }
+    const uint64_t n = ids.size();
+    if (n >= 0xFFFFFFFFull - (1u << 20)) return "too many nodes (n must be < 2^32 - 2^20)";
+    out->row_ptr.assign(n + 1, 0);
+    if (n == 0 || m == 0) return "";
+    // ---- map endpoints, order records by (to, from, stream position)
+    std::vector<KeyPos> recs;
+    try {
+        IdIndex index;
+        index.build(ids.data(), n);
+        recs.resize(m);
+#pragma omp parallel for schedule(static)
+        for (int64_t i = 0; i < (int64_t)m; i++) {
+            int64_t f = index.find(edges[i].from), t = index.find(edges[i].to);
+            // harmonic.rs:135: `if let (Some, Some)` - records with an unknown endpoint are ignored
+            recs[i].key = (f < 0 || t < 0) ? ~0ull : (((uint64_t)t << 32) | (uint64_t)f);
+            recs[i].pos = (uint64_t)i;
+        }
+        HB_SORT(recs.begin(), recs.end());
+    } catch (const std::bad_alloc &) {
+        return "out of host memory sorting edge records";
+    }
+    // ---- first occurrence wins, then the flag filter
+    std::vector<uint64_t> &row_ptr = out->row_ptr;
+    std::vector<uint32_t> &src = out->src;
+    uint64_t m_unique = 0;
+    src.reserve(m);
+    for (uint64_t i = 0; i < m;) {
+        uint64_t key = recs[i].key;
+        if (key == ~0ull) break; // unknown-endpoint records sort last
+        uint64_t j = i + 1;
+        while (j < m && recs[j].key == key) j++;
+        m_unique++;
+        if ((edges[recs[i].pos].rel_flags & HB_SKIPPED_REL_MASK) == 0) {
+            src.push_back((uint32_t)key);
+            row_ptr[(key >> 32) + 1]++;
+        }
+        i = j;
+    }
+    for (uint64_t v = 0; v < n; v++) row_ptr[v + 1] += row_ptr[v];
+    out->m_unique = m_unique;
+    return "";
+}
+
+std::string check_dense(const hb_u128 *ids, uint64_t n, const uint64_t *row_ptr, const uint32_t *src,
+                        uint64_t m)
+{
+    if (n >= 0xFFFFFFFFull - (1u << 20)) return "too many nodes (n must be < 2^32 - 2^20)";
+    if (n && (!ids || !row_ptr)) return "NULL ids/row_ptr";
+    if (m && !src) return "NULL src";
+    if (n == 0) return m ? "edges without nodes" : "";
+    if (row_ptr[0] != 0 || row_ptr[n] != m) return "row_ptr[0] != 0 or row_ptr[n] != m_eff";
+    int bad = 0;
+#pragma omp parallel for schedule(static) reduction(| : bad)
+    for (int64_t v = 0; v < (int64_t)n; v++) {
+        if (row_ptr[v + 1] < row_ptr[v]) bad |= 1;
+        if (v > 0 && !u128_less(ids[v - 1], ids[v])) bad |= 2;
+    }
+    if (bad & 1) return "row_ptr not monotone";
+    if (bad & 2) return "sorted_ids not strictly ascending";
+#pragma omp parallel for schedule(static) reduction(| : bad)
+    for (int64_t e = 0; e < (int64_t)m; e++)
+        if (src[e] >= n) bad |= 4;
+    if (bad & 4) return "src index out of range";
+    return "";
+}
+
+void count_out_degree(const uint64_t *row_ptr, const uint32_t *src, uint64_t n, std::vector<uint32_t> *deg)
+{
+    deg->assign(n, 0);
+    const uint64_t m = n ? row_ptr[n] : 0;
+    for (uint64_t e = 0; e < m; e++) (*deg)[src[e]]++;
+}
+
+// ---------------------------------------------------------------------------------------
+// Planner.
+//
+// Device order: nodes sorted by (global) out-degree, descending - the counters that are
+// gathered most often become one contiguous, cache-resident prefix of the register array
+// (per-XCD L2 4 MiB = 64 Ki counters, Infinity Cache 256 MiB = 4 Mi counters).
+//
+// Hub splitting: a row with more than `chunk` sources is replaced by a tree of "virtual
+// rows" (partial maxima over <= chunk sources each); every level is a separate launch,
+// so the pass stays a synchronous (Jacobi) pull with one writer per row.
+// ---------------------------------------------------------------------------------------
+std::string build_plan(uint64_t n, const uint64_t *row_ptr, const uint32_t *src,
+                       const std::vector<uint32_t> &out_degree, bool reorder, uint32_t chunk, Plan *p)
+{
+    if (chunk < 4) chunk = 4;
+    if (chunk > 4096) chunk = 4096;
+    p->n = n;
+    p->n_pad = (n + kRowAlign - 1) / kRowAlign * kRowAlign;
+    p->chunk = chunk;
+    p->m_eff = n ? row_ptr[n] : 0;
+    p->order.resize(n);
+    p->dev_of.resize(n);
+    p->level_begin.clear();
+    try {
+        // ---- device order
+        if (reorder && n) {
+            std::vector<uint64_t> keys(n);
+#pragma omp parallel for schedule(static)
+            for (int64_t s = 0; s < (int64_t)n; s++)
+                keys[s] = ((uint64_t)(0xFFFFFFFFu - out_degree[s]) << 32) | (uint64_t)s;
+            HB_SORT(keys.begin(), keys.end());
+#pragma omp parallel for schedule(static)
+            for (int64_t d = 0; d < (int64_t)n; d++) p->order[d] = (uint32_t)keys[d];
+        } else {
+            std::iota(p->order.begin(), p->order.end(), 0u);
+        }
+#pragma omp parallel for schedule(static)
+        for (int64_t d = 0; d < (int64_t)n; d++) p->dev_of[p->order[d]] = (uint32_t)d;
+
+        // ---- rows in device order, sources relabelled and sorted
+        std::vector<uint64_t> rp(n + 1, 0);
+        for (uint64_t d = 0; d < n; d++) {
+            uint32_t s = p->order[d];
+            rp[d + 1] = rp[d] + (row_ptr[s + 1] - row_ptr[s]);
+        }
+        std::vector<uint32_t> rs(p->m_eff);
+#pragma omp parallel for schedule(dynamic, 1024)
+        for (int64_t d = 0; d < (int64_t)n; d++) {
+            uint32_t s = p->order[d];
+            uint64_t b = row_ptr[s], e = row_ptr[s + 1], o = rp[d];
+            for (uint64_t k = b; k < e; k++) rs[o + (k - b)] = p->dev_of[src[k]];
+            std::sort(rs.begin() + o, rs.begin() + o + (e - b));
+        }
+
+        // ---- hub splitting, level by level
+        // cur_len[d] / cur lists: the list a real row currently reads.  Level 0: its real
+        // sources (in rs).  After splitting at level l its list is a run of virtual ids.
+        struct Split { uint32_t row; uint64_t first_vid; uint32_t count; };
+        std::vector<uint64_t> vrow_ptr; // offsets of virtual rows' lists in vsrc
+        std::vector<uint32_t> vsrc;
+        vrow_ptr.push_back(0);
+        // For real rows that were split: their final (short) list of virtual ids.
+        std::vector<uint8_t> is_split(n, 0);
+        std::vector<uint64_t> split_first(n, 0);
+        std::vector<uint32_t> split_count(n, 0);
+        uint64_t next_vid = p->n_pad;
+        p->level_begin.push_back(next_vid);
+        // level 1 from real sources
+        std::vector<Split> cur;
+        for (uint64_t d = 0; d < n; d++) {
+            uint64_t deg = rp[d + 1] - rp[d];
+            if (deg <= chunk) continue;
+            uint32_t parts = (uint32_t)((deg + chunk - 1) / chunk);
+            uint64_t per = (deg + parts - 1) / parts;
+            Split sp{(uint32_t)d, next_vid, parts};
+            for (uint32_t k = 0; k < parts; k++) {
+                uint64_t b = rp[d] + (uint64_t)k * per, e = std::min(rp[d + 1], b + per);
+                vsrc.insert(vsrc.end(), rs.begin() + b, rs.begin() + e);
+                vrow_ptr.push_back(vsrc.size());
+            }
+            next_vid += parts;
+            cur.push_back(sp);
+        }
+        auto pad_level = [&]() {
+            while ((next_vid - p->n_pad) % kRowAlign) {
+                vrow_ptr.push_back(vsrc.size());
+                next_vid++;
+            }
+        };
+        while (true) {
+            pad_level();
+            p->level_begin.push_back(next_vid);
+            std::vector<Split> nxt;
+            for (const Split &sp : cur) {
+                if (sp.count <= chunk) {
+                    is_split[sp.row] = 1;
+                    split_first[sp.row] = sp.first_vid;
+                    split_count[sp.row] = sp.count;
+                    continue;
+                }
+                uint32_t parts = (sp.count + chunk - 1) / chunk;
+                uint64_t per = ((uint64_t)sp.count + parts - 1) / parts;
+                Split ns{sp.row, next_vid, parts};
+                for (uint32_t k = 0; k < parts; k++) {
+                    uint64_t b = (uint64_t)k * per, e = std::min<uint64_t>(sp.count, b + per);
+                    for (uint64_t i = b; i < e; i++) vsrc.push_back((uint32_t)(sp.first_vid + i));
+                    vrow_ptr.push_back(vsrc.size());
+                }
+                next_vid += parts;
+                nxt.push_back(ns);
+            }
+            if (nxt.empty()) break;
+            cur.swap(nxt);
+        }
+        if (p->level_begin.size() >= 2 && p->level_begin[p->level_begin.size() - 1] ==
+                                              p->level_begin[p->level_begin.size() - 2])
+            p->level_begin.pop_back(); // no trailing empty level
+        p->nv = next_vid - p->n_pad;
+        if (next_vid >= (uint64_t)kNone) return "row id space exhausted (n + virtual rows >= 2^32 - 1)";
+
+        // ---- assemble: real rows [0, n_pad), then virtual rows
+        const uint64_t rows_total = p->n_pad + p->nv;
+        p->row_ptr.assign(rows_total + 1, 0);
+        uint64_t total = 0;
+        for (uint64_t d = 0; d < n; d++) {
+            p->row_ptr[d] = total;
+            total += is_split[d] ? split_count[d] : (rp[d + 1] - rp[d]);
+        }
+        for (uint64_t d = n; d <= p->n_pad; d++) p->row_ptr[d] = total;
+        const uint64_t real_total = total;
+        for (uint64_t k = 0; k < p->nv; k++) p->row_ptr[p->n_pad + k + 1] = real_total + vrow_ptr[k + 1];
+        p->src.resize(real_total + vsrc.size());
+#pragma omp parallel for schedule(dynamic, 4096)
+        for (int64_t d = 0; d < (int64_t)n; d++) {
+            uint64_t o = p->row_ptr[d];
+            if (is_split[d]) {
+                for (uint32_t k = 0; k < split_count[d]; k++) p->src[o + k] = (uint32_t)(split_first[d] + k);
+            } else {
+                std::memcpy(p->src.data() + o, rs.data() + rp[d], (rp[d + 1] - rp[d]) * sizeof(uint32_t));
+            }
+        }
+        if (!vsrc.empty()) std::memcpy(p->src.data() + real_total, vsrc.data(), vsrc.size() * sizeof(uint32_t));
+    } catch (const std::bad_alloc &) {
+        return "out of host memory in the planner";
+    }
+    return "";
+}
+
+bool build_lc_table(uint8_t lc[68])
+{
+    // linear_counting(v) = m * (m / v).ln() with m = 64 (hyperloglog.rs:4472-4476); used
+    // only when v != 0 and the value is <= threshold(6) = 40 (:4505-4515), and then only
+    // its truncation `as usize` matters.
+    bool robust = true;
+    lc[0] = 0xFF;
+    lc[65] = lc[66] = lc[67] = 0xFF;
+    for (int v = 1; v <= 64; v++) {
+        double h = 64.0 * std::log(64.0 / (double)v);
+        if (std::fabs(h - 40.0) < 1e-6) robust = false;
+        if (h <= 40.0) {
+            double fl = std::floor(h);
+            if (h - fl < 1e-6 || (fl + 1.0) - h < 1e-6) robust = false;
+            lc[v] = (uint8_t)fl;
+        } else {
+            lc[v] = 0xFF;
+        }
+    }
+    return robust;
+}
+
+} // namespace hb

@@ -1,0 +1,68 @@
+// hb_internal.h - shared declarations of the host-side planner and the HIP side.
+#ifndef HB_INTERNAL_H
+#define HB_INTERNAL_H
+
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "../../include/hyperball.h"
+
+namespace hb {
+
+constexpr uint32_t kNone = 0xFFFFFFFFu;   // "no source" sentinel in the device src stream
+constexpr uint32_t kRowAlign = 64;        // row-id alignment of level boundaries (rows per block tile)
+constexpr uint32_t kDefaultChunk = 64;    // max sources per work row
+
+static inline bool u128_less(const hb_u128 &a, const hb_u128 &b)
+{
+    return a.hi != b.hi ? a.hi < b.hi : a.lo < b.lo;
+}
+static inline bool u128_eq(const hb_u128 &a, const hb_u128 &b) { return a.hi == b.hi && a.lo == b.lo; }
+
+// The reduced graph in ascending-NodeID ("sid") indexing: what the reference's
+// host_nodes()/host_edges() semantics leave.
+struct DenseGraph {
+    std::vector<hb_u128> ids;      // n, strictly ascending
+    std::vector<uint64_t> row_ptr; // n + 1, in-edges of sid v
+    std::vector<uint32_t> src;     // m_eff, sids
+    uint64_t m_input = 0, m_unique = 0;
+};
+
+// Device work layout produced by the planner.
+struct Plan {
+    uint64_t n = 0;          // real nodes
+    uint64_t n_pad = 0;      // round_up(n, kRowAlign): virtual row ids start here
+    uint64_t nv = 0;         // virtual rows (incl. padding rows)
+    uint64_t m_eff = 0;      // real edges
+    uint32_t chunk = kDefaultChunk;
+    std::vector<uint32_t> order;      // device index -> sid
+    std::vector<uint32_t> dev_of;     // sid -> device index
+    std::vector<uint64_t> row_ptr;    // (n_pad + nv) + 1 offsets into src
+    std::vector<uint32_t> src;        // device indices (real < n_pad <= virtual ids)
+    std::vector<uint64_t> level_begin; // virtual level l = rows [level_begin[l], level_begin[l+1])
+};
+
+// --- hb_host.cpp ---------------------------------------------------------------------
+// Reference ingest semantics: node set (store.rs:338-357), first-occurrence dedup
+// (store.rs:313), then rel-flag filter (harmonic.rs:131).  Returns "" or an error text.
+std::string ingest_edges(const hb_u128 *node_ids, uint64_t n, const hb_edge *edges, uint64_t m,
+                         DenseGraph *out);
+std::string check_dense(const hb_u128 *sorted_ids, uint64_t n, const uint64_t *row_ptr,
+                        const uint32_t *src, uint64_t m);
+// out_degree[sid] over the local edges.
+void count_out_degree(const uint64_t *row_ptr, const uint32_t *src, uint64_t n, std::vector<uint32_t> *deg);
+// Builds the device layout.  global_out_degree: per sid (already summed over ranks).
+std::string build_plan(uint64_t n, const uint64_t *row_ptr, const uint32_t *src,
+                       const std::vector<uint32_t> &global_out_degree, bool reorder, uint32_t chunk,
+                       Plan *plan);
+// Tables for the estimator's linear-counting branch (hyperloglog.rs:4472-4476,
+// :4505-4515): lc[v] = trunc(64 ln(64/v)) when that is <= 40, else 0xFF (v = 0..64).  Built with the
+// host libm; returns false if some value sits too close to an integer/threshold to be
+// libm-independent.
+bool build_lc_table(uint8_t lc[68]);
+
+double now_ms();
+
+} // namespace hb
+#endif

@@ -1,0 +1,556 @@
+// hb_kernels.hip.h - gfx950 device code of the HyperBall pass.
+//
+// What is computed (reference file:line):
+//   * counter merge  new[v] = max(old[v], max_{u->v} old[u]), per-register u8 max
+//       update_all_counters  crates/core/src/webgraph/centrality/harmonic.rs:116-157
+//       HyperLogLog::merge   crates/core/src/hyperloglog.rs:4531-4535
+//   * changed detection "any from > to" (harmonic.rs:137-141) == new[v] != old[v]
+//   * cardinality estimate HyperLogLog::size (hyperloglog.rs:4484-4516) incl. the
+//     6-nearest-neighbour bias lookup (:4407-4470) and linear counting (:4472-4476)
+//   * per-node harmonic increment  update_centralities (harmonic.rs:159-176) with
+//     KahanSum += (kahan_sum.rs:47-54)
+//
+// Mapping to the machine: one QUAD (4 lanes) owns one row; lane q of the quad holds
+// registers [16q, 16q+16) of the 64-byte counter as a uint4, so a counter gather is one
+// 64-byte contiguous segment per quad and one global_load_dwordx4 per lane; a wave64
+// covers 16 rows, a 256-thread block 64.  Byte-wise max is done with v_pk_max_u16 on the
+// even/odd bytes.  Source indices of a row are loaded 4 at a time (one per lane) and
+// broadcast inside the quad with DPP quad_perm, so control flow stays quad-uniform.
+// Integer/bitwise work only: no MFMA.  Compiled with -ffp-contract=off: the f64 estimator
+// and the Kahan update must round exactly like the reference's scalar Rust.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace hbk {
+
+constexpr uint32_t kNone = 0xFFFFFFFFu;
+constexpr int kTableLen = 159;
+
+struct PassParams {
+    const uint64_t *row_ptr;
+    const uint32_t *src;
+    const uint4 *rd;          // counters of the previous pass ("old"), n_pad rows
+    uint4 *wr;                // counters being produced ("new")
+    uint4 *part;              // virtual (hub-chunk) rows, indexed by vid - n_pad
+    const uint32_t *bits_rd;  // changed bits: real rows = previous pass, virtual rows = this pass
+    uint32_t *bits_wr;        // changed bits of this pass for real rows (next frontier)
+    uint32_t *kdirty;         // per real row: Kahan compensation term != 0
+    double *ksum;
+    double *kerr;
+    uint64_t *size;           // cached size() of rd[row]
+    unsigned long long *counters; // [0] changed rows, [1] active edges, [2] rows processed
+    const double *raw;        // HLL64_RAW_ESTIMATE (global copy, staged to LDS)
+    const double *bias;       // HLL64_BIAS
+    const uint8_t *lc;        // linear-counting table, 65 entries (index = zero registers)
+    uint64_t row_lo, row_hi;  // rows of this launch (row_lo multiple of 64)
+    uint64_t n, n_pad;
+    uint64_t slice_lo, slice_hi; // rows whose Kahan state this rank owns
+    double t_plus_1;          // (t + 1) as f64, harmonic.rs:174
+};
+
+// ---- quad helpers ---------------------------------------------------------------------
+template <int J>
+__device__ __forceinline__ uint32_t quad_bcast(uint32_t v)
+{
+    return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, J * 0x55, 0xF, 0xF, true);
+}
+template <int CTRL>
+__device__ __forceinline__ uint32_t quad_perm(uint32_t v)
+{
+    return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, CTRL, 0xF, 0xF, true);
+}
+// bit g of the result = any lane of quad g voted (ballot folded 4:1); scalar ALU work
+__device__ __forceinline__ uint32_t pack16(uint64_t b)
+{
+    b |= b >> 1;
+    b |= b >> 2;
+    b &= 0x1111111111111111ull;
+    b = (b | (b >> 3)) & 0x0303030303030303ull;
+    b = (b | (b >> 6)) & 0x000F000F000F000Full;
+    b = (b | (b >> 12)) & 0x000000FF000000FFull;
+    b = (b | (b >> 24)) & 0xFFFFull;
+    return (uint32_t)b;
+}
+
+typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pkmax(uint32_t a, uint32_t b)
+{
+    us2 x = __builtin_bit_cast(us2, a), y = __builtin_bit_cast(us2, b);
+    us2 z = __builtin_elementwise_max(x, y);
+    return __builtin_bit_cast(uint32_t, z);
+}
+
+// 16 registers of one lane kept as even/odd bytes so that one merge is 2 AND + 2 v_pk_max_u16
+struct Acc {
+    uint32_t e[4], o[4];
+};
+__device__ __forceinline__ void acc_zero(Acc &a)
+{
+#pragma unroll
+    for (int k = 0; k < 4; k++) a.e[k] = a.o[k] = 0;
+}
+__device__ __forceinline__ void acc_merge(Acc &a, const uint4 &r)
+{
+    const uint32_t w[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        a.e[k] = pkmax(a.e[k], w[k] & 0x00FF00FFu);
+        a.o[k] = pkmax(a.o[k], w[k] & 0xFF00FF00u);
+    }
+}
+__device__ __forceinline__ uint4 acc_value(const Acc &a)
+{
+    return make_uint4(a.e[0] | a.o[0], a.e[1] | a.o[1], a.e[2] | a.o[2], a.e[3] | a.o[3]);
+}
+__device__ __forceinline__ bool u4_ne(const uint4 &a, const uint4 &b)
+{
+    return ((a.x ^ b.x) | (a.y ^ b.y) | (a.z ^ b.z) | (a.w ^ b.w)) != 0;
+}
+
+// ---- HyperLogLog<64>::size(), one quad per counter -------------------------------------
+// slice::binary_search_by of Rust >= 1.82 (see oracle/hb_oracle.c)
+__device__ __forceinline__ int bias_first_index(const double *raw, double e)
+{
+    int size = kTableLen, base = 0;
+    while (size > 1) {
+        int half = size >> 1;
+        int mid = base + half;
+        if (!(raw[mid] > e)) base = mid;
+        size -= half;
+    }
+    int i = (raw[base] == e) ? base : base + (raw[base] < e ? 1 : 0);
+    return i == kTableLen ? kTableLen - 1 : i; // hyperloglog.rs:4413-4416
+}
+
+// estimate_bias, hyperloglog.rs:4407-4470 (K = 6 nearest neighbours, mean of their biases)
+__device__ __forceinline__ double estimate_bias(const double *raw, const double *bias, double e)
+{
+    int left = bias_first_index(raw, e);
+    int right = (left < kTableLen - 1) ? left + 1 : -1;
+    double s = 0.0;
+#pragma unroll 1
+    for (int k = 0; k < 6; k++) {
+        bool take_right;
+        if (left >= 0 && right >= 0) {
+            double dl = fabs(raw[left] - e), dr = fabs(raw[right] - e);
+            take_right = dr < dl;
+        } else {
+            take_right = left < 0;
+        }
+        int idx = take_right ? right : left;
+        s += bias[idx];
+        if (take_right) right = (idx < kTableLen - 1) ? idx + 1 : -1;
+        else left = (idx > 0) ? idx - 1 : -1;
+    }
+    return s / 6.0;
+}
+
+__device__ __forceinline__ uint64_t f64_as_usize(double x) // Rust `as usize`
+{
+    if (!(x > 0.0)) return 0;
+    if (x >= 18446744073709551616.0) return ~0ull;
+    return (uint64_t)x;
+}
+
+__device__ __forceinline__ double pow2_neg(uint32_t r) // ONE_OVER_POWER_OF_TWO[r], :4043
+{
+    return __hiloint2double((int)((1023u - r) << 20), 0);
+}
+
+// All 4 lanes of the quad call this with their uint4; all get the same result.
+// raw/bias/lc: tables (LDS or global).
+__device__ __forceinline__ uint64_t hll_size_quad(const uint4 &v, const double *raw, const double *bias,
+                                                  const uint8_t *lc)
+{
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+    // Fast path: every register <= 47  =>  all partial sums of the left fold
+    // (hyperloglog.rs:4488-4492) are multiples of 2^-47 below 2^7, hence exact in f64 and
+    // order-independent: sum them as integers scaled by 2^47.
+    uint64_t s = 0;
+    uint32_t zeros = 0, big = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+            uint32_t r = (w[k] >> (8 * b)) & 0xFFu;
+            zeros += (r == 0);
+            big |= (r > 47u);
+            s += (r > 47u) ? 0ull : (1ull << (47u - r));
+        }
+    }
+    // quad reduction (xor 1, xor 2)
+    {
+        uint32_t lo = (uint32_t)s, hi = (uint32_t)(s >> 32);
+        uint64_t o = ((uint64_t)quad_perm<0xB1>(hi) << 32) | quad_perm<0xB1>(lo);
+        s += o;
+        zeros += quad_perm<0xB1>(zeros);
+        big |= quad_perm<0xB1>(big);
+        lo = (uint32_t)s; hi = (uint32_t)(s >> 32);
+        o = ((uint64_t)quad_perm<0x4E>(hi) << 32) | quad_perm<0x4E>(lo);
+        s += o;
+        zeros += quad_perm<0x4E>(zeros);
+        big |= quad_perm<0x4E>(big);
+    }
+    double sum;
+    if (big == 0) {
+        sum = (double)s * 0x1p-47; // s <= 2^53: exact
+    } else {
+        // Rare (a register > 47 needs a hash with > 46 leading zeros): replay the
+        // reference's sequential f64 fold over all 64 registers in index order.
+        uint32_t all[16];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            all[0 + k] = quad_bcast<0>(w[k]);
+            all[4 + k] = quad_bcast<1>(w[k]);
+            all[8 + k] = quad_bcast<2>(w[k]);
+            all[12 + k] = quad_bcast<3>(w[k]);
+        }
+        sum = 0.0;
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+#pragma unroll
+            for (int b = 0; b < 4; b++) sum += pow2_neg((all[k] >> (8 * b)) & 0xFFu);
+        }
+    }
+    const double z = 1.0 / sum;                 // :4494
+    const double e = (0.709 * 4096.0) * z;      // :4496  am() * m.powi(2) * z
+    double e_star = e;
+    if (e <= 320.0) e_star = e - estimate_bias(raw, bias, e); // :4498-4502
+    // :4504-4515 : linear counting wins iff v != 0 and 64 ln(64/v) <= 40
+    uint32_t l = lc[zeros]; // zeros in 0..64
+    if (zeros != 0 && l != 0xFFu) return (uint64_t)l;
+    return f64_as_usize(e_star);
+}
+
+// update_centralities for one node (harmonic.rs:159-176) + KahanSum::add_assign
+__device__ __forceinline__ void kahan_update(double &sum, double &err, uint64_t sz_new, uint64_t sz_old,
+                                             double t_plus_1)
+{
+    uint64_t d = (sz_new >= sz_old) ? sz_new - sz_old : 0; // checked_sub().unwrap_or_default()
+    double rhs = (double)d / t_plus_1;
+    double y = rhs - err;
+    double t = sum + y;
+    err = (t - sum) - y;
+    sum = t;
+}
+
+// ---- the pass kernel --------------------------------------------------------------------
+// REAL      rows are nodes (self = rd[row], output = wr[row]); else virtual hub-chunk rows
+//           (self/output = part[row - n_pad], accumulating across passes)
+// FRONTIER  skip sources whose changed bit is clear (results-inert) and
+//           skip rows nothing happened to; else every source is gathered, every row written
+// FUSED     REAL only: estimator + Kahan in the same kernel (single GPU)
+// STATS     count active edges / processed rows
+template <bool REAL, bool FRONTIER, bool FUSED, bool STATS, int UNROLL>
+__global__ __launch_bounds__(256) void pass_kernel(const PassParams p)
+{
+    __shared__ double s_raw[FUSED ? kTableLen : 1];
+    __shared__ double s_bias[FUSED ? kTableLen : 1];
+    __shared__ uint8_t s_lc[68];
+    if (FUSED) {
+        for (int i = threadIdx.x; i < kTableLen; i += 256) {
+            s_raw[i] = p.raw[i];
+            s_bias[i] = p.bias[i];
+        }
+        if (threadIdx.x < 65) s_lc[threadIdx.x] = p.lc[threadIdx.x];
+        __syncthreads();
+    }
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int g = lane >> 2, q = lane & 3;
+    const int qshift = lane & ~3;
+    const uint64_t ntiles = (p.row_hi - p.row_lo + 63) >> 6;
+    unsigned long long cnt_changed = 0, cnt_active = 0, cnt_rows = 0;
+
+    for (uint64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const uint64_t row16 = p.row_lo + (tile << 6) + ((uint64_t)wave << 4); // first row of this wave
+        const uint64_t row = row16 + (uint64_t)g;
+        const bool valid = row < p.row_hi;
+        uint64_t beg = 0, end = 0;
+        if (valid) {
+            beg = p.row_ptr[row];
+            end = p.row_ptr[row + 1];
+        }
+        const uint4 *selfp = REAL ? (p.rd + row * 4 + q) : (p.part + (row - p.n_pad) * 4 + q);
+        uint4 selfv = make_uint4(0, 0, 0, 0);
+        Acc acc;
+        acc_zero(acc);
+        if (!FRONTIER && valid) { // dense mode: self is always needed, issue it first
+            selfv = *selfp;
+            acc_merge(acc, selfv);
+        }
+        bool lane_act = false;
+        if (beg < end) {
+            // all sources of one row are of one kind: real nodes (read rd) or virtual rows (read part)
+            const uint32_t first = p.src[beg];
+            const uint4 *base = (first >= p.n_pad) ? (const uint4 *)(p.part - p.n_pad * 4) : p.rd;
+            const bool real_src = first < p.n_pad;
+            for (uint64_t e = beg; e < end; e += 4 * UNROLL) {
+                uint32_t idx[UNROLL];
+#pragma unroll
+                for (int u = 0; u < UNROLL; u++) {
+                    uint64_t ee = e + 4 * u + q;
+                    idx[u] = (ee < end) ? p.src[ee] : kNone;
+                }
+                if (FRONTIER) {
+#pragma unroll
+                    for (int u = 0; u < UNROLL; u++) {
+                        if (idx[u] != kNone) {
+                            uint32_t wbits = p.bits_rd[idx[u] >> 5];
+                            if (!((wbits >> (idx[u] & 31u)) & 1u)) idx[u] = kNone;
+                        }
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < UNROLL; u++) {
+                    lane_act |= (idx[u] != kNone);
+                    if (STATS && real_src) cnt_active += (idx[u] != kNone);
+                }
+                if (FRONTIER) {
+#pragma unroll
+                    for (int u = 0; u < UNROLL; u++) {
+                        const uint32_t s0 = quad_bcast<0>(idx[u]), s1 = quad_bcast<1>(idx[u]);
+                        const uint32_t s2 = quad_bcast<2>(idx[u]), s3 = quad_bcast<3>(idx[u]);
+                        // max with an all-zero block is the identity: skipped sources stay 0
+                        uint4 r0 = make_uint4(0, 0, 0, 0), r1 = r0, r2 = r0, r3 = r0;
+                        if (s0 != kNone) r0 = base[(uint64_t)s0 * 4 + q];
+                        if (s1 != kNone) r1 = base[(uint64_t)s1 * 4 + q];
+                        if (s2 != kNone) r2 = base[(uint64_t)s2 * 4 + q];
+                        if (s3 != kNone) r3 = base[(uint64_t)s3 * 4 + q];
+                        acc_merge(acc, r0);
+                        acc_merge(acc, r1);
+                        acc_merge(acc, r2);
+                        acc_merge(acc, r3);
+                    }
+                } else {
+                    // dense: branch-free, out-of-row slots re-read the row's first source
+                    uint4 r[UNROLL][4];
+#pragma unroll
+                    for (int u = 0; u < UNROLL; u++) {
+                        uint32_t s0 = quad_bcast<0>(idx[u]), s1 = quad_bcast<1>(idx[u]);
+                        uint32_t s2 = quad_bcast<2>(idx[u]), s3 = quad_bcast<3>(idx[u]);
+                        s0 = (s0 != kNone) ? s0 : first;
+                        s1 = (s1 != kNone) ? s1 : first;
+                        s2 = (s2 != kNone) ? s2 : first;
+                        s3 = (s3 != kNone) ? s3 : first;
+                        r[u][0] = base[(uint64_t)s0 * 4 + q];
+                        r[u][1] = base[(uint64_t)s1 * 4 + q];
+                        r[u][2] = base[(uint64_t)s2 * 4 + q];
+                        r[u][3] = base[(uint64_t)s3 * 4 + q];
+                    }
+#pragma unroll
+                    for (int u = 0; u < UNROLL; u++) {
+#pragma unroll
+                        for (int j = 0; j < 4; j++) acc_merge(acc, r[u][j]);
+                    }
+                }
+            }
+        }
+        // ---- row epilogue (quad-uniform decisions come from ballots)
+        const uint32_t prev16 = REAL ? (uint32_t)((const uint16_t *)p.bits_rd)[row16 >> 4] : 0u;
+        const uint32_t kd16 = (REAL && FUSED) ? (uint32_t)((const uint16_t *)p.kdirty)[row16 >> 4] : 0u;
+        const bool self_prev = (prev16 >> g) & 1u;
+        const bool kd = (kd16 >> g) & 1u;
+        bool need = valid;
+        if (FRONTIER) {
+            const bool touched = ((__ballot(lane_act) >> qshift) & 0xFull) != 0;
+            need = valid && (touched || (REAL && (self_prev || kd)));
+            if (need) {
+                selfv = *selfp;
+                acc_merge(acc, selfv);
+            }
+        }
+        const uint4 accv = acc_value(acc);
+        const bool lane_diff = need && u4_ne(accv, selfv);
+        const uint64_t bal = __ballot(lane_diff);
+        const bool changed = ((bal >> qshift) & 0xFull) != 0;
+        if (REAL) {
+            // lazy double buffer: wr[row] already holds the right value unless the row changed
+            // in this or in the previous pass
+            if (need && (!FRONTIER || changed || self_prev)) p.wr[row * 4 + q] = accv;
+        } else {
+            if (changed) p.part[(row - p.n_pad) * 4 + q] = accv;
+        }
+        const uint32_t ch16 = pack16(bal);
+        if (FUSED || !REAL) {
+            // changed bits: real rows -> next frontier; virtual rows -> this pass' bits
+            uint16_t *dst = REAL ? (uint16_t *)p.bits_wr : (uint16_t *)p.bits_rd;
+            if (lane == 0 && row16 < p.row_hi) dst[row16 >> 4] = (uint16_t)ch16;
+        }
+        if (REAL && FUSED) cnt_changed += __popc(ch16);
+        if (STATS) cnt_rows += (need && q == 0);
+        if (REAL && FUSED) {
+            bool err_nz = false;
+            if (need && (changed || kd)) {
+                const uint64_t sz_old = p.size[row];
+                const uint64_t sz_new = changed ? hll_size_quad(accv, s_raw, s_bias, s_lc) : sz_old;
+                if (q == 0) {
+                    double ks = p.ksum[row], ke = p.kerr[row];
+                    kahan_update(ks, ke, sz_new, sz_old, p.t_plus_1);
+                    p.ksum[row] = ks;
+                    p.kerr[row] = ke;
+                    if (changed) p.size[row] = sz_new;
+                    err_nz = (ke != 0.0);
+                }
+            }
+            const uint32_t nk16 = pack16(__ballot(err_nz));
+            if (lane == 0 && row16 < p.row_hi && (nk16 | kd16)) ((uint16_t *)p.kdirty)[row16 >> 4] = (uint16_t)nk16;
+        }
+    }
+    // ---- per-wave totals, one atomic each
+    if (REAL) {
+        // cnt_changed is identical in all lanes of the wave (derived from a ballot)
+        if (lane == 0 && cnt_changed) atomicAdd(&p.counters[0], cnt_changed);
+    }
+    if (STATS) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            cnt_active += __shfl_down(cnt_active, off);
+            cnt_rows += __shfl_down(cnt_rows, off);
+        }
+        if (lane == 0) {
+            if (cnt_active) atomicAdd(&p.counters[1], cnt_active);
+            if (cnt_rows) atomicAdd(&p.counters[2], cnt_rows);
+        }
+    }
+}
+
+// ---- unfused epilogue (edge-partition mode, after the all-reduce) ----------------------
+// changed detection over ALL rows (every rank needs the full next frontier), estimator and
+// Kahan only for the rows this rank owns.
+__global__ __launch_bounds__(256) void epilogue_kernel(const PassParams p)
+{
+    __shared__ double s_raw[kTableLen];
+    __shared__ double s_bias[kTableLen];
+    __shared__ uint8_t s_lc[68];
+    for (int i = threadIdx.x; i < kTableLen; i += 256) {
+        s_raw[i] = p.raw[i];
+        s_bias[i] = p.bias[i];
+    }
+    if (threadIdx.x < 65) s_lc[threadIdx.x] = p.lc[threadIdx.x];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int g = lane >> 2, q = lane & 3, qshift = lane & ~3;
+    const uint64_t ntiles = (p.row_hi - p.row_lo + 63) >> 6;
+    unsigned long long cnt_changed = 0;
+    for (uint64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const uint64_t row16 = p.row_lo + (tile << 6) + ((uint64_t)wave << 4);
+        const uint64_t row = row16 + (uint64_t)g;
+        const bool valid = row < p.row_hi;
+        const uint32_t prev16 = (uint32_t)((const uint16_t *)p.bits_rd)[row16 >> 4];
+        const uint32_t kd16 = (uint32_t)((const uint16_t *)p.kdirty)[row16 >> 4];
+        const bool self_prev = (prev16 >> g) & 1u;
+        const bool kd = (kd16 >> g) & 1u;
+        uint4 oldv = make_uint4(0, 0, 0, 0), newv = oldv;
+        if (valid) {
+            oldv = p.rd[row * 4 + q];
+            newv = p.wr[row * 4 + q];
+        }
+        (void)self_prev;
+        const uint64_t bal = __ballot(valid && u4_ne(oldv, newv));
+        const bool changed = ((bal >> qshift) & 0xFull) != 0;
+        const uint32_t ch16 = pack16(bal);
+        if (lane == 0 && row16 < p.row_hi) ((uint16_t *)p.bits_wr)[row16 >> 4] = (uint16_t)ch16;
+        cnt_changed += __popc(ch16);
+        bool err_nz = false;
+        const bool mine = valid && row >= p.slice_lo && row < p.slice_hi;
+        if (mine && (changed || kd)) {
+            const uint64_t sz_old = p.size[row];
+            const uint64_t sz_new = changed ? hll_size_quad(newv, s_raw, s_bias, s_lc) : sz_old;
+            if (q == 0) {
+                double ks = p.ksum[row], ke = p.kerr[row];
+                kahan_update(ks, ke, sz_new, sz_old, p.t_plus_1);
+                p.ksum[row] = ks;
+                p.kerr[row] = ke;
+                if (changed) p.size[row] = sz_new;
+                err_nz = (ke != 0.0);
+            }
+        }
+        const uint32_t nk16 = pack16(__ballot(err_nz));
+        if (lane == 0 && row16 < p.row_hi && (nk16 | kd16)) ((uint16_t *)p.kdirty)[row16 >> 4] = (uint16_t)nk16;
+    }
+    if (lane == 0 && cnt_changed) atomicAdd(&p.counters[0], cnt_changed);
+}
+
+// ---- initialisation: counter = HLL::default(); add_u128(id) (harmonic.rs:60-66) ----------
+// HyperLogLog::add, hyperloglog.rs:4385-4396 with FastHasher (:4311-4313); only the low 64
+// bits of the id are hashed (:4398-4400).
+__global__ __launch_bounds__(256) void init_kernel(const uint64_t *id_low, uint64_t n, uint64_t n_pad, uint4 *a,
+                                                   uint4 *b, double *ksum, double *kerr, uint64_t *size,
+                                                   uint32_t *bits, uint32_t *kdirty, const double *raw,
+                                                   const double *bias, const uint8_t *lc)
+{
+    const uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    const uint64_t row = t >> 2;
+    const int q = (int)(t & 3);
+    if (row >= n_pad) return; // n_pad is a multiple of 64, so whole quads/waves exit together
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (row < n) {
+        const uint64_t hash = id_low[row] * 11400714819323198549ull;
+        const uint32_t j = (uint32_t)(hash >> 58);
+        const uint64_t w = hash << 6;
+        const uint32_t pval = (w == 0 ? 64u : (uint32_t)__clzll((long long)w)) + 1u;
+        if ((int)(j >> 4) == q) {
+            const uint32_t word = (j & 15u) >> 2, byte = j & 3u;
+            uint32_t ww[4] = {0, 0, 0, 0};
+            ww[word] = pval << (8 * byte);
+            v = make_uint4(ww[0], ww[1], ww[2], ww[3]);
+        }
+    }
+    a[row * 4 + q] = v;
+    b[row * 4 + q] = v;
+    const uint64_t sz = hll_size_quad(v, raw, bias, lc);
+    if (q == 0) {
+        ksum[row] = 0.0;
+        kerr[row] = 0.0;
+        size[row] = (row < n) ? sz : 0;
+    }
+    // every node starts in the changed set (harmonic.rs:221-225)
+    if ((row & 31) == 0 && q == 0) {
+        uint32_t m = 0xFFFFFFFFu;
+        if (row + 32 > n) m = (row >= n) ? 0u : (uint32_t)((1ull << (n - row)) - 1ull);
+        bits[row >> 5] = m;
+        kdirty[row >> 5] = 0;
+    }
+}
+
+// ---- helpers ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void hll_size_kernel(const uint4 *regs, uint64_t count, uint64_t *out,
+                                                       const double *raw, const double *bias, const uint8_t *lc)
+{
+    const uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    const uint64_t row = t >> 2;
+    const uint64_t rows_pad = (count + 15) & ~15ull;
+    if (row >= rows_pad) return;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (row < count) v = regs[t];
+    const uint64_t sz = hll_size_quad(v, raw, bias, lc);
+    if (row < count && (t & 3) == 0) out[row] = sz;
+}
+
+// wr = max(wr, other) byte-wise: all-reduce(max) between logical ranks on one device
+__global__ __launch_bounds__(256) void merge_max_kernel(uint4 *dst, const uint4 *other, uint64_t count4)
+{
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < count4; i += (uint64_t)gridDim.x * 256) {
+        uint4 a = dst[i];
+        const uint4 b = other[i];
+        Acc acc;
+        acc_zero(acc);
+        acc_merge(acc, a);
+        acc_merge(acc, b);
+        dst[i] = acc_value(acc);
+    }
+}
+
+// scatter/gather between device order and ascending-NodeID order (debug exports)
+__global__ __launch_bounds__(256) void gather_rows_kernel(const uint4 *regs, const uint32_t *dev_of, uint64_t n,
+                                                          uint4 *out)
+{
+    const uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    const uint64_t sid = t >> 2;
+    if (sid >= n) return;
+    out[t] = regs[(uint64_t)dev_of[sid] * 4 + (t & 3)];
+}
+
+} // namespace hbk

@@ -1,0 +1,274 @@
+// hb_synth.cpp - synthetic webgraph generator (bench / test INPUT support, host only).
+//
+// Not part of the drop-in boundary and not on the hot path: it manufactures the
+// power-law host graphs BASELINE.json's configs name (R-MAT, Graph500 parameters
+// a,b,c,d = 0.57,0.19,0.19,0.05) in the two forms the library
+// ingests: (1) the reduced dense form hb_load_dense() takes (ascending NodeIDs +
+// CSR by destination), (2) raw SmallEdge records (reference: crates/core/src/webgraph/
+// edge.rs:31-35) for hb_load_edges(), optionally "salted" with skipped rel-flags,
+// duplicates with different flags, and self-loops so the ingest semantics
+// (store.rs:297-357, harmonic.rs:131) are exercised.
+//
+// Determinism: every raw edge k is a pure function of (seed, k) (counter-based
+// splitmix64), so any thread count gives the same graph.
+#include <algorithm>
+#include <cstdint>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+#ifdef _OPENMP
+#include <omp.h>
+#include <parallel/algorithm>
+#define HBS_SORT(b, e) __gnu_parallel::sort((b), (e))
+#else
+#define HBS_SORT(b, e) std::sort((b), (e))
+#endif
+
+extern "C" {
+typedef struct { uint64_t lo, hi; } hbs_u128;
+typedef struct { hbs_u128 from, to; uint64_t rel_flags; } hbs_edge; // == hb_edge (include/hyperball.h)
+}
+
+static inline bool operator<(const hbs_u128 &a, const hbs_u128 &b)
+{
+    return a.hi != b.hi ? a.hi < b.hi : a.lo < b.lo;
+}
+
+static inline uint64_t splitmix64(uint64_t x)
+{
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+
+// NodeID of synthetic vertex i: looks like a 128-bit hash, id order != index order
+// (SURVEY.md §8(d)).
+static inline hbs_u128 node_id_of(uint64_t i)
+{
+    hbs_u128 r;
+    r.hi = splitmix64(2 * i + 1);
+    r.lo = splitmix64(2 * i + 2);
+    return r;
+}
+
+struct hbs_graph {
+    int scale = 0;
+    uint64_t seed = 0;
+    uint64_t raw_drawn = 0;
+    std::vector<uint64_t> edges;   // unique non-self edges, key = (dst_dense << 32) | src_dense, sorted
+    std::vector<hbs_u128> ids;     // ascending NodeID of dense node r
+    std::vector<uint32_t> vertex;  // synthetic vertex index of dense node r
+    std::vector<uint64_t> row_ptr; // n + 1
+    std::vector<uint32_t> src;     // m
+};
+
+// One R-MAT edge: `scale` quadrant draws, 16 random bits per level.
+// Thresholds: a = 0.57, a+b = 0.76, a+b+c = 0.95 of 65536.
+static inline void rmat_edge(int scale, uint64_t seed, uint64_t k, uint32_t *from, uint32_t *to)
+{
+    uint64_t f = 0, t = 0;
+    uint64_t ctr = seed ^ (k * 0xD1342543DE82EF95ull);
+    uint64_t bits = 0;
+    for (int l = 0; l < scale; l++) {
+        if ((l & 3) == 0) bits = splitmix64(ctr + (uint64_t)(l >> 2));
+        uint32_t r = (uint32_t)(bits & 0xFFFF);
+        bits >>= 16;
+        uint32_t fb, tb;
+        if (r < 37356u) { fb = 0; tb = 0; }        // a
+        else if (r < 49807u) { fb = 0; tb = 1; }   // b
+        else if (r < 62259u) { fb = 1; tb = 0; }   // c
+        else { fb = 1; tb = 1; }                   // d
+        f = (f << 1) | fb;
+        t = (t << 1) | tb;
+    }
+    *from = (uint32_t)f;
+    *to = (uint32_t)t;
+}
+
+extern "C" {
+
+void hbs_free(hbs_graph *g) { delete g; }
+
+// Draw raw R-MAT edges until at least m_target unique non-self edges exist, then keep
+// exactly the m_target smallest (in (to,from) vertex-key order is NOT stream order, so
+// instead we keep all uniques of the drawn prefix; the measured m is reported).
+hbs_graph *hbs_rmat(int scale, uint64_t m_target, uint64_t seed, int threads)
+{
+    if (scale < 1 || scale > 31) return nullptr;
+#ifdef _OPENMP
+    if (threads > 0) omp_set_num_threads(threads);
+#else
+    (void)threads;
+#endif
+    hbs_graph *g = new hbs_graph();
+    g->scale = scale;
+    g->seed = seed;
+    std::vector<uint64_t> keys; // (to << 32) | from, vertex ids
+    uint64_t drawn = 0;
+    uint64_t want = m_target + m_target / 16 + 64;
+    for (int round = 0; round < 64; round++) {
+        size_t base = keys.size();
+        keys.resize(base + want);
+        uint64_t *kp = keys.data() + base;
+        const uint64_t d0 = drawn;
+#pragma omp parallel for schedule(static)
+        for (int64_t i = 0; i < (int64_t)want; i++) {
+            uint32_t f, t;
+            rmat_edge(scale, seed, d0 + (uint64_t)i, &f, &t);
+            kp[i] = (f == t) ? ~0ull : (((uint64_t)t << 32) | f); // self-loops dropped
+        }
+        drawn += want;
+        HBS_SORT(keys.begin(), keys.end());
+        keys.erase(std::unique(keys.begin(), keys.end()), keys.end());
+        if (!keys.empty() && keys.back() == ~0ull) keys.pop_back();
+        if (keys.size() >= m_target) break;
+        uint64_t missing = m_target - keys.size();
+        want = missing + missing / 4 + 64;
+    }
+    g->raw_drawn = drawn;
+    const uint64_t m = keys.size();
+    // touched vertices
+    const uint64_t space = 1ull << scale;
+    std::vector<uint8_t> touched(space, 0);
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < (int64_t)m; i++) {
+        touched[(uint32_t)keys[i]] = 1;
+        touched[(uint32_t)(keys[i] >> 32)] = 1;
+    }
+    struct IdV {
+        hbs_u128 id;
+        uint32_t v;
+        bool operator<(const IdV &o) const { return id < o.id; }
+    };
+    std::vector<IdV> nodes;
+    for (uint64_t v = 0; v < space; v++)
+        if (touched[v]) nodes.push_back({node_id_of(v), (uint32_t)v});
+    HBS_SORT(nodes.begin(), nodes.end()) ;
+    const uint64_t n = nodes.size();
+    g->ids.resize(n);
+    g->vertex.resize(n);
+    std::vector<uint32_t> dense_of(space, 0xFFFFFFFFu);
+    for (uint64_t r = 0; r < n; r++) {
+        g->ids[r] = nodes[r].id;
+        g->vertex[r] = nodes[r].v;
+        dense_of[nodes[r].v] = (uint32_t)r;
+    }
+    std::vector<IdV>().swap(nodes);
+    // remap to dense indices and sort by (dst, src)
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < (int64_t)m; i++) {
+        uint32_t f = dense_of[(uint32_t)keys[i]], t = dense_of[(uint32_t)(keys[i] >> 32)];
+        keys[i] = ((uint64_t)t << 32) | f;
+    }
+    HBS_SORT(keys.begin(), keys.end());
+    g->row_ptr.assign(n + 1, 0);
+    g->src.resize(m);
+    for (uint64_t i = 0; i < m; i++) g->row_ptr[(keys[i] >> 32) + 1]++;
+    for (uint64_t v = 0; v < n; v++) g->row_ptr[v + 1] += g->row_ptr[v];
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < (int64_t)m; i++) g->src[i] = (uint32_t)keys[i];
+    g->edges.swap(keys);
+    return g;
+}
+
+uint64_t hbs_num_nodes(const hbs_graph *g) { return g->ids.size(); }
+uint64_t hbs_num_edges(const hbs_graph *g) { return g->src.size(); }
+uint64_t hbs_raw_drawn(const hbs_graph *g) { return g->raw_drawn; }
+const hbs_u128 *hbs_ids(const hbs_graph *g) { return g->ids.data(); }
+const uint64_t *hbs_row_ptr(const hbs_graph *g) { return g->row_ptr.data(); }
+const uint32_t *hbs_src(const hbs_graph *g) { return g->src.data(); }
+
+// Raw SmallEdge export of the same graph in a seeded pseudo-random stream order.
+// salt = 0: exactly the m unique edges, rel_flags = 0.
+// salt = 1 (parity runs): additionally
+//   * ~10% extra edges (not in the clean graph) whose first occurrence carries one
+//     SKIPPED_REL bit, half of them followed later by a clean copy that must stay lost
+//     (dedup precedes the flag filter, store.rs:313 then harmonic.rs:131);
+//   * ~1% duplicates of clean edges, with a skipped flag, placed AFTER the clean copy
+//     (must be ignored);
+//   * ~0.1% self-loops (kept, no-ops);
+//   * clean edges get harmless flag bits (bits outside 0x6FED00) now and then.
+// The reduced graph (after the reference's semantics) is NOT the clean graph: its node set
+// is larger (flagged-only edges introduce endpoints that appear in no surviving edge) and
+// a few extra edges survive; parity on salted input is checked against the oracle's
+// structure-faithful path run on the same records.  Returns the number of records written, or
+// the required capacity if out == NULL.
+uint64_t hbs_export_edges(const hbs_graph *g, hbs_edge *out, uint64_t cap, int salt, uint64_t salt_seed)
+{
+    const uint64_t m = g->edges.size();
+    const uint64_t n = g->ids.size();
+    const uint64_t mask = 0x6FED00ull;
+    static const int skipped_bits[12] = {8, 10, 11, 13, 14, 15, 16, 17, 18, 19, 21, 22};
+    static const int harmless_bits[11] = {0, 1, 2, 3, 4, 5, 6, 7, 9, 12, 20};
+    struct Rec { uint64_t order; uint32_t from, to; uint64_t flags; uint8_t synthetic_from, synthetic_to; };
+    std::vector<Rec> recs;
+    recs.reserve(m + (salt ? m / 8 + 16 : 0));
+    for (uint64_t i = 0; i < m; i++) {
+        uint64_t h = splitmix64(salt_seed ^ (i * 0x9E3779B97F4A7C15ull));
+        Rec r;
+        r.order = (h >> 2) | 1;      // odd, < 2^62
+        r.from = (uint32_t)g->edges[i];
+        r.to = (uint32_t)(g->edges[i] >> 32);
+        r.flags = 0;
+        r.synthetic_from = r.synthetic_to = 0;
+        if (salt) {
+            uint64_t h2 = splitmix64(h);
+            if ((h2 & 7) == 0) r.flags = 1ull << harmless_bits[(h2 >> 8) % 11];
+            if ((h2 >> 16) % 100 == 0) { // later flagged duplicate: ignored
+                Rec d = r;
+                d.order = r.order + ((splitmix64(h2) >> 3) % (0x3FFFFFFFFFFFFFFFull - r.order)) + 1;
+                d.flags = 1ull << skipped_bits[(h2 >> 32) % 12];
+                recs.push_back(d);
+            }
+        }
+        recs.push_back(r);
+    }
+    if (salt && n >= 2) {
+        // a set of the clean edges for membership tests
+        const std::vector<uint64_t> &E = g->edges; // sorted
+        uint64_t extra = m / 10 + 4;
+        for (uint64_t j = 0; j < extra; j++) {
+            uint64_t h = splitmix64(salt_seed + 0xABCDEF + j * 0x2545F4914F6CDD1Dull);
+            Rec r;
+            r.synthetic_from = r.synthetic_to = 0;
+            r.from = (uint32_t)(h % n);
+            r.to = (uint32_t)((h >> 32) % n);
+            if (j % 97 == 0) r.to = r.from; // self-loop (flag 0: kept, no-op)
+            else if (j % 89 == 0) {          // endpoint that exists only through a flagged edge
+                r.synthetic_to = 1;
+                r.to = (uint32_t)j;
+            }
+            uint64_t key = ((uint64_t)r.to << 32) | r.from;
+            bool self = (r.to == r.from) && !r.synthetic_to;
+            if (!self && !r.synthetic_to && std::binary_search(E.begin(), E.end(), key)) continue;
+            r.order = (splitmix64(h) >> 2) | 1;
+            r.flags = self ? 0 : (1ull << skipped_bits[(h >> 20) % 12]) | ((h & 1) ? 1ull << harmless_bits[(h >> 8) % 11] : 0);
+            recs.push_back(r);
+            if (!self && (j & 1)) { // clean copy AFTER the flagged first occurrence: stays lost
+                Rec c = r;
+                c.flags = 0;
+                c.order = r.order + ((splitmix64(h + 7) >> 3) % (0x3FFFFFFFFFFFFFFFull - r.order)) + 1;
+                recs.push_back(c);
+            }
+        }
+    }
+    if (!out) return recs.size();
+    if (recs.size() > cap) return ~0ull;
+    std::sort(recs.begin(), recs.end(), [](const Rec &a, const Rec &b) {
+        if (a.order != b.order) return a.order < b.order;
+        if (a.to != b.to) return a.to < b.to;
+        if (a.from != b.from) return a.from < b.from;
+        return a.flags < b.flags;
+    });
+    for (uint64_t i = 0; i < recs.size(); i++) {
+        const Rec &r = recs[i];
+        out[i].from = r.synthetic_from ? node_id_of((1ull << 40) + r.from) : g->ids[r.from];
+        out[i].to = r.synthetic_to ? node_id_of((1ull << 40) + r.to) : g->ids[r.to];
+        out[i].rel_flags = r.flags;
+    }
+    (void)mask;
+    return recs.size();
+}
+
+} // extern "C"
