@@ -213,6 +213,21 @@ int hb_debug_merge_pending(hb_ctx *ctx, hb_ctx *other);
 int hb_step_local(hb_ctx *ctx);
 int hb_step_finish(hb_ctx *ctx, int *has_changes);
 
+/* ---- host-only test exports (no device needed) -------------------------------------------- */
+/* The reference ingest semantics alone (node set, first-occurrence de-duplication, flag
+ * filter; store.rs:297-357, harmonic.rs:131).  Two-call pattern: with ids/row_ptr/src NULL
+ * only the counts are returned; then row_ptr needs n+1 and src m_eff entries. */
+int hb_host_ingest(const hb_u128 *node_ids, uint64_t n, const hb_edge *edges, uint64_t m,
+                   uint64_t *n_out, uint64_t *m_unique, uint64_t *m_eff, hb_u128 *ids,
+                   uint64_t *row_ptr, uint32_t *src);
+/* The device work layout the planner would build for a reduced graph (device order +
+ * hub-row splitting), so its invariants can be checked on the host.  flags: HB_FLAG_NO_REORDER.
+ * Two-call pattern: sizes[0..3] = {n_pad, nv, plan_src_len, levels}; then
+ * order[n], plan_row_ptr[n_pad+nv+1], plan_src[plan_src_len], level_begin[levels+1]. */
+int hb_host_plan(uint64_t n, const uint64_t *row_ptr, const uint32_t *src, uint32_t flags,
+                 uint32_t chunk, uint64_t sizes[4], uint32_t *order, uint64_t *plan_row_ptr,
+                 uint32_t *plan_src, uint64_t *level_begin);
+
 #ifdef __cplusplus
 }
 #endif

@@ -190,6 +190,7 @@ struct hbo_dense {
     int has_changes;
     int threads;
     int bsearch;
+    uint64_t last_active, last_touched;
 };
 
 hbo_dense *hbo_dense_create(uint64_t n, const uint64_t *id_low64, const uint64_t *row_ptr,
@@ -242,16 +243,18 @@ void hbo_dense_destroy(hbo_dense *s)
     free(s);
 }
 
-int hbo_dense_step(hbo_dense *s, int flags, hbo_pass_stats *st)
+/* First half of a pass: update_all_counters (harmonic.rs:116-157) over the edges this
+ * state holds, into the "new" buffer.  No centrality update.  In an edge-partitioned run
+ * each rank calls this on its own edge subset; the per-register max of all ranks' "new"
+ * buffers (an all-reduce MAX) is the reference's "new" map. */
+void hbo_dense_step_local(hbo_dense *s, int flags)
 {
     const uint64_t n = s->n;
     const int frontier = (flags & HBO_FRONTIER) != 0;
-    const int literal = (flags & HBO_LITERAL) != 0;
-    const double denom = (double)(s->t + 1); /* (t + 1) as f64, harmonic.rs:174 */
-    uint64_t active = 0, touched = 0, changed = 0;
+    uint64_t active = 0, touched = 0;
 #ifdef _OPENMP
     int nt = s->threads > 0 ? s->threads : omp_get_max_threads();
-#pragma omp parallel for schedule(dynamic, 4096) num_threads(nt) reduction(+ : active, touched, changed)
+#pragma omp parallel for schedule(dynamic, 4096) num_threads(nt) reduction(+ : active, touched)
 #endif
     for (int64_t vi = 0; vi < (int64_t)n; vi++) {
         const uint64_t v = (uint64_t)vi;
@@ -259,8 +262,7 @@ int hbo_dense_step(hbo_dense *s, int flags, hbo_pass_stats *st)
         uint8_t acc[64];
         memcpy(acc, ov, 64); /* new[v] == old[v] on entry (Counters::step, harmonic.rs:210-212) */
         uint64_t act = 0;
-        /* update_all_counters (harmonic.rs:116-157), restricted to edges into v.
-         * The merge is a per-register max, so edge order is irrelevant (App. A-5). */
+        /* The merge is a per-register max, so edge order is irrelevant (App. A-5). */
         for (uint64_t e = s->row_ptr[v]; e < s->row_ptr[v + 1]; e++) {
             uint32_t u = s->src[e];
             if (s->changed_prev[u]) act++;
@@ -269,34 +271,61 @@ int hbo_dense_step(hbo_dense *s, int flags, hbo_pass_stats *st)
             for (int i = 0; i < 64; i++)
                 if (ou[i] > acc[i]) acc[i] = ou[i];
         }
-        int ch = memcmp(acc, ov, 64) != 0; /* "any from > to" happened at least once */
         memcpy(s->new_regs + 64 * v, acc, 64);
-        s->changed_next[v] = (uint8_t)ch;
         active += act;
         touched += (act != 0);
+    }
+    s->last_active = active;
+    s->last_touched = touched;
+}
+
+uint8_t *hbo_dense_pending_registers(hbo_dense *s) { return s->new_regs; }
+
+/* Second half: changed detection, update_centralities (harmonic.rs:159-176), then
+ * counters.step(); t += 1 (harmonic.rs:273-275). */
+int hbo_dense_step_finish(hbo_dense *s, int flags, hbo_pass_stats *st)
+{
+    const uint64_t n = s->n;
+    const int literal = (flags & HBO_LITERAL) != 0;
+    const double denom = (double)(s->t + 1); /* (t + 1) as f64, harmonic.rs:174 */
+    uint64_t changed = 0;
+#ifdef _OPENMP
+    int nt = s->threads > 0 ? s->threads : omp_get_max_threads();
+#pragma omp parallel for schedule(static) num_threads(nt) reduction(+ : changed)
+#endif
+    for (int64_t vi = 0; vi < (int64_t)n; vi++) {
+        const uint64_t v = (uint64_t)vi;
+        const uint8_t *ov = s->old_regs + 64 * v;
+        const uint8_t *nv = s->new_regs + 64 * v;
+        int ch = memcmp(nv, ov, 64) != 0; /* "any from > to" happened at least once */
+        s->changed_next[v] = (uint8_t)ch;
         changed += (uint64_t)ch;
-        /* update_centralities (harmonic.rs:159-176) */
         uint64_t sz_old = literal ? hbo_hll_size_ex(ov, s->bsearch, NULL, NULL) : s->size_old[v];
-        uint64_t sz_new = (literal || ch) ? hbo_hll_size_ex(acc, s->bsearch, NULL, NULL) : sz_old;
+        uint64_t sz_new = (literal || ch) ? hbo_hll_size_ex(nv, s->bsearch, NULL, NULL) : sz_old;
         uint64_t d = (sz_new >= sz_old) ? sz_new - sz_old : 0; /* checked_sub().unwrap_or_default() */
         hbo_kahan_add(&s->ksum[v], &s->kerr[v], (double)d / denom);
         s->size_old[v] = sz_new;
     }
-    /* counters.step(); changed_nodes = new_changed_nodes; t += 1 (harmonic.rs:273-275) */
     uint8_t *tr = s->old_regs; s->old_regs = s->new_regs; s->new_regs = tr;
-    /* the "new" buffer must equal "old" at the start of the next pass; we rewrite
-     * every row each pass so no copy is needed. */
+    /* every row of "new" is rewritten by the next step_local, so no clone is needed */
     uint8_t *tc = s->changed_prev; s->changed_prev = s->changed_next; s->changed_next = tc;
     s->has_changes = changed != 0;
     if (st) {
         st->pass = s->t;
-        st->active_edges = active;
-        st->touched = touched;
+        st->active_edges = s->last_active;
+        st->touched = s->last_touched;
         st->changed = changed;
         st->has_changes = s->has_changes;
     }
     s->t += 1;
     return s->has_changes;
+}
+
+/* One pass of the loop body harmonic.rs:237-275. */
+int hbo_dense_step(hbo_dense *s, int flags, hbo_pass_stats *st)
+{
+    hbo_dense_step_local(s, flags);
+    return hbo_dense_step_finish(s, flags, st);
 }
 
 uint64_t hbo_dense_run(hbo_dense *s, int flags)

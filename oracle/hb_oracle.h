@@ -91,6 +91,13 @@ void hbo_dense_destroy(hbo_dense *);
 /* One pass of the loop body harmonic.rs:237-275: update counters, update
  * centralities, step, t += 1.  Returns has_changes. */
 int hbo_dense_step(hbo_dense *, int flags, hbo_pass_stats *stats);
+/* The same pass in two halves, for edge-partitioned emulation: step_local merges over the
+ * edges this state holds into the pending ("new") registers; the caller may then combine
+ * the pending registers of several states with a per-register max (what the all-reduce
+ * does); step_finish does changed detection + update_centralities + step. */
+void hbo_dense_step_local(hbo_dense *, int flags);
+uint8_t *hbo_dense_pending_registers(hbo_dense *); /* n*64, writable */
+int hbo_dense_step_finish(hbo_dense *, int flags, hbo_pass_stats *stats);
 /* Loop until a pass changes nothing (harmonic.rs:237-240).  Returns T = passes
  * executed (including the final no-change pass). */
 uint64_t hbo_dense_run(hbo_dense *, int flags);

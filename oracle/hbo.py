@@ -56,6 +56,11 @@ def load():
     L.hbo_dense_destroy.argtypes = [P]
     L.hbo_dense_step.restype = ctypes.c_int
     L.hbo_dense_step.argtypes = [P, ctypes.c_int, P]
+    L.hbo_dense_step_local.argtypes = [P, ctypes.c_int]
+    L.hbo_dense_pending_registers.restype = P
+    L.hbo_dense_pending_registers.argtypes = [P]
+    L.hbo_dense_step_finish.restype = ctypes.c_int
+    L.hbo_dense_step_finish.argtypes = [P, ctypes.c_int, P]
     L.hbo_dense_run.restype = U64
     L.hbo_dense_run.argtypes = [P, ctypes.c_int]
     for f in ("hbo_dense_registers", "hbo_dense_kahan_sum", "hbo_dense_kahan_err", "hbo_dense_sizes"):
@@ -123,6 +128,19 @@ class Dense:
     def step(self, flags=FRONTIER):
         ps = PassStats()
         has = self.L.hbo_dense_step(self.h, flags, ctypes.byref(ps))
+        return bool(has), dict(t=ps.pass_, active_edges=ps.active_edges, touched=ps.touched, changed=ps.changed)
+
+    def step_local(self, flags=FRONTIER):
+        self.L.hbo_dense_step_local(self.h, flags)
+
+    def pending(self):
+        """Writable (n, 64) view of the registers produced by step_local."""
+        ptr = self.L.hbo_dense_pending_registers(self.h)
+        return np.ctypeslib.as_array(ctypes.cast(ptr, ctypes.POINTER(ctypes.c_uint8)), (max(self.n, 1), 64))[:self.n]
+
+    def step_finish(self, flags=FRONTIER):
+        ps = PassStats()
+        has = self.L.hbo_dense_step_finish(self.h, flags, ctypes.byref(ps))
         return bool(has), dict(t=ps.pass_, active_edges=ps.active_edges, touched=ps.touched, changed=ps.changed)
 
     def run(self, flags=FRONTIER):

@@ -119,6 +119,9 @@ _SIGNATURES = [
     ("hb_debug_merge_pending", ctypes.c_int, [_P, _P]),
     ("hb_step_local", ctypes.c_int, [_P]),
     ("hb_step_finish", ctypes.c_int, [_P, ctypes.POINTER(ctypes.c_int)]),
+    ("hb_host_ingest", ctypes.c_int, [_P, _U64, _P, _U64, ctypes.POINTER(_U64), ctypes.POINTER(_U64),
+                                      ctypes.POINTER(_U64), _P, _P, _P]),
+    ("hb_host_plan", ctypes.c_int, [_U64, _P, _P, ctypes.c_uint32, ctypes.c_uint32, _P, _P, _P, _P, _P]),
 ]
 SYMBOLS = [s[0] for s in _SIGNATURES]
 
@@ -335,3 +338,49 @@ def rccl_unique_id():
     if rc != HB_OK:
         raise HyperballError(rc, (load().hb_last_error(None) or b"").decode())
     return bytes(buf)
+
+
+def host_ingest(edges, node_ids=None):
+    """Host-only: the reference's node/edge-set semantics (no device needed).
+    Returns (ids, row_ptr, src, m_unique)."""
+    lib = load()
+    edges = np.ascontiguousarray(edges, dtype=EDGE)
+    nn = 0
+    if node_ids is not None:
+        node_ids = np.ascontiguousarray(node_ids, dtype=U128)
+        nn = len(node_ids)
+    n, mu, me = ctypes.c_uint64(0), ctypes.c_uint64(0), ctypes.c_uint64(0)
+    rc = lib.hb_host_ingest(_ptr(node_ids), nn, _ptr(edges), len(edges), ctypes.byref(n), ctypes.byref(mu),
+                            ctypes.byref(me), None, None, None)
+    if rc != HB_OK:
+        raise HyperballError(rc, (lib.hb_last_error(None) or b"").decode())
+    ids = np.zeros(n.value, dtype=U128)
+    row_ptr = np.zeros(n.value + 1, dtype=np.uint64)
+    src = np.zeros(me.value, dtype=np.uint32)
+    rc = lib.hb_host_ingest(_ptr(node_ids), nn, _ptr(edges), len(edges), ctypes.byref(n), ctypes.byref(mu),
+                            ctypes.byref(me), _ptr(ids), _ptr(row_ptr), _ptr(src))
+    if rc != HB_OK:
+        raise HyperballError(rc, (lib.hb_last_error(None) or b"").decode())
+    return ids, row_ptr, src, mu.value
+
+
+def host_plan(row_ptr, src, flags=0, chunk=0):
+    """Host-only: the device work layout (order, plan_row_ptr, plan_src, level_begin, n_pad)."""
+    lib = load()
+    row_ptr = np.ascontiguousarray(row_ptr, dtype=np.uint64)
+    src = np.ascontiguousarray(src, dtype=np.uint32)
+    n = len(row_ptr) - 1
+    sizes = np.zeros(4, dtype=np.uint64)
+    rc = lib.hb_host_plan(n, _ptr(row_ptr), _ptr(src), flags, chunk, _ptr(sizes), None, None, None, None)
+    if rc != HB_OK:
+        raise HyperballError(rc, (lib.hb_last_error(None) or b"").decode())
+    n_pad, nv, slen, levels = (int(x) for x in sizes)
+    order = np.zeros(n, dtype=np.uint32)
+    prp = np.zeros(n_pad + nv + 1, dtype=np.uint64)
+    psrc = np.zeros(slen, dtype=np.uint32)
+    lb = np.zeros(levels + 1, dtype=np.uint64)
+    rc = lib.hb_host_plan(n, _ptr(row_ptr), _ptr(src), flags, chunk, _ptr(sizes), _ptr(order), _ptr(prp), _ptr(psrc),
+                          _ptr(lb))
+    if rc != HB_OK:
+        raise HyperballError(rc, (lib.hb_last_error(None) or b"").decode())
+    return dict(order=order, row_ptr=prp, src=psrc, level_begin=lb, n_pad=n_pad, nv=nv)

@@ -824,6 +824,47 @@ int hb_debug_copy_graph(hb_ctx *c, hb_u128 *ids, uint64_t *row_ptr, uint32_t *sr
     return HB_OK;
 }
 
+int hb_host_ingest(const hb_u128 *node_ids, uint64_t n, const hb_edge *edges, uint64_t m, uint64_t *n_out,
+                   uint64_t *m_unique, uint64_t *m_eff, hb_u128 *ids, uint64_t *row_ptr, uint32_t *src)
+{
+    hb_ctx *c = nullptr;
+    DenseGraph g;
+    std::string e = ingest_edges(node_ids, n, edges, m, &g);
+    if (!e.empty()) return fail(c, HB_ERR_INVALID, e);
+    const uint64_t nn = g.ids.size();
+    if (n_out) *n_out = nn;
+    if (m_unique) *m_unique = g.m_unique;
+    if (m_eff) *m_eff = g.src.size();
+    if (ids && nn) std::memcpy(ids, g.ids.data(), nn * sizeof(hb_u128));
+    if (row_ptr) std::memcpy(row_ptr, g.row_ptr.data(), (nn + 1) * sizeof(uint64_t));
+    if (src && !g.src.empty()) std::memcpy(src, g.src.data(), g.src.size() * sizeof(uint32_t));
+    return HB_OK;
+}
+
+int hb_host_plan(uint64_t n, const uint64_t *row_ptr, const uint32_t *src, uint32_t flags, uint32_t chunk,
+                 uint64_t sizes[4], uint32_t *order, uint64_t *plan_row_ptr, uint32_t *plan_src, uint64_t *level_begin)
+{
+    hb_ctx *c = nullptr;
+    if (!sizes || (n && !row_ptr)) return fail(c, HB_ERR_INVALID, "NULL argument");
+    std::vector<uint32_t> outdeg;
+    const bool reorder = !(flags & HB_FLAG_NO_REORDER);
+    static const uint64_t zero = 0;
+    if (n == 0) row_ptr = &zero;
+    if (reorder) count_out_degree(row_ptr, src, n, &outdeg);
+    Plan p;
+    std::string e = build_plan(n, row_ptr, src, outdeg, reorder, chunk ? chunk : kDefaultChunk, &p);
+    if (!e.empty()) return fail(c, HB_ERR_LIMIT, e);
+    sizes[0] = p.n_pad;
+    sizes[1] = p.nv;
+    sizes[2] = p.src.size();
+    sizes[3] = p.level_begin.size() ? p.level_begin.size() - 1 : 0;
+    if (order && n) std::memcpy(order, p.order.data(), n * sizeof(uint32_t));
+    if (plan_row_ptr) std::memcpy(plan_row_ptr, p.row_ptr.data(), p.row_ptr.size() * sizeof(uint64_t));
+    if (plan_src && !p.src.empty()) std::memcpy(plan_src, p.src.data(), p.src.size() * sizeof(uint32_t));
+    if (level_begin) std::memcpy(level_begin, p.level_begin.data(), p.level_begin.size() * sizeof(uint64_t));
+    return HB_OK;
+}
+
 int hb_debug_merge_pending(hb_ctx *c, hb_ctx *other)
 {
     if (!c || !other) return HB_ERR_INVALID;

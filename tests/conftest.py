@@ -1,0 +1,28 @@
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (gfx950) GPU")
+    # native pieces are built in-tree; build them when a test run starts without them
+    need = [os.path.join(ROOT, "stract_amd", "lib", "libhyperball.so"),
+            os.path.join(ROOT, "stract_amd", "lib", "libhb_synth.so"),
+            os.path.join(ROOT, "oracle", "libhb_oracle.so")]
+    if not all(os.path.exists(p) for p in need):
+        subprocess.check_call([sys.executable, "-c", "import __graft_entry__ as g; g.build()"], cwd=ROOT)
+
+
+@pytest.fixture(scope="session")
+def gpu_ctx_factory():
+    from stract_amd import _lib
+
+    if _lib.device_count() == 0:
+        pytest.fail("GPU test selected but no HIP device is visible (no CPU fallback exists)")
+    return _lib.Context

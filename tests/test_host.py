@@ -1,0 +1,185 @@
+"""CPU-side checks: the C-ABI library loads and exports every symbol include/hyperball.h
+declares, fails loudly without a device, and its host logic (ingest semantics, planner)
+is correct.  No compute calls on a GPU here."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from oracle import hbo
+from stract_amd import _lib, dist, synth
+from stract_amd.harmonic import EdgeListGraph, HarmonicCentrality
+from tests import graphs
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_header_symbols_all_exported():
+    hdr = open(os.path.join(ROOT, "include", "hyperball.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(hb_[a-z0-9_]+)\s*\(", hdr))
+    assert declared, "no declarations parsed"
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    missing = [s for s in sorted(declared) if not hasattr(lib, s)]
+    assert not missing, missing
+    # and the Python binding covers exactly the declared set
+    assert declared == set(_lib.SYMBOLS)
+    assert _lib.load().hb_abi_version() == 1
+
+
+def test_struct_layouts_match_header():
+    assert ctypes.sizeof(_lib.HbOptions) == 4 * 7 + 128 + 32
+    assert _lib.EDGE.itemsize == 40 and _lib.U128.itemsize == 16
+    assert ctypes.sizeof(_lib.HbStats) == 16 * 8
+    assert ctypes.sizeof(_lib.HbPassStats) == 4 * 8 + 4 * 4
+
+
+@pytest.mark.skipif(_lib.device_count() > 0, reason="only meaningful on a box without a GPU")
+def test_no_device_fails_loudly():
+    with pytest.raises(_lib.HyperballError) as ei:
+        _lib.Context()
+    assert ei.value.code == _lib.HB_ERR_NO_DEVICE
+    with pytest.raises(_lib.HyperballError):
+        HarmonicCentrality.calculate(graphs.fixture_graph())
+
+
+def test_null_ctx_is_rejected():
+    lib = _lib.load()
+    assert lib.hb_run(None, None) == _lib.HB_ERR_INVALID
+    assert lib.hb_load_edges(None, None, 0, None, 0) == _lib.HB_ERR_INVALID
+    lib.hb_destroy(None)  # no-op
+
+
+def _reference_semantics_python(edges):
+    """Plain-Python statement of store.rs:297-357 + harmonic.rs:131 for small inputs."""
+    key = lambda r: ((int(r["from"]["hi"]) << 64) | int(r["from"]["lo"]), (int(r["to"]["hi"]) << 64) | int(r["to"]["lo"]))
+    nodes = sorted({x for r in edges for x in key(r)})
+    seen, kept = set(), []
+    for r in edges:
+        k = key(r)
+        if k in seen:
+            continue
+        seen.add(k)
+        if int(r["rel_flags"]) & 0x6FED00:
+            continue
+        kept.append(k)
+    return nodes, len(seen), sorted(kept, key=lambda k: (k[1], k[0]))
+
+
+def test_ingest_semantics_small():
+    A, B, C, D = 5, (1 << 100) + 3, 7, (1 << 64)
+    e = EdgeListGraph.from_tuples([(A, B, 0), (A, B, 1 << 8), (B, C, 1 << 13), (B, C, 0), (C, C, 0), (D, A, 1 << 21),
+                                   (C, A, 1 << 12), (A, C, 0)]).host_edges()
+    ids, row_ptr, src, mu = _lib.host_ingest(e)
+    nodes, n_unique, kept = _reference_semantics_python(e)
+    got_ids = [(int(h) << 64) | int(l) for l, h in zip(ids["lo"], ids["hi"])]
+    assert got_ids == nodes                      # numeric u128 order; D only via a flagged edge
+    assert mu == n_unique == 6
+    got = [(got_ids[s], got_ids[v]) for v in range(len(ids)) for s in src[row_ptr[v]:row_ptr[v + 1]]]
+    assert got == kept
+    assert (B, C) not in kept and (C, A) in kept  # flagged-first stays lost; harmless flag bit 12 kept
+
+
+def test_ingest_matches_python_on_salted_rmat():
+    g = synth.RmatGraph(9, 3000)
+    e = g.edges(salt=1, salt_seed=3)
+    ids, row_ptr, src, mu = _lib.host_ingest(e)
+    nodes, n_unique, kept = _reference_semantics_python(e)
+    got_ids = [(int(h) << 64) | int(l) for l, h in zip(ids["lo"], ids["hi"])]
+    assert got_ids == nodes and mu == n_unique
+    got = [(got_ids[s], got_ids[v]) for v in range(len(ids)) for s in src[row_ptr[v]:row_ptr[v + 1]]]
+    assert got == kept
+    # explicit node list (graph.host_nodes()) gives the same reduction, any order, duplicates ok
+    shuffled = np.concatenate([ids[::-1], ids[:5]])
+    ids2, rp2, src2, mu2 = _lib.host_ingest(e, shuffled)
+    assert np.array_equal(ids2, ids) and np.array_equal(rp2, row_ptr) and np.array_equal(src2, src)
+
+
+def test_ingest_edge_cases():
+    ids, row_ptr, src, mu = _lib.host_ingest(np.zeros(0, dtype=_lib.EDGE))
+    assert len(ids) == 0 and row_ptr.tolist() == [0] and len(src) == 0 and mu == 0
+    # records whose endpoint is not in the supplied node set are ignored (harmonic.rs:135)
+    e = EdgeListGraph.from_tuples([(1, 2), (2, 3), (9, 1)]).host_edges()
+    ids, row_ptr, src, mu = _lib.host_ingest(e, graphs.dense_from_tuples([(1, 2), (2, 3)])[0])
+    assert len(ids) == 3 and len(src) == 2
+
+
+def _expand(plan, row, n_pad):
+    out = []
+    for s in plan["src"][int(plan["row_ptr"][row]):int(plan["row_ptr"][row + 1])]:
+        out.extend(_expand(plan, int(s), n_pad) if s >= n_pad else [int(s)])
+    return out
+
+
+@pytest.mark.parametrize("chunk,flags", [(4, 0), (16, 0), (64, 0), (8, _lib.HB_FLAG_NO_REORDER)])
+def test_planner_invariants(chunk, flags):
+    g = synth.RmatGraph(12, 40_000)
+    plan = _lib.host_plan(g.row_ptr, g.src, flags, chunk)
+    n, n_pad = g.n, plan["n_pad"]
+    order = plan["order"].astype(np.int64)
+    assert sorted(order.tolist()) == list(range(n))          # a permutation
+    if flags & _lib.HB_FLAG_NO_REORDER:
+        assert np.array_equal(order, np.arange(n))
+    else:
+        outdeg = np.bincount(g.src, minlength=n)
+        assert np.all(np.diff(outdeg[order]) <= 0)            # hottest sources first
+    dev_of = np.zeros(n, np.int64)
+    dev_of[order] = np.arange(n)
+    lens = np.diff(plan["row_ptr"].astype(np.int64))
+    assert lens.max() <= chunk                                # no work row longer than chunk
+    lb = plan["level_begin"].astype(np.int64)
+    assert lb[0] == n_pad and np.all(lb % 64 == 0) and np.all(np.diff(lb) > 0) and lb[-1] == n_pad + plan["nv"]
+    # level discipline: level-1 rows read real nodes, level-l rows read level l-1 only,
+    # real rows read either only real nodes or only virtual rows
+    for l in range(len(lb) - 1):
+        for row in range(lb[l], lb[l + 1]):
+            s = plan["src"][int(plan["row_ptr"][row]):int(plan["row_ptr"][row + 1])]
+            if len(s) == 0:
+                continue
+            if l == 0:
+                assert s.max() < n
+            else:
+                assert s.min() >= lb[l - 1] and s.max() < lb[l]
+    for d in range(n):
+        s = plan["src"][int(plan["row_ptr"][d]):int(plan["row_ptr"][d + 1])]
+        assert len(s) == 0 or s.max() < n or s.min() >= n_pad
+        sid = order[d]
+        want = sorted(dev_of[g.src[int(g.row_ptr[sid]):int(g.row_ptr[sid + 1])]].tolist())
+        assert sorted(_expand(plan, d, n_pad)) == want        # the tree covers exactly the row's in-edges
+
+
+def test_planner_deep_hub():
+    # one destination with 5000 in-edges and chunk 4 needs a 6-level tree
+    n = 5001
+    row_ptr = np.zeros(n + 1, dtype=np.uint64)
+    row_ptr[1:] = 5000
+    src = np.arange(1, 5001, dtype=np.uint32)
+    plan = _lib.host_plan(row_ptr, src, _lib.HB_FLAG_NO_REORDER, 4)
+    assert len(plan["level_begin"]) - 1 == 6
+    assert sorted(_expand(plan, 0, plan["n_pad"])) == list(range(1, 5001))
+
+
+def test_partition_helpers():
+    g = synth.RmatGraph(10, 6000)
+    e = g.edges(salt=1, salt_seed=5)
+    parts = [dist.partition_edges(e, r, 3) for r in range(3)]
+    assert sum(len(p) for p in parts) == len(e)
+    owner = dist.edge_owner(e, 3)
+    # all records of one (from,to) pair live on one rank
+    keys = {}
+    for r, rec in zip(owner.tolist(), e):
+        k = (int(rec["from"]["lo"]), int(rec["from"]["hi"]), int(rec["to"]["lo"]), int(rec["to"]["hi"]))
+        assert keys.setdefault(k, r) == r
+    # dense partition: disjoint cover, CSR consistent
+    tot = []
+    for r in range(3):
+        rp, s = dist.partition_dense(g.row_ptr, g.src, r, 3)
+        assert rp[0] == 0 and rp[-1] == len(s) and np.all(np.diff(rp.astype(np.int64)) >= 0)
+        for v in (0, 1, g.n // 2, g.n - 1):
+            full = g.src[int(g.row_ptr[v]):int(g.row_ptr[v + 1])]
+            idx = np.arange(int(g.row_ptr[v]), int(g.row_ptr[v + 1]))
+            assert np.array_equal(s[int(rp[v]):int(rp[v + 1])], full[idx % 3 == r])
+        tot.append(len(s))
+    assert sum(tot) == g.m

@@ -1,0 +1,206 @@
+"""CPU oracle (oracle/hb_oracle.c) against every known answer the reference's tests hold
+for this path, SURVEY.md Appendix B, and the committed golden fixtures."""
+import json
+import math
+import os
+
+import numpy as np
+import pytest
+
+from oracle import hbo
+from tests import graphs
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden", "hyperball_golden.json")
+
+
+def test_kahan_known_answer():
+    # kahan_sum.rs:87-125 - the only exact float the reference pins on this path
+    vals = [10000.0, math.pi, math.e, math.pi, math.e, math.pi, math.e]
+    s, _ = hbo.kahan_sum(vals)
+    assert s == 10017.579623446147
+
+
+def test_hll_add_positions():
+    # add(1) sets reg[39] = 1, add(0) sets reg[0] = 65
+    r = np.zeros(64, np.uint8)
+    hbo.hll_add(r, 1)
+    assert r[39] == 1 and r.sum() == 1
+    r[:] = 0
+    hbo.hll_add(r, 0)
+    assert r[0] == 65 and np.count_nonzero(r) == 1
+    # only the low 64 bits of a u128 id matter (hyperloglog.rs:4398-4400)
+    r2 = np.zeros(64, np.uint8)
+    hbo.hll_add(r2, (123 << 64) | 0)
+    assert np.array_equal(r, r2)
+
+
+def test_hll_size_sequence():
+    # SURVEY.md Appendix B (independent survey-time derivation)
+    ks = [1, 2, 3, 4, 5, 10, 20, 35, 50, 64, 100, 128, 200, 500, 1000, 10**4, 10**5, 10**6]
+    exp = [1, 2, 3, 4, 5, 10, 23, 67, 89, 110, 181, 226, 364, 875, 1782, 16753, 184912, 1794420]
+    r = np.zeros(64, np.uint8)
+    got, j = [], 0
+    for i in range(10**6):
+        hbo.hll_add(r, i)
+        if i + 1 == ks[j]:
+            got.append(hbo.hll_size(r))
+            j += 1
+    assert got == exp
+
+
+def test_hll_merge_is_union():
+    # hyperloglog.rs:4579-4598 `merge` (there with N = 128): registers of a merged pair
+    # equal those of a counter that saw both streams
+    L = hbo.load()
+    whole, a, b = (np.zeros(64, np.uint8) for _ in range(3))
+    for i in range(10_000):
+        hbo.hll_add(whole, i)
+        hbo.hll_add(a, i)
+    for i in range(10_001, 20_000):
+        hbo.hll_add(whole, i)
+        hbo.hll_add(b, i)
+    L.hbo_hll_merge(a.ctypes.data, b.ctypes.data)
+    assert np.array_equal(a, whole)
+
+
+# hyperloglog.rs:4553-4611 (size_estimate_within_bounds, many_different_sizes,
+# accurate_counts) instantiate N = 128 / 65536 only; with N = 64 the estimator indexes the
+# precision-5 bias rows (SURVEY.md surprise 3) and sequential items under FastHasher give
+# e.g. size(0..10^4) = 16753, so those accuracy bounds do not apply to this path and are
+# not asserted - test_hll_size_sequence pins the exact N = 64 values instead.
+
+
+def _run_faithful(graph):
+    ids, vals, st = hbo.faithful_run(graph.host_edges())
+    return {(int(h) << 64) | int(l): v for l, h, v in zip(ids["lo"], ids["hi"], vals)}, st
+
+
+def test_reference_fixture_ordering_and_values():
+    # harmonic.rs:460-474: C > A > B and D absent
+    res, st = _run_faithful(graphs.fixture_graph())
+    A, B, C, D = graphs.A, graphs.B, graphs.C, graphs.D
+    assert res[C] > res[A] > res[B]
+    assert D not in res
+    # SURVEY.md Appendix B hand derivation: ball sizes A:1,2,4  B:1,2,3,4  C:1,4
+    assert st["passes"] == 4
+    assert np.float64(res[A]).view(np.uint64) == 0x3FE5555555555555
+    assert np.float64(res[B]).view(np.uint64) == 0x3FE38E38E38E38E3
+    assert np.float64(res[C]).view(np.uint64) == 0x3FF0000000000000
+
+
+def test_reference_host_fixture():
+    # harmonic.rs:358-458: B.com > A.com (A.com has only a self-loop -> absent -> 0.0)
+    g, (a, b, c, d) = graphs.host_fixture()
+    res, _ = _run_faithful(g)
+    assert res[b] > res.get(a, 0.0)
+    assert a not in res
+
+
+def test_additional_edges_ignored():
+    # harmonic.rs:476-528: duplicate edges give an identical map
+    base, _ = _run_faithful(graphs.fixture_graph())
+    extra, _ = _run_faithful(graphs.fixture_graph(extra=[(graphs.A, graphs.B, 0)] * 8))
+    assert base == extra
+
+
+@pytest.mark.parametrize("flag", [graphs.TAG, graphs.SAME_ICANN_DOMAIN])
+def test_rel_flags_ignored(flag):
+    # harmonic.rs:530-578: every value == 0.0, i.e. nothing survives the > 0 filter
+    res, st = _run_faithful(graphs.fixture_graph(flags=flag))
+    assert res == {}
+    assert st["n"] == 4 and st["m_eff"] == 0
+
+
+def test_first_occurrence_flag_wins():
+    # store.rs:313 (unique_by) precedes harmonic.rs:131 (flag filter): a later clean copy
+    # of a flagged first record stays lost, a later flagged copy of a clean record is ignored
+    A, B, C = 10, 20, 30
+    lost, _ = _run_faithful(graphs.EdgeListGraph.from_tuples([(A, B, graphs.NOFOLLOW), (A, B, 0), (B, C, 0)]))
+    assert B not in lost and C in lost
+    kept, _ = _run_faithful(graphs.EdgeListGraph.from_tuples([(A, B, 0), (A, B, graphs.NOFOLLOW), (B, C, 0)]))
+    assert B in kept and C in kept
+
+
+def test_lcg_graph_appendix_b():
+    # 7 passes, 200 results, first five values
+    edges = graphs.lcg_graph()
+    ids, row_ptr, src = graphs.dense_from_tuples(edges)
+    o = hbo.Dense(np.ascontiguousarray(ids["lo"]), row_ptr, src)
+    T = o.run()
+    vals, keep, k = o.finish()
+    assert T == 7 and k == 200
+    exp = [0.5506700167504188, 0.6469849246231156, 0.612646566164154, 0.6017587939698492, 0.5182579564489113]
+    assert vals[:5].tolist() == exp
+
+
+def test_dense_equals_faithful_on_salted_rmat():
+    from stract_amd import _lib, synth
+
+    g = synth.RmatGraph(11, 12_000)
+    e = g.edges(salt=1, salt_seed=7)
+    fids, fvals, fst = hbo.faithful_run(e)
+    ids, row_ptr, src, mu = _lib.host_ingest(e)
+    assert fst["n"] == len(ids) and fst["m_unique"] == mu and fst["m_eff"] == len(src)
+    o = hbo.Dense(np.ascontiguousarray(ids["lo"]), row_ptr, src)
+    for flags in (0, hbo.FRONTIER, hbo.FRONTIER | hbo.LITERAL):
+        o = hbo.Dense(np.ascontiguousarray(ids["lo"]), row_ptr, src)
+        T = o.run(flags)
+        vals, keep, k = o.finish()
+        assert T == fst["passes"]
+        assert np.array_equal(ids[keep], fids)
+        assert np.array_equal(vals[keep].view(np.uint64), fvals.view(np.uint64))
+    assert fst["passes_exact"] > 0  # the sqrt(n) tail mode was exercised
+
+
+def test_threads_do_not_change_results():
+    from stract_amd import synth
+
+    g = synth.RmatGraph(12, 40_000)
+    outs = []
+    for th in (1, 4):
+        o = hbo.Dense(g.id_low64(), g.row_ptr, g.src, threads=th)
+        o.run()
+        outs.append((o.registers(), o.kahan()))
+    assert np.array_equal(outs[0][0], outs[1][0])
+    assert np.array_equal(outs[0][1][0].view(np.uint64), outs[1][1][0].view(np.uint64))
+
+
+def test_binary_search_variants_agree_on_reachable_estimates():
+    # The raw-estimate table is unsorted at indices 127/128 and 130/131.
+    # Scan e densely over the table range + every table value and its neighbours.
+    L = hbo.load()
+    raw = np.array([L.hbo_hll_bias_first_index(0.0, 0)])  # noqa: F841 (load check)
+    es = list(np.linspace(20.0, 330.0, 200_001))
+    diffs = 0
+    for e in es:
+        if L.hbo_hll_estimate_bias(e, 0) != L.hbo_hll_estimate_bias(e, 1):
+            diffs += 1
+    # the two std versions may pick different first neighbours only inside the two unsorted
+    # spots; record how often (golden) rather than assume zero
+    gold = json.load(open(GOLD))
+    assert diffs == gold["bsearch_variant_disagreements_linspace_20_330_200001"]
+
+
+def test_golden_vectors():
+    gold = json.load(open(GOLD))
+    regs = np.array(gold["size_cases"]["registers"], dtype=np.uint8)
+    assert hbo.hll_sizes(regs).tolist() == gold["size_cases"]["sizes"]
+    for case in gold["graphs"]:
+        ids, row_ptr, src = graphs.dense_from_tuples([tuple(e) for e in case["edges"]])
+        o = hbo.Dense(np.ascontiguousarray(ids["lo"]), row_ptr, src)
+        T = o.run()
+        vals, keep, k = o.finish()
+        assert T == case["passes"]
+        got = {str((int(h) << 64) | int(l)): float(v).hex() for l, h, v in zip(ids["lo"][keep], ids["hi"][keep], vals[keep])}
+        assert got == case["centrality_hex"]
+
+
+def test_bloom_pieces():
+    # bloom/src/lib.rs:36-41: bits = ceil(n ln(0.05) / (-8 ln^2 2)) ~= 0.78 n
+    assert hbo.load().hbo_bloom_num_bits(1000, 0.05) == 780
+    L = hbo.load()
+    # :108-123 - the logarithm is truncated to i64 BEFORE the multiplication
+    assert L.hbo_bloom_estimate_card(1000, 0) == 0
+    assert L.hbo_bloom_estimate_card(1000, 600) == 0        # ln(0.4) = -0.91 -> 0
+    assert L.hbo_bloom_estimate_card(1000, 700) == 1000     # ln(0.3) = -1.2  -> -1
+    assert L.hbo_bloom_estimate_card(1000, 1000) == 0xFFFFFFFFFFFFFFFF
