@@ -76,8 +76,11 @@ struct hb_ctx {
     uint32_t cur_mode = 0;
 
     hb_stats stats{};
-    std::vector<hb_u128> res_ids;
-    std::vector<double> res_vals;
+    // results: one f64 per node in ascending-NodeID order, -1.0 = absent (centrality <= 0)
+    double *d_out = nullptr;
+    double *h_out = nullptr; // pinned, n entries
+    uint64_t h_out_len = 0;
+    uint64_t res_count = 0;
 };
 
 namespace {
@@ -135,6 +138,10 @@ void free_graph_buffers(hb_ctx *c)
     c->d_counters = nullptr;
     c->d_raw = c->d_bias = nullptr;
     c->d_lc = nullptr;
+    c->d_out = nullptr;
+    if (c->h_out) (void)hipHostFree(c->h_out);
+    c->h_out = nullptr;
+    c->h_out_len = 0;
 }
 
 bool edge_partitioned(const hb_ctx *c) { return c->opt.world_size > 1; }
@@ -206,6 +213,12 @@ int plan_and_upload(hb_ctx *c)
     if ((rc = dev_alloc(c, &c->d_raw, HLL64_TABLE_LEN))) return rc;
     if ((rc = dev_alloc(c, &c->d_bias, HLL64_TABLE_LEN))) return rc;
     if ((rc = dev_alloc(c, &c->d_lc, 68))) return rc;
+    if ((rc = dev_alloc(c, &c->d_out, n))) return rc;
+    if (n) {
+        if (hipHostMalloc((void **)&c->h_out, n * sizeof(double)) != hipSuccess)
+            return fail(c, HB_ERR_NOMEM, "hipHostMalloc(result buffer) failed");
+        c->h_out_len = n;
+    }
 
     uint8_t lc[68];
     if (!build_lc_table(lc)) return fail(c, HB_ERR_INVALID, "host libm log() too close to a rounding boundary for the linear-counting table");
@@ -600,8 +613,7 @@ int hb_begin(hb_ctx *c)
     c->pstats.clear();
     c->begun = true;
     c->finished = false;
-    c->res_ids.clear();
-    c->res_vals.clear();
+    c->res_count = 0;
     return HB_OK;
 }
 
@@ -643,27 +655,23 @@ int hb_finish(hb_ctx *c)
         HB_NCCL(ncclAllGather(c->d_ksum + (uint64_t)c->opt.rank * c->slice_rows, c->d_ksum, c->slice_rows, ncclDouble,
                               c->comm, c->stream));
     }
-    std::vector<double> ksum(p.n_pad ? p.n_pad : 1);
-    if (p.n_pad) HB_HIP(hipMemcpyAsync(ksum.data(), c->d_ksum, p.n_pad * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    HB_HIP(hipStreamSynchronize(c->stream));
-    // normalize_centralities (harmonic.rs:178-195); norm_factor = (num_nodes - 1) as f64 (:229)
-    c->res_ids.clear();
-    c->res_vals.clear();
+    // normalize_centralities (harmonic.rs:178-195) on the device, in ascending-NodeID order;
+    // norm_factor = (num_nodes - 1) as f64 (:229)
     const double norm = (double)(p.n ? p.n - 1 : 0);
-    try {
-        for (uint64_t sid = 0; sid < p.n; sid++) {
-            double s = ksum[p.dev_of[sid]]; // f64::from(KahanSum) = sum (kahan_sum.rs:35-39)
-            if (!(s > 0.0)) continue;
-            double v = s / norm;
-            if (!std::isfinite(v)) v = 0.0;
-            c->res_ids.push_back(c->g.ids[sid]);
-            c->res_vals.push_back(v);
-        }
-    } catch (const std::bad_alloc &) {
-        return fail(c, HB_ERR_NOMEM, "out of host memory collecting results");
+    unsigned long long *cnt = c->d_counters + 4 * (size_t)(c->max_passes - 1) + 3; // spare word
+    HB_HIP(hipMemsetAsync(cnt, 0, sizeof(unsigned long long), c->stream));
+    if (p.n) {
+        unsigned blocks = (unsigned)std::min<uint64_t>((p.n + 255) / 256, (uint64_t)c->num_cu * 8);
+        hipLaunchKernelGGL(hbk::finish_kernel, dim3(blocks), dim3(256), 0, c->stream, (const double *)c->d_ksum,
+                           (const uint32_t *)c->d_dev_of, p.n, norm, c->d_out, cnt);
+        HB_HIP(hipGetLastError());
+        HB_HIP(hipMemcpyAsync(c->h_out, c->d_out, p.n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     }
+    HB_HIP(hipMemcpyAsync(c->h_counters, cnt, sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+    HB_HIP(hipStreamSynchronize(c->stream));
+    c->res_count = c->h_counters[0];
     c->stats.ms_d2h = now_ms() - t0;
-    c->stats.results = c->res_ids.size();
+    c->stats.results = c->res_count;
     c->stats.passes = c->t;
     double g = 0, coll = 0;
     for (auto &ps : c->pstats) { g += ps.ms_gpu; coll += ps.ms_collective; }
@@ -710,7 +718,7 @@ int hb_result_count(hb_ctx *c, uint64_t *count)
 {
     if (!c || !count) return HB_ERR_INVALID;
     if (!c->finished) return fail(c, HB_ERR_INVALID, "no results: hb_run / hb_finish not called");
-    *count = c->res_ids.size();
+    *count = c->res_count;
     return HB_OK;
 }
 
@@ -718,9 +726,16 @@ int hb_result_copy(hb_ctx *c, hb_u128 *ids, double *vals, uint64_t cap)
 {
     if (!c) return HB_ERR_INVALID;
     if (!c->finished) return fail(c, HB_ERR_INVALID, "no results: hb_run / hb_finish not called");
-    uint64_t k = std::min<uint64_t>(cap, c->res_ids.size());
-    if (ids && k) std::memcpy(ids, c->res_ids.data(), k * sizeof(hb_u128));
-    if (vals && k) std::memcpy(vals, c->res_vals.data(), k * sizeof(double));
+    // compaction of the per-node array (absent = negative) into the caller's buffers
+    const uint64_t n = c->plan.n;
+    uint64_t k = 0;
+    for (uint64_t sid = 0; sid < n && k < cap; sid++) {
+        const double v = c->h_out[sid];
+        if (v < 0.0) continue;
+        if (ids) ids[k] = c->g.ids[sid];
+        if (vals) vals[k] = v;
+        k++;
+    }
     return HB_OK;
 }
 

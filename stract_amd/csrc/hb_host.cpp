@@ -342,7 +342,8 @@ bool build_lc_table(uint8_t lc[68])
     bool robust = true;
     lc[0] = 0xFF;
     lc[65] = lc[66] = lc[67] = 0xFF;
-    for (int v = 1; v <= 64; v++) {
+    lc[64] = 0; // 64 ln(1) = 0 exactly in every libm (an all-zero counter; padding rows only)
+    for (int v = 1; v < 64; v++) {
         double h = 64.0 * std::log(64.0 / (double)v);
         if (std::fabs(h - 40.0) < 1e-6) robust = false;
         if (h <= 40.0) {

@@ -543,6 +543,28 @@ __global__ __launch_bounds__(256) void merge_max_kernel(uint4 *dst, const uint4 
     }
 }
 
+// ---- normalize_centralities (harmonic.rs:178-195) -----------------------------------------
+// out[sid] for sid in ascending-NodeID order: f64::from(KahanSum) = sum (kahan_sum.rs:35-39);
+// kept iff > 0.0, then / norm, non-finite -> 0.0; absent nodes are marked -1.0.
+__global__ __launch_bounds__(256) void finish_kernel(const double *ksum, const uint32_t *dev_of, uint64_t n,
+                                                     double norm, double *out, unsigned long long *count)
+{
+    unsigned long long kept = 0;
+    for (uint64_t sid = (uint64_t)blockIdx.x * 256 + threadIdx.x; sid < n; sid += (uint64_t)gridDim.x * 256) {
+        const double s = ksum[dev_of[sid]];
+        double v = -1.0;
+        if (s > 0.0) {
+            v = s / norm;
+            if (!(fabs(v) <= 1.7976931348623157e308)) v = 0.0; // is_finite
+            kept++;
+        }
+        out[sid] = v;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) kept += __shfl_down(kept, off);
+    if ((threadIdx.x & 63) == 0 && kept) atomicAdd(count, kept);
+}
+
 // scatter/gather between device order and ascending-NodeID order (debug exports)
 __global__ __launch_bounds__(256) void gather_rows_kernel(const uint4 *regs, const uint32_t *dev_of, uint64_t n,
                                                           uint4 *out)

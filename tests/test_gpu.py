@@ -1,0 +1,286 @@
+"""Parity tests proper: the HIP path (through the C ABI, stract_amd._lib) against the CPU
+oracle on the same inputs - bit-exact registers, Kahan state, pass counts and final
+(NodeID, f64) lists.  Mirrors the reference's own tests for this path
+(crates/core/src/webgraph/centrality/harmonic.rs:358-578) plus per-pass state checks the
+reference cannot express.  All tests need a gfx950 device; there is no CPU fallback."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle import hbo
+from stract_amd import _lib, dist, synth
+from stract_amd.harmonic import EdgeListGraph, HarmonicCentrality
+from tests import graphs
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden", "hyperball_golden.json")
+
+
+def _as_map(ids, vals):
+    return {(int(h) << 64) | int(l): float(v).hex() for l, h, v in zip(ids["lo"], ids["hi"], vals)}
+
+
+def _oracle_dense(ids, row_ptr, src):
+    o = hbo.Dense(np.ascontiguousarray(ids["lo"]), row_ptr, src)
+    T = o.run()
+    vals, keep, k = o.finish()
+    return o, T, vals, keep, k
+
+
+def _check_final(ctx, ids, T, vals, keep, st):
+    gids, gvals = ctx.results()
+    assert st["passes"] == T
+    assert np.array_equal(gids, ids[keep])
+    assert np.array_equal(gvals.view(np.uint64), vals[keep].view(np.uint64))
+
+
+# ---- estimator ------------------------------------------------------------------------------
+def test_device_estimator_matches_oracle(gpu_ctx_factory):
+    gold = json.load(open(GOLD))
+    regs = np.array(gold["size_cases"]["registers"], dtype=np.uint8)
+    rng = np.random.default_rng(7)
+    more = graphs.random_registers(rng, 20_000)
+    # counters as they occur in a run: k random items added
+    real = np.zeros((3000, 64), dtype=np.uint8)
+    for i in range(len(real)):
+        for x in rng.integers(0, 1 << 63, size=int(rng.integers(1, 400)), dtype=np.uint64):
+            hbo.hll_add(real[i], int(x))
+    with gpu_ctx_factory() as ctx:
+        assert ctx.hll_size(regs).tolist() == gold["size_cases"]["sizes"]
+        for block in (more, real, np.zeros((1, 64), np.uint8), np.full((3, 64), 65, np.uint8)):
+            assert np.array_equal(ctx.hll_size(block), hbo.hll_sizes(block))
+
+
+# ---- the reference's behavioural tests, through the operator mirror ---------------------------
+def test_harmonic_centrality_fixture(gpu_ctx_factory):
+    # harmonic.rs:460-474
+    hc = HarmonicCentrality.calculate(graphs.fixture_graph())
+    A, B, C, D = graphs.A, graphs.B, graphs.C, graphs.D
+    assert hc.get(C) > hc.get(A) > hc.get(B)
+    assert hc.get(D) is None
+    assert hc.len() == 3 and not hc.is_empty()
+    assert [k for k, _ in hc.iter()] == [A, B, C]
+    assert np.float64(hc.get(A)).view(np.uint64) == 0x3FE5555555555555
+    assert np.float64(hc.get(B)).view(np.uint64) == 0x3FE38E38E38E38E3
+    assert np.float64(hc.get(C)).view(np.uint64) == 0x3FF0000000000000
+    assert hc.stats["passes"] == 4
+
+
+def test_host_harmonic_centrality(gpu_ctx_factory):
+    # harmonic.rs:358-458
+    g, (a, b, c, d) = graphs.host_fixture()
+    hc = HarmonicCentrality.calculate(g)
+    assert hc.get(b) > (hc.get(a) or 0.0)
+    assert hc.get(a) is None
+
+
+def test_additional_edges_ignored(gpu_ctx_factory):
+    # harmonic.rs:476-528
+    base = HarmonicCentrality.calculate(graphs.fixture_graph())
+    extra = HarmonicCentrality.calculate(graphs.fixture_graph(extra=[(graphs.A, graphs.B, 0)] * 8))
+    assert _as_map(*base.arrays()) == _as_map(*extra.arrays())
+
+
+@pytest.mark.parametrize("flag", [graphs.TAG, graphs.SAME_ICANN_DOMAIN])
+def test_rel_flags_ignored(gpu_ctx_factory, flag):
+    # harmonic.rs:530-578
+    hc = HarmonicCentrality.calculate(graphs.fixture_graph(flags=flag))
+    assert hc.is_empty() and hc.len() == 0
+    assert hc.stats["n"] == 4 and hc.stats["m_eff"] == 0
+
+
+def test_first_occurrence_flag_wins(gpu_ctx_factory):
+    A, B, C = 10, 20, 30
+    lost = HarmonicCentrality.calculate(EdgeListGraph.from_tuples([(A, B, graphs.NOFOLLOW), (A, B, 0), (B, C, 0)]))
+    assert lost.get(B) is None and lost.get(C) is not None
+    kept = HarmonicCentrality.calculate(EdgeListGraph.from_tuples([(A, B, 0), (A, B, graphs.NOFOLLOW), (B, C, 0)]))
+    assert kept.get(B) is not None and kept.get(C) is not None
+
+
+def test_empty_and_singleton_graphs(gpu_ctx_factory):
+    # n = 0 and n = 1 are defined as "empty result"
+    hc = HarmonicCentrality.calculate(EdgeListGraph(np.zeros(0, dtype=_lib.EDGE)))
+    assert hc.is_empty() and hc.stats["n"] == 0
+    hc = HarmonicCentrality.calculate(EdgeListGraph.from_tuples([(5, 5)]))
+    assert hc.is_empty() and hc.stats["n"] == 1
+    with gpu_ctx_factory() as ctx:
+        with pytest.raises(_lib.HyperballError):
+            ctx.run()  # nothing loaded
+        with pytest.raises(_lib.HyperballError):
+            ctx.results()
+
+
+def test_golden_graphs(gpu_ctx_factory):
+    gold = json.load(open(GOLD))
+    for case in gold["graphs"]:
+        ids, row_ptr, src = graphs.dense_from_tuples([tuple(e) for e in case["edges"]])
+        for kw in (dict(), dict(chunk=4), dict(flags=_lib.HB_FLAG_NO_FRONTIER | _lib.HB_FLAG_NO_REORDER)):
+            hc = HarmonicCentrality.calculate_dense(ids, row_ptr, src, **kw)
+            assert hc.stats["passes"] == case["passes"], (case["name"], kw)
+            assert _as_map(*hc.arrays()) == case["centrality_hex"], (case["name"], kw)
+
+
+# ---- per-pass state parity --------------------------------------------------------------------
+VARIANTS = {
+    "default": dict(),
+    "chunk4_multilevel": dict(chunk=4),
+    "chunk16": dict(chunk=16, tune=(0, 1)),
+    "no_frontier": dict(flags=_lib.HB_FLAG_NO_FRONTIER),
+    "frontier_always": dict(tune=(0, 0, 101)),
+    "no_reorder_unroll4": dict(flags=_lib.HB_FLAG_NO_REORDER, tune=(0, 4)),
+    "unfused": dict(flags=_lib.HB_FLAG_UNFUSED),
+    "unfused_frontier_always": dict(flags=_lib.HB_FLAG_UNFUSED, tune=(0, 0, 101), chunk=8),
+    "pass_stats": dict(flags=_lib.HB_FLAG_PASS_STATS),
+    "few_blocks": dict(tune=(1,)),
+}
+
+
+@pytest.mark.parametrize("variant", sorted(VARIANTS))
+def test_per_pass_state_matches_oracle(gpu_ctx_factory, variant):
+    g = synth.RmatGraph(13, 60_000)
+    o = hbo.Dense(g.id_low64(), g.row_ptr, g.src)
+    kw = VARIANTS[variant]
+    with gpu_ctx_factory(**kw) as ctx:
+        ctx.load_dense(g.ids, g.row_ptr, g.src)
+        ctx.begin()
+        assert np.array_equal(ctx.registers(), o.registers())
+        assert np.array_equal(ctx.sizes(), o.sizes())
+        has = True
+        t = 0
+        while has:
+            has = ctx.step()
+            ohas, ost = o.step(hbo.FRONTIER)
+            assert has == ohas, t
+            assert np.array_equal(ctx.registers(), o.registers()), "registers differ after pass %d" % t
+            s, e = ctx.kahan()
+            os_, oe = o.kahan()
+            assert np.array_equal(s.view(np.uint64), os_.view(np.uint64)), "Kahan sum differs after pass %d" % t
+            assert np.array_equal(e.view(np.uint64), oe.view(np.uint64)), "Kahan err differs after pass %d" % t
+            assert np.array_equal(ctx.sizes(), o.sizes()), t
+            ps = ctx.pass_stats()[t]
+            assert ps["changed"] == ost["changed"], t
+            if kw.get("flags", 0) & _lib.HB_FLAG_PASS_STATS and ps["mode"] == 1:
+                assert ps["active_edges"] == ost["active_edges"], t
+            t += 1
+        ctx.finish()
+        vals, keep, k = o.finish()
+        _check_final(ctx, g.ids, t, vals, keep, ctx.stats())
+
+
+def test_salted_edge_records_match_faithful_oracle(gpu_ctx_factory):
+    g = synth.RmatGraph(12, 30_000)
+    e = g.edges(salt=1, salt_seed=3)
+    fids, fvals, fst = hbo.faithful_run(e)
+    graph = EdgeListGraph(e)
+    hc = HarmonicCentrality.calculate(graph)
+    ids, vals = hc.arrays()
+    assert hc.stats["n"] == fst["n"] and hc.stats["m_unique"] == fst["m_unique"] and hc.stats["m_eff"] == fst["m_eff"]
+    assert hc.stats["passes"] == fst["passes"]
+    assert np.array_equal(ids, fids)
+    assert np.array_equal(vals.view(np.uint64), fvals.view(np.uint64))
+    # chunked hand-over, node set derived by the library
+    with gpu_ctx_factory() as ctx:
+        for part in np.array_split(e, 7):
+            ctx.append_edges(part)
+        ctx.finalize()
+        ctx.run()
+        ids2, vals2 = ctx.results()
+    assert np.array_equal(ids2, fids) and np.array_equal(vals2.view(np.uint64), fvals.view(np.uint64))
+
+
+def test_hub_rows_and_isolated_nodes(gpu_ctx_factory):
+    # a 3000-source star (multi-level virtual rows at chunk 8), a long chain (many passes in
+    # frontier mode) and nodes that only appear on flagged edges (count in n, no output row)
+    tuples = [(i, 1, 0) for i in range(2, 3002)] + [(5000 + i, 5001 + i, 0) for i in range(300)]
+    tuples += [(1, 5000, 0), (9001, 9002, graphs.NOFOLLOW), (9003, 1, graphs.TAG)]
+    e = EdgeListGraph.from_tuples(tuples)
+    fids, fvals, fst = hbo.faithful_run(e.host_edges())
+    for kw in (dict(chunk=8), dict(), dict(chunk=8, flags=_lib.HB_FLAG_UNFUSED)):
+        hc = HarmonicCentrality.calculate(e, **kw)
+        ids, vals = hc.arrays()
+        assert hc.stats["passes"] == fst["passes"] and hc.stats["n"] == fst["n"]
+        assert np.array_equal(ids, fids) and np.array_equal(vals.view(np.uint64), fvals.view(np.uint64)), kw
+
+
+# ---- edge-partition mode ------------------------------------------------------------------------
+@pytest.mark.parametrize("world", [2, 3])
+def test_logical_ranks_on_one_device(gpu_ctx_factory, world):
+    """SURVEY.md §8(e) caveat: R logical ranks on one device, the all-reduce(max) emulated by
+    hb_debug_merge_pending; every rank must reproduce the single-GPU result bit for bit."""
+    g = synth.RmatGraph(12, 40_000)
+    o, T, vals, keep, k = _oracle_dense(g.ids, g.row_ptr, g.src)
+    ctxs = []
+    try:
+        for r in range(world):
+            c = gpu_ctx_factory(rank=r, world_size=world, flags=_lib.HB_FLAG_NO_RCCL, chunk=16)
+            rp, src = dist.partition_dense(g.row_ptr, g.src, r, world)
+            c.load_dense(g.ids, rp, src)
+            c.begin()
+            ctxs.append(c)
+        has, t = True, 0
+        while has:
+            for c in ctxs:
+                c.step_local()
+            for c in ctxs[1:]:
+                ctxs[0].merge_pending(c)
+            for c in ctxs[1:]:
+                c.merge_pending(ctxs[0])
+            flags = [c.step_finish() for c in ctxs]
+            assert len(set(flags)) == 1
+            has = flags[0]
+            t += 1
+        assert t == T
+        for c in ctxs:
+            c.finish()
+            assert np.array_equal(c.registers(), o.registers())
+            _check_final(c, g.ids, T, vals, keep, c.stats())
+    finally:
+        for c in ctxs:
+            c.close()
+
+
+def test_rccl_call_path_single_rank(gpu_ctx_factory):
+    """A 1-rank RCCL communicator: ncclAllReduce(max, u8) / ncclAllGather run for real."""
+    g = synth.RmatGraph(12, 40_000)
+    o, T, vals, keep, k = _oracle_dense(g.ids, g.row_ptr, g.src)
+    uid = _lib.rccl_unique_id()
+    with gpu_ctx_factory(flags=_lib.HB_FLAG_RCCL_SELF, rccl_id=uid) as ctx:
+        ctx.load_dense(g.ids, g.row_ptr, g.src)
+        st = ctx.run()
+        _check_final(ctx, g.ids, T, vals, keep, st)
+        assert st["ms_collective"] > 0.0
+
+
+# ---- larger sizes ---------------------------------------------------------------------------------
+def test_c1_config_bit_exact(gpu_ctx_factory):
+    cfg = synth.CONFIGS["C1"]
+    g = synth.RmatGraph(cfg["scale"], cfg["m"])
+    o, T, vals, keep, k = _oracle_dense(g.ids, g.row_ptr, g.src)
+    with gpu_ctx_factory() as ctx:
+        ctx.load_dense(g.ids, g.row_ptr, g.src)
+        st = ctx.run()
+        _check_final(ctx, g.ids, T, vals, keep, st)
+        assert np.array_equal(ctx.registers(), o.registers())
+
+
+def test_c2_config_bit_exact_and_properties(gpu_ctx_factory):
+    """BASELINE.json configs[1]: 1M-host / 20M-edge, 1 GPU, bit-exact vs the oracle; plus
+    size-independent properties: idempotence of a re-run, independence from the device
+    layout (reorder / chunking / frontier), monotone counters."""
+    cfg = synth.CONFIGS["C2"]
+    g = synth.RmatGraph(cfg["scale"], cfg["m"])
+    o, T, vals, keep, k = _oracle_dense(g.ids, g.row_ptr, g.src)
+    outs = []
+    for kw in (dict(), dict(flags=_lib.HB_FLAG_NO_REORDER | _lib.HB_FLAG_NO_FRONTIER, chunk=256)):
+        with gpu_ctx_factory(**kw) as ctx:
+            ctx.load_dense(g.ids, g.row_ptr, g.src)
+            st = ctx.run()
+            _check_final(ctx, g.ids, T, vals, keep, st)
+            regs = ctx.registers()
+            assert np.array_equal(regs, o.registers())
+            st2 = ctx.run()  # re-running the loaded graph gives the same answer
+            _check_final(ctx, g.ids, T, vals, keep, st2)
+            outs.append(regs)
+    assert np.array_equal(outs[0], outs[1])
