@@ -145,7 +145,7 @@ void free_graph_buffers(hb_ctx *c)
 }
 
 bool edge_partitioned(const hb_ctx *c) { return c->opt.world_size > 1; }
-bool unfused(const hb_ctx *c) { return edge_partitioned(c) || (c->opt.flags & HB_FLAG_UNFUSED); }
+bool unfused(const hb_ctx *c) { return edge_partitioned(c) || c->comm || (c->opt.flags & HB_FLAG_UNFUSED); }
 
 // ---- plan + upload (common tail of every load entry point) -------------------------------
 int plan_and_upload(hb_ctx *c)

@@ -19,7 +19,7 @@ GOLD = os.path.join(os.path.dirname(__file__), "golden", "hyperball_golden.json"
 
 
 def _as_map(ids, vals):
-    return {(int(h) << 64) | int(l): float(v).hex() for l, h, v in zip(ids["lo"], ids["hi"], vals)}
+    return {str((int(h) << 64) | int(l)): float(v).hex() for l, h, v in zip(ids["lo"], ids["hi"], vals)}
 
 
 def _oracle_dense(ids, row_ptr, src):

@@ -1,0 +1,23 @@
+#!/bin/bash
+# Runs on the GPU box (via gpurun): rocprofv3 kernel trace + stats of bench.py, then the HBM
+# PMC counters in their own passes (never combined with tracing; FETCH_SIZE and WRITE_SIZE do
+# not fit one pass: /opt/skills/guides/MI355X_MICROARCH.md "rocprofv3 PMC slots").
+# usage: tools/profile.sh <config> <tag> [extra bench args]
+set -u
+CFG=${1:-C3}
+TAG=${2:-r01}
+shift 2 || true
+ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+OUT=$ROOT/gpurun_out/prof_${TAG}_${CFG}
+mkdir -p "$OUT"
+cd /tmp && export TMPDIR=/tmp
+BENCH="python $ROOT/bench.py --config $CFG --steps 2 --warmup 1 --cpu-seconds 0 $*"
+timeout 900 rocprofv3 --kernel-trace --stats -d "$OUT/trace" -o trace -- $BENCH > "$OUT/trace.log" 2>&1
+for C in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum" "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum" "TCP_TCC_READ_REQ_sum TCC_REQ_sum"; do
+    name=$(echo $C | tr ' ' '+')
+    timeout 900 rocprofv3 --pmc $C -d "$OUT/pmc_$name" -o pmc -- $BENCH > "$OUT/pmc_$name.log" 2>&1
+done
+# keep what is small enough to travel back: stats + counter CSVs (kernel trace can be large)
+find "$OUT" -name "*.csv" -size +20M -delete
+python $ROOT/tools/pmc_summary.py "$OUT" "$CFG" > "$OUT/summary.json" 2> "$OUT/summary.err"
+ls -la "$OUT" "$OUT"/*/ 2>/dev/null | head -50
