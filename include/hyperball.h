@@ -225,8 +225,8 @@ int hb_host_ingest(const hb_u128 *node_ids, uint64_t n, const hb_edge *edges, ui
  * Two-call pattern: sizes[0..3] = {n_pad, nv, plan_src_len, levels}; then
  * order[n], plan_row_ptr[n_pad+nv+1], plan_src[plan_src_len], level_begin[levels+1]. */
 int hb_host_plan(uint64_t n, const uint64_t *row_ptr, const uint32_t *src, uint32_t flags,
-                 uint32_t chunk, uint64_t sizes[4], uint32_t *order, uint64_t *plan_row_ptr,
-                 uint32_t *plan_src, uint64_t *level_begin);
+                 uint32_t chunk, const uint32_t *tune /* hb_options.tune or NULL */, uint64_t sizes[4],
+                 uint32_t *order, uint64_t *plan_row_ptr, uint32_t *plan_src, uint64_t *level_begin);
 
 #ifdef __cplusplus
 }

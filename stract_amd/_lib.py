@@ -121,7 +121,7 @@ _SIGNATURES = [
     ("hb_step_finish", ctypes.c_int, [_P, ctypes.POINTER(ctypes.c_int)]),
     ("hb_host_ingest", ctypes.c_int, [_P, _U64, _P, _U64, ctypes.POINTER(_U64), ctypes.POINTER(_U64),
                                       ctypes.POINTER(_U64), _P, _P, _P]),
-    ("hb_host_plan", ctypes.c_int, [_U64, _P, _P, ctypes.c_uint32, ctypes.c_uint32, _P, _P, _P, _P, _P]),
+    ("hb_host_plan", ctypes.c_int, [_U64, _P, _P, ctypes.c_uint32, ctypes.c_uint32, _P, _P, _P, _P, _P, _P]),
 ]
 SYMBOLS = [s[0] for s in _SIGNATURES]
 
@@ -364,14 +364,16 @@ def host_ingest(edges, node_ids=None):
     return ids, row_ptr, src, mu.value
 
 
-def host_plan(row_ptr, src, flags=0, chunk=0):
+def host_plan(row_ptr, src, flags=0, chunk=0, tune=()):
     """Host-only: the device work layout (order, plan_row_ptr, plan_src, level_begin, n_pad)."""
     lib = load()
     row_ptr = np.ascontiguousarray(row_ptr, dtype=np.uint64)
     src = np.ascontiguousarray(src, dtype=np.uint32)
     n = len(row_ptr) - 1
     sizes = np.zeros(4, dtype=np.uint64)
-    rc = lib.hb_host_plan(n, _ptr(row_ptr), _ptr(src), flags, chunk, _ptr(sizes), None, None, None, None)
+    tn = np.zeros(8, dtype=np.uint32)
+    tn[:len(tune)] = tune
+    rc = lib.hb_host_plan(n, _ptr(row_ptr), _ptr(src), flags, chunk, _ptr(tn), _ptr(sizes), None, None, None, None)
     if rc != HB_OK:
         raise HyperballError(rc, (lib.hb_last_error(None) or b"").decode())
     n_pad, nv, slen, levels = (int(x) for x in sizes)
@@ -379,8 +381,8 @@ def host_plan(row_ptr, src, flags=0, chunk=0):
     prp = np.zeros(n_pad + nv + 1, dtype=np.uint64)
     psrc = np.zeros(slen, dtype=np.uint32)
     lb = np.zeros(levels + 1, dtype=np.uint64)
-    rc = lib.hb_host_plan(n, _ptr(row_ptr), _ptr(src), flags, chunk, _ptr(sizes), _ptr(order), _ptr(prp), _ptr(psrc),
-                          _ptr(lb))
+    rc = lib.hb_host_plan(n, _ptr(row_ptr), _ptr(src), flags, chunk, _ptr(tn), _ptr(sizes), _ptr(order), _ptr(prp),
+                          _ptr(psrc), _ptr(lb))
     if rc != HB_OK:
         raise HyperballError(rc, (lib.hb_last_error(None) or b"").decode())
     return dict(order=order, row_ptr=prp, src=psrc, level_begin=lb, n_pad=n_pad, nv=nv)

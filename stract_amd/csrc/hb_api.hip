@@ -144,6 +144,20 @@ void free_graph_buffers(hb_ctx *c)
     c->h_out_len = 0;
 }
 
+// hb_options.chunk / tune[3..5] -> planner knobs
+PlanTune plan_tune(uint32_t chunk, const uint32_t *tune)
+{
+    PlanTune t;
+    t.chunk = chunk ? chunk : kDefaultChunk;
+    if (tune) {
+        if (tune[3] == 1) t.band_w = 0;                     // banding off
+        else if (tune[3] >= 4 && tune[3] < 31) t.band_w = 1u << tune[3];
+        if (tune[4]) t.minc = tune[4];
+        if (tune[5]) t.direct_max = tune[5];
+    }
+    return t;
+}
+
 bool edge_partitioned(const hb_ctx *c) { return c->opt.world_size > 1; }
 bool unfused(const hb_ctx *c) { return edge_partitioned(c) || c->comm || (c->opt.flags & HB_FLAG_UNFUSED); }
 
@@ -179,8 +193,8 @@ int plan_and_upload(hb_ctx *c)
             if (e != hipSuccess) return fail(c, HB_ERR_HIP, std::string("out-degree all-reduce: ") + hipGetErrorString(e));
         }
     }
-    uint32_t chunk = c->opt.chunk ? c->opt.chunk : kDefaultChunk;
-    std::string perr = build_plan(n, c->g.row_ptr.data(), c->g.src.data(), outdeg, reorder, chunk, &c->plan);
+    std::string perr = build_plan(n, c->g.row_ptr.data(), c->g.src.data(), outdeg, reorder,
+                                  plan_tune(c->opt.chunk, c->opt.tune), &c->plan);
     if (!perr.empty()) return fail(c, perr.find("memory") != std::string::npos ? HB_ERR_NOMEM : HB_ERR_LIMIT, perr);
     c->stats.ms_plan = now_ms() - t0;
     const Plan &p = c->plan;
@@ -857,7 +871,8 @@ int hb_host_ingest(const hb_u128 *node_ids, uint64_t n, const hb_edge *edges, ui
 }
 
 int hb_host_plan(uint64_t n, const uint64_t *row_ptr, const uint32_t *src, uint32_t flags, uint32_t chunk,
-                 uint64_t sizes[4], uint32_t *order, uint64_t *plan_row_ptr, uint32_t *plan_src, uint64_t *level_begin)
+                 const uint32_t *tune, uint64_t sizes[4], uint32_t *order, uint64_t *plan_row_ptr, uint32_t *plan_src,
+                 uint64_t *level_begin)
 {
     hb_ctx *c = nullptr;
     if (!sizes || (n && !row_ptr)) return fail(c, HB_ERR_INVALID, "NULL argument");
@@ -867,7 +882,7 @@ int hb_host_plan(uint64_t n, const uint64_t *row_ptr, const uint32_t *src, uint3
     if (n == 0) row_ptr = &zero;
     if (reorder) count_out_degree(row_ptr, src, n, &outdeg);
     Plan p;
-    std::string e = build_plan(n, row_ptr, src, outdeg, reorder, chunk ? chunk : kDefaultChunk, &p);
+    std::string e = build_plan(n, row_ptr, src, outdeg, reorder, plan_tune(chunk, tune), &p);
     if (!e.empty()) return fail(c, HB_ERR_LIMIT, e);
     sizes[0] = p.n_pad;
     sizes[1] = p.nv;

@@ -198,10 +198,14 @@ void count_out_degree(const uint64_t *row_ptr, const uint32_t *src, uint64_t n, 
 // so the pass stays a synchronous (Jacobi) pull with one writer per row.
 // ---------------------------------------------------------------------------------------
 std::string build_plan(uint64_t n, const uint64_t *row_ptr, const uint32_t *src,
-                       const std::vector<uint32_t> &out_degree, bool reorder, uint32_t chunk, Plan *p)
+                       const std::vector<uint32_t> &out_degree, bool reorder, const PlanTune &tune_in, Plan *p)
 {
+    PlanTune tune = tune_in;
+    uint32_t chunk = tune.chunk ? tune.chunk : kDefaultChunk;
     if (chunk < 4) chunk = 4;
     if (chunk > 4096) chunk = 4096;
+    if (tune.direct_max == 0 || tune.direct_max > chunk) tune.direct_max = chunk;
+    if (tune.minc == 0) tune.minc = 16;
     p->n = n;
     p->n_pad = (n + kRowAlign - 1) / kRowAlign * kRowAlign;
     p->chunk = chunk;
@@ -241,70 +245,117 @@ std::string build_plan(uint64_t n, const uint64_t *row_ptr, const uint32_t *src,
         }
 
         // ---- hub splitting, level by level
-        // cur_len[d] / cur lists: the list a real row currently reads.  Level 0: its real
-        // sources (in rs).  After splitting at level l its list is a run of virtual ids.
-        struct Split { uint32_t row; uint64_t first_vid; uint32_t count; };
+        // Level 1: a hub row's (ascending = hottest-first) source list is cut into chunks of
+        // <= chunk sources; a cut is also made where the list crosses a band boundary of the
+        // source index space (band 0 = the `band_w` hottest counters = what one XCD's L2 holds,
+        // then bands doubling in width), provided the chunk already has >= minc sources.  The
+        // chunks of ALL rows are then ordered by band, so that workgroups running at the same
+        // time gather from the same few MiB of the counter array (L2 hits instead of fabric
+        // requests; measured ceilings: tools/gather_bench.hip).
         std::vector<uint64_t> vrow_ptr; // offsets of virtual rows' lists in vsrc
         std::vector<uint32_t> vsrc;
         vrow_ptr.push_back(0);
-        // For real rows that were split: their final (short) list of virtual ids.
         std::vector<uint8_t> is_split(n, 0);
-        std::vector<uint64_t> split_first(n, 0);
-        std::vector<uint32_t> split_count(n, 0);
         uint64_t next_vid = p->n_pad;
         p->level_begin.push_back(next_vid);
-        // level 1 from real sources
-        std::vector<Split> cur;
+        auto band_of = [&](uint32_t idx) -> uint32_t {
+            if (!tune.band_w || idx < tune.band_w) return 0;
+            return 1u + (uint32_t)(63 - __builtin_clzll((uint64_t)idx / tune.band_w));
+        };
+        struct Chunk { uint64_t beg; uint32_t len; uint32_t key; };
+        std::vector<Chunk> chunks;
+        std::vector<uint32_t> hub_rows;          // split rows, ascending
+        std::vector<uint64_t> hub_first;         // first chunk (creation order) of each split row, +1 sentinel
+        const uint32_t minc = std::max<uint32_t>(1, std::min(tune.minc, chunk));
         for (uint64_t d = 0; d < n; d++) {
-            uint64_t deg = rp[d + 1] - rp[d];
-            if (deg <= chunk) continue;
-            uint32_t parts = (uint32_t)((deg + chunk - 1) / chunk);
-            uint64_t per = (deg + parts - 1) / parts;
-            Split sp{(uint32_t)d, next_vid, parts};
-            for (uint32_t k = 0; k < parts; k++) {
-                uint64_t b = rp[d] + (uint64_t)k * per, e = std::min(rp[d + 1], b + per);
-                vsrc.insert(vsrc.end(), rs.begin() + b, rs.begin() + e);
-                vrow_ptr.push_back(vsrc.size());
+            const uint64_t b = rp[d], e = rp[d + 1];
+            if (e - b <= tune.direct_max) continue;
+            is_split[d] = 1;
+            hub_rows.push_back((uint32_t)d);
+            hub_first.push_back(chunks.size());
+            uint64_t i = b;
+            while (i < e) {
+                const uint32_t b0 = band_of(rs[i]);
+                uint64_t j = i + 1;
+                while (j < e && j - i < chunk) {
+                    if (j - i >= minc && band_of(rs[j]) != b0) break;
+                    j++;
+                }
+                // do not leave a tiny remainder behind: absorb it when it fits
+                if (e - j < minc && e - i <= chunk) j = e;
+                chunks.push_back({i, (uint32_t)(j - i), b0});
+                i = j;
             }
-            next_vid += parts;
-            cur.push_back(sp);
         }
+        hub_first.push_back(chunks.size());
+        // order: band ascending, longer chunks first inside a band (wave-uniform trip counts)
+        std::vector<uint32_t> corder(chunks.size());
+        std::iota(corder.begin(), corder.end(), 0u);
+        std::stable_sort(corder.begin(), corder.end(), [&](uint32_t a, uint32_t b2) {
+            if (chunks[a].key != chunks[b2].key) return chunks[a].key < chunks[b2].key;
+            return chunks[a].len > chunks[b2].len;
+        });
+        std::vector<uint32_t> vid_of(chunks.size());
+        vsrc.reserve(p->m_eff);
+        for (size_t k = 0; k < corder.size(); k++) {
+            const Chunk &c = chunks[corder[k]];
+            vid_of[corder[k]] = (uint32_t)(next_vid + k);
+            vsrc.insert(vsrc.end(), rs.begin() + c.beg, rs.begin() + c.beg + c.len);
+            vrow_ptr.push_back(vsrc.size());
+        }
+        next_vid += chunks.size();
+        // per split row: the list of virtual ids it currently reads (flat, CSR-like)
+        std::vector<uint64_t> lptr(hub_rows.size() + 1, 0);
+        std::vector<uint32_t> lids(chunks.size());
+        for (size_t h = 0; h < hub_rows.size(); h++) {
+            lptr[h] = hub_first[h];
+            for (uint64_t k = hub_first[h]; k < hub_first[h + 1]; k++) lids[k] = vid_of[k];
+        }
+        lptr[hub_rows.size()] = chunks.size();
         auto pad_level = [&]() {
             while ((next_vid - p->n_pad) % kRowAlign) {
                 vrow_ptr.push_back(vsrc.size());
                 next_vid++;
             }
         };
+        // upper levels: while some row still reads more than `chunk` virtual rows, group them
         while (true) {
             pad_level();
             p->level_begin.push_back(next_vid);
-            std::vector<Split> nxt;
-            for (const Split &sp : cur) {
-                if (sp.count <= chunk) {
-                    is_split[sp.row] = 1;
-                    split_first[sp.row] = sp.first_vid;
-                    split_count[sp.row] = sp.count;
+            bool any = false;
+            std::vector<uint64_t> nptr(hub_rows.size() + 1, 0);
+            std::vector<uint32_t> nids;
+            nids.reserve(lids.size() / 2 + 16);
+            for (size_t h = 0; h < hub_rows.size(); h++) {
+                nptr[h] = nids.size();
+                const uint64_t cnt = lptr[h + 1] - lptr[h];
+                if (cnt <= chunk) {
+                    nids.insert(nids.end(), lids.begin() + lptr[h], lids.begin() + lptr[h + 1]);
                     continue;
                 }
-                uint32_t parts = (sp.count + chunk - 1) / chunk;
-                uint64_t per = ((uint64_t)sp.count + parts - 1) / parts;
-                Split ns{sp.row, next_vid, parts};
-                for (uint32_t k = 0; k < parts; k++) {
-                    uint64_t b = (uint64_t)k * per, e = std::min<uint64_t>(sp.count, b + per);
-                    for (uint64_t i = b; i < e; i++) vsrc.push_back((uint32_t)(sp.first_vid + i));
+                any = true;
+                const uint64_t parts = (cnt + chunk - 1) / chunk;
+                const uint64_t per = (cnt + parts - 1) / parts;
+                for (uint64_t k = 0; k < parts; k++) {
+                    const uint64_t b = lptr[h] + k * per, e = std::min<uint64_t>(lptr[h + 1], b + per);
+                    vsrc.insert(vsrc.end(), lids.begin() + b, lids.begin() + e);
                     vrow_ptr.push_back(vsrc.size());
+                    nids.push_back((uint32_t)next_vid++);
                 }
-                next_vid += parts;
-                nxt.push_back(ns);
             }
-            if (nxt.empty()) break;
-            cur.swap(nxt);
+            nptr[hub_rows.size()] = nids.size();
+            lptr.swap(nptr);
+            lids.swap(nids);
+            if (!any) break;
         }
         if (p->level_begin.size() >= 2 && p->level_begin[p->level_begin.size() - 1] ==
                                               p->level_begin[p->level_begin.size() - 2])
             p->level_begin.pop_back(); // no trailing empty level
         p->nv = next_vid - p->n_pad;
         if (next_vid >= (uint64_t)kNone) return "row id space exhausted (n + virtual rows >= 2^32 - 1)";
+        // hub index of a split row (for the assembly below)
+        std::vector<uint32_t> hub_index(n, 0);
+        for (size_t h = 0; h < hub_rows.size(); h++) hub_index[hub_rows[h]] = (uint32_t)h;
 
         // ---- assemble: real rows [0, n_pad), then virtual rows
         const uint64_t rows_total = p->n_pad + p->nv;
@@ -312,7 +363,7 @@ std::string build_plan(uint64_t n, const uint64_t *row_ptr, const uint32_t *src,
         uint64_t total = 0;
         for (uint64_t d = 0; d < n; d++) {
             p->row_ptr[d] = total;
-            total += is_split[d] ? split_count[d] : (rp[d + 1] - rp[d]);
+            total += is_split[d] ? (lptr[hub_index[d] + 1] - lptr[hub_index[d]]) : (rp[d + 1] - rp[d]);
         }
         for (uint64_t d = n; d <= p->n_pad; d++) p->row_ptr[d] = total;
         const uint64_t real_total = total;
@@ -322,7 +373,8 @@ std::string build_plan(uint64_t n, const uint64_t *row_ptr, const uint32_t *src,
         for (int64_t d = 0; d < (int64_t)n; d++) {
             uint64_t o = p->row_ptr[d];
             if (is_split[d]) {
-                for (uint32_t k = 0; k < split_count[d]; k++) p->src[o + k] = (uint32_t)(split_first[d] + k);
+                const uint64_t b = lptr[hub_index[d]], e = lptr[hub_index[d] + 1];
+                std::memcpy(p->src.data() + o, lids.data() + b, (e - b) * sizeof(uint32_t));
             } else {
                 std::memcpy(p->src.data() + o, rs.data() + rp[d], (rp[d + 1] - rp[d]) * sizeof(uint32_t));
             }

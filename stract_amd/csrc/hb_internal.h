@@ -43,6 +43,14 @@ struct Plan {
     std::vector<uint64_t> level_begin; // virtual level l = rows [level_begin[l], level_begin[l+1])
 };
 
+// Planner knobs (hb_options.chunk / tune[3..5]).
+struct PlanTune {
+    uint32_t chunk = kDefaultChunk; // max sources per work row
+    uint32_t band_w = 1u << 16;     // hottest band of the source index space, in counters (0 = no banding)
+    uint32_t minc = 16;             // a band cut needs at least this many sources in the chunk
+    uint32_t direct_max = 0;        // rows with at most this many sources are not split (0 = chunk)
+};
+
 // --- hb_host.cpp ---------------------------------------------------------------------
 // Reference ingest semantics: node set (store.rs:338-357), first-occurrence dedup
 // (store.rs:313), then rel-flag filter (harmonic.rs:131).  Returns "" or an error text.
@@ -54,7 +62,7 @@ std::string check_dense(const hb_u128 *sorted_ids, uint64_t n, const uint64_t *r
 void count_out_degree(const uint64_t *row_ptr, const uint32_t *src, uint64_t n, std::vector<uint32_t> *deg);
 // Builds the device layout.  global_out_degree: per sid (already summed over ranks).
 std::string build_plan(uint64_t n, const uint64_t *row_ptr, const uint32_t *src,
-                       const std::vector<uint32_t> &global_out_degree, bool reorder, uint32_t chunk,
+                       const std::vector<uint32_t> &global_out_degree, bool reorder, const PlanTune &tune,
                        Plan *plan);
 // Tables for the estimator's linear-counting branch (hyperloglog.rs:4472-4476,
 // :4505-4515): lc[v] = trunc(64 ln(64/v)) when that is <= 40, else 0xFF (v = 0..64).  Built with the

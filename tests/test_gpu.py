@@ -134,6 +134,8 @@ VARIANTS = {
     "unfused_frontier_always": dict(flags=_lib.HB_FLAG_UNFUSED, tune=(0, 0, 101), chunk=8),
     "pass_stats": dict(flags=_lib.HB_FLAG_PASS_STATS),
     "few_blocks": dict(tune=(1,)),
+    "banded_chunks": dict(chunk=16, tune=(0, 0, 0, 6, 4)),
+    "banded_frontier_small_direct": dict(chunk=32, tune=(0, 0, 101, 5, 8, 8)),
 }
 
 

@@ -113,10 +113,14 @@ def _expand(plan, row, n_pad):
     return out
 
 
-@pytest.mark.parametrize("chunk,flags", [(4, 0), (16, 0), (64, 0), (8, _lib.HB_FLAG_NO_REORDER)])
-def test_planner_invariants(chunk, flags):
+@pytest.mark.parametrize("chunk,flags,tune", [(4, 0, ()), (16, 0, ()), (64, 0, ()), (8, _lib.HB_FLAG_NO_REORDER, ()),
+                                              (16, 0, (0, 0, 0, 6, 4)), (64, 0, (0, 0, 0, 5, 8, 16)),
+                                              (32, 0, (0, 0, 0, 1))])
+def test_planner_invariants(chunk, flags, tune):
+    # tune[3] = log2 of the hottest source band (1 = banding off), tune[4] = min sources before a band
+    # cut, tune[5] = largest row that is not split
     g = synth.RmatGraph(12, 40_000)
-    plan = _lib.host_plan(g.row_ptr, g.src, flags, chunk)
+    plan = _lib.host_plan(g.row_ptr, g.src, flags, chunk, tune)
     n, n_pad = g.n, plan["n_pad"]
     order = plan["order"].astype(np.int64)
     assert sorted(order.tolist()) == list(range(n))          # a permutation

@@ -1,0 +1,141 @@
+// gather_bench.hip - ceiling of the access pattern the HyperBall pass is made of: one quad
+// (4 lanes x 16 B) gathers one 64-byte counter, byte-max accumulates, 64 gathers per row.
+// Measures GB/s of gathered bytes for source indices drawn uniformly from a region of R
+// counters (R*64 B = 4 MiB one L2 ... 8 GiB HBM) and for an exactly-once permutation (known
+// byte count: calibrates rocprofv3 FETCH_SIZE for 64-byte gathers on gfx950).
+// Build: hipcc --offload-arch=gfx950 -O3 tools/gather_bench.hip -o gpurun_out/gather_bench
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
+
+typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pkmax(uint32_t a, uint32_t b)
+{
+    us2 x = __builtin_bit_cast(us2, a), y = __builtin_bit_cast(us2, b);
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(x, y));
+}
+template <int J> __device__ __forceinline__ uint32_t qb(uint32_t v)
+{
+    return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, J * 0x55, 0xF, 0xF, true);
+}
+
+template <int UNROLL>
+__global__ __launch_bounds__(256) void gather_kernel(const uint32_t *idx, const uint4 *regs, uint4 *out, uint64_t rows, int deg)
+{
+    const int lane = threadIdx.x & 63, q = lane & 3;
+    const uint64_t ntiles = (rows + 63) / 64;
+    for (uint64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const uint64_t row = tile * 64 + (threadIdx.x >> 2);
+        if (row >= rows) continue;
+        uint32_t e[4] = {0, 0, 0, 0}, o[4] = {0, 0, 0, 0};
+        const uint32_t *p = idx + row * deg;
+        for (int k = 0; k < deg; k += 4 * UNROLL) {
+            uint32_t id[UNROLL];
+#pragma unroll
+            for (int u = 0; u < UNROLL; u++) id[u] = p[k + 4 * u + q];
+            uint4 r[UNROLL][4];
+#pragma unroll
+            for (int u = 0; u < UNROLL; u++) {
+                r[u][0] = regs[(uint64_t)qb<0>(id[u]) * 4 + q];
+                r[u][1] = regs[(uint64_t)qb<1>(id[u]) * 4 + q];
+                r[u][2] = regs[(uint64_t)qb<2>(id[u]) * 4 + q];
+                r[u][3] = regs[(uint64_t)qb<3>(id[u]) * 4 + q];
+            }
+#pragma unroll
+            for (int u = 0; u < UNROLL; u++)
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const uint32_t w[4] = {r[u][j].x, r[u][j].y, r[u][j].z, r[u][j].w};
+#pragma unroll
+                    for (int c = 0; c < 4; c++) {
+                        e[c] = pkmax(e[c], w[c] & 0x00FF00FFu);
+                        o[c] = pkmax(o[c], w[c] & 0xFF00FF00u);
+                    }
+                }
+        }
+        out[row * 4 + q] = make_uint4(e[0] | o[0], e[1] | o[1], e[2] | o[2], e[3] | o[3]);
+    }
+}
+
+__global__ void stream_kernel(const uint4 *in, uint4 *out, uint64_t n4)
+{
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (uint64_t)gridDim.x * 256) out[i] = in[i];
+}
+
+static uint64_t sm(uint64_t &s)
+{
+    uint64_t z = (s += 0x9E3779B97F4A7C15ull);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+int main(int argc, char **argv)
+{
+    const uint64_t total = 1ull << 27;       // counters in the big array: 8 GiB
+    const uint64_t rows = 1ull << 21;        // 2 Mi rows x 64 gathers = 128 Mi gathers = 8 GiB gathered
+    const int deg = 64;
+    const char *only = argc > 1 ? argv[1] : "";
+    uint4 *regs, *out;
+    uint32_t *d_idx;
+    CK(hipMalloc(&regs, total * 64));
+    CK(hipMalloc(&out, rows * 64));
+    CK(hipMalloc(&d_idx, rows * deg * 4));
+    CK(hipMemset(regs, 1, total * 64));
+    std::vector<uint32_t> idx(rows * deg);
+    hipEvent_t a, b;
+    CK(hipEventCreate(&a));
+    CK(hipEventCreate(&b));
+    struct Case { const char *name; uint64_t region; int perm; };
+    Case cases[] = {{"L2_4MiB", 1ull << 16, 0},   {"L2x8_32MiB", 1ull << 19, 0}, {"MALL_128MiB", 1ull << 21, 0},
+                    {"MALL_256MiB", 1ull << 22, 0}, {"HBM_512MiB", 1ull << 23, 0}, {"HBM_8GiB", 1ull << 27, 0},
+                    {"perm_8GiB_once", 1ull << 27, 1}, {"seq_8GiB_once", 1ull << 27, 2}};
+    for (const Case &c : cases) {
+        if (only[0] && strcmp(only, c.name)) continue;
+        uint64_t s = 42;
+        if (c.perm == 1) {
+            // exactly-once: a random permutation of all 2^27 blocks (multiplicative + xor shuffle)
+            for (uint64_t i = 0; i < rows * deg; i++) idx[i] = (uint32_t)(((i * 0x9E3779B1ull) ^ 0x5A5A5A5ull) & (total - 1));
+        } else if (c.perm == 2) {
+            for (uint64_t i = 0; i < rows * deg; i++) idx[i] = (uint32_t)i;
+        } else {
+            for (uint64_t i = 0; i < rows * deg; i++) idx[i] = (uint32_t)(sm(s) & (c.region - 1));
+        }
+        CK(hipMemcpy(d_idx, idx.data(), rows * deg * 4, hipMemcpyHostToDevice));
+        for (int unroll = 2; unroll <= 4; unroll += 2) {
+            float best = 1e9f;
+            for (int it = 0; it < 3; it++) {
+                CK(hipEventRecord(a));
+                if (unroll == 2) hipLaunchKernelGGL(gather_kernel<2>, dim3(2048), dim3(256), 0, 0, d_idx, regs, out, rows, deg);
+                else hipLaunchKernelGGL(gather_kernel<4>, dim3(2048), dim3(256), 0, 0, d_idx, regs, out, rows, deg);
+                CK(hipEventRecord(b));
+                CK(hipEventSynchronize(b));
+                float ms;
+                CK(hipEventElapsedTime(&ms, a, b));
+                if (ms < best) best = ms;
+            }
+            double gathered = (double)rows * deg * 64, index = (double)rows * deg * 4, wr = (double)rows * 64;
+            printf("%-16s unroll %d: %8.3f ms  gathered %7.1f GB/s  (+idx+out %7.1f GB/s)  %.2f Ggather/s\n", c.name, unroll,
+                   best, gathered / best / 1e6, (gathered + index + wr) / best / 1e6, rows * deg / best / 1e6);
+        }
+    }
+    if (!only[0] || !strcmp(only, "stream")) {
+        float best = 1e9f;
+        for (int it = 0; it < 3; it++) {
+            CK(hipEventRecord(a));
+            hipLaunchKernelGGL(stream_kernel, dim3(4096), dim3(256), 0, 0, regs, regs + total * 2, total * 2);
+            CK(hipEventRecord(b));
+            CK(hipEventSynchronize(b));
+            float ms;
+            CK(hipEventElapsedTime(&ms, a, b));
+            if (ms < best) best = ms;
+        }
+        printf("stream copy 4 GiB -> 4 GiB: %.3f ms  %.1f GB/s (read+write)\n", best, 2.0 * total * 32 / best / 1e6);
+    }
+    return 0;
+}
