@@ -14,8 +14,9 @@ torch.distributed.run, one rank per GPU).  Prints ONE JSON line on rank 0.
               it says little about HBM), C4 = configs[3].
   N > 1     = the same graph edge-partitioned over the ranks (strong scaling), one
               ncclAllReduce(max, u8) of the counters per pass.
-  roofline  = dominant kernel (dense pull pass): algorithmic bytes 68*m_eff + 192.25*n per
-              launch / its mean duration (HIP events on the library's stream) vs 8 TB/s.
+  roofline  = dominant kernel (dense pull over the hub chunks): algorithmic bytes per launch / its
+              mean duration (HIP events on the library's stream) vs 8 TB/s; the whole dense pass
+              (68*m_eff + 192.25*n bytes) is reported next to it.
   cpu_baseline = the CPU oracle's dense OpenMP port of the reference arithmetic, timed on
               this box's host cores on the same graph for a bounded number of passes.
 """
@@ -112,7 +113,7 @@ def main():
         one_step()
     barrier()
     t0 = time.perf_counter()
-    dense_ms, dense_launches, loop_ms, gpu_ms, coll_ms, d2h_ms = 0.0, 0, 0.0, 0.0, 0.0, 0.0
+    hub_ms, main_ms, dense_passes, loop_ms, gpu_ms, coll_ms, d2h_ms = 0.0, 0.0, 0, 0.0, 0.0, 0.0, 0.0
     passes = 0
     last_pass_stats = []
     for _ in range(a.steps):
@@ -124,9 +125,10 @@ def main():
         d2h_ms += st["ms_d2h"]
         last_pass_stats = ctx.pass_stats()
         for ps in last_pass_stats:
-            if ps["mode"] == 0:
-                dense_ms += ps["ms_main"]
-                dense_launches += 1
+            if ps["mode"] == 0:  # dense pass: hub-level launches (ev0..ev1) + the real-row launch (ev1..ev2)
+                hub_ms += ps["ms_gpu"] - ps["ms_main"] - ps["ms_collective"]
+                main_ms += ps["ms_main"]
+                dense_passes += 1
     barrier()
     dt = time.perf_counter() - t0
     if td is not None:
@@ -139,20 +141,28 @@ def main():
     if rank == 0:
         steps = max(a.steps, 1)
         teps = m_eff * passes * steps / dt
-        # dominant kernel: the dense pull pass (pass_kernel<REAL, !FRONTIER, FUSED>), one launch per dense pass.
-        # Algorithmic bytes per launch (SURVEY.md §8(d), A = m_eff, V = n): 68 B per edge (64 B source counter +
-        # 4 B index) + per node 64 B read + 64 B write + 32 B Kahan + 16 B size + 8 B row pointer + 2 bitmaps.
-        m_local = len(src)
-        alg_bytes = 68.0 * m_local + 192.25 * n
+        # Dominant kernel (rocprofv3 --stats, profiles/): the dense pull over the hub chunks,
+        # pass_kernel<REAL=false, FRONTIER=false, ...>, launched once per virtual level per dense pass.
+        # Algorithmic bytes of one dense pass over the virtual rows: per gathered source 64 B counter + 4 B
+        # index; per virtual row 64 B partial read + 64 B partial write + 8 B row pointer.  Per launch =
+        # that / levels (the same average rocprofv3 reports for the kernel symbol).
+        levels = max(int(stats["levels"]), 1)
+        v_edges, v_rows = int(stats["virtual_edges"]), int(stats["virtual_rows"])
         roof = None
-        if dense_launches:
-            avg_ms = dense_ms / dense_launches
+        if dense_passes and v_rows:
+            alg_bytes = (68.0 * v_edges + 136.0 * v_rows) / levels
+            avg_ms = hub_ms / dense_passes / levels
             achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
+            traffic = _pmc_traffic(a.config)
             roof = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": _pmc_traffic(a.config),
-                    "kernel": "pass_kernel<real,dense,%s>" % ("fused" if world == 1 else "unfused"),
+                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                    "kernel": "hbk::pass_kernel<false,false,false,false,2> (dense pull over hub chunks)",
                     "alg_bytes_per_launch": alg_bytes, "avg_launch_ms": round(avg_ms, 4),
-                    "launches": dense_launches}
+                    "launches": dense_passes * levels,
+                    "whole_dense_pass": {"alg_bytes": 68.0 * m_eff + 192.25 * n,
+                                         "avg_ms": round((hub_ms + main_ms) / dense_passes, 4),
+                                         "achieved_GBs": round((68.0 * m_eff + 192.25 * n) /
+                                                               ((hub_ms + main_ms) / dense_passes * 1e-3) / 1e9, 1)}}
         cpu = None
         if world == 1 and a.cpu_seconds > 0:
             cpu = cpu_baseline(g, a.cpu_seconds, passes, ids, vals, a.verify)
@@ -194,12 +204,16 @@ def main():
 def _pmc_traffic(config):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC summary
     (profiles/pmc_<config>.json, produced by tools/pmc_summary.py), or None."""
-    p = os.path.join(ROOT, "profiles", "pmc_%s.json" % config)
+    p = os.path.join(ROOT, "profiles", "current_%s_pmc.json" % config)
     try:
         with open(p) as f:
-            return json.load(f).get("hbm_bytes_per_launch")
+            d = json.load(f)
+        for k, v in d.items():
+            if "pass_kernel<false, false" in k:
+                return v.get("hbm_bytes_per_dispatch")
     except Exception:
-        return None
+        pass
+    return None
 
 
 def cpu_baseline(g, seconds, gpu_passes, gpu_ids, gpu_vals, verify):

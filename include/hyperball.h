@@ -107,6 +107,8 @@ typedef struct hb_stats {
     uint64_t work_rows;     /* real + virtual (hub-chunk) rows                              */
     uint64_t virtual_rows;
     uint64_t device_bytes;  /* device memory held by the context                            */
+    uint64_t virtual_edges; /* entries of the virtual rows' source lists, all levels        */
+    uint64_t levels;        /* virtual levels = hub-kernel launches per pass                */
 } hb_stats;
 
 typedef struct hb_pass_stats {

@@ -63,6 +63,8 @@ class HbStats(ctypes.Structure):
         ("work_rows", ctypes.c_uint64),
         ("virtual_rows", ctypes.c_uint64),
         ("device_bytes", ctypes.c_uint64),
+        ("virtual_edges", ctypes.c_uint64),
+        ("levels", ctypes.c_uint64),
     ]
 
     def as_dict(self):

@@ -200,6 +200,8 @@ int plan_and_upload(hb_ctx *c)
     const Plan &p = c->plan;
     c->stats.work_rows = p.n_pad + p.nv;
     c->stats.virtual_rows = p.nv;
+    c->stats.virtual_edges = p.row_ptr.empty() ? 0 : p.row_ptr[p.n_pad + p.nv] - p.row_ptr[p.n_pad];
+    c->stats.levels = p.level_begin.size() > 1 ? p.level_begin.size() - 1 : 0;
 
     // ---- device memory
     t0 = now_ms();

@@ -24,7 +24,17 @@ template <int J> __device__ __forceinline__ uint32_t qb(uint32_t v)
     return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, J * 0x55, 0xF, 0xF, true);
 }
 
-template <int UNROLL>
+template <int MODE> __device__ __forceinline__ uint4 ld(const uint4 *p)
+{
+    if (MODE == 1) {
+        typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+        v4u v = __builtin_nontemporal_load((const v4u *)p);
+        return make_uint4(v.x, v.y, v.z, v.w);
+    }
+    return *p;
+}
+
+template <int UNROLL, int MODE>
 __global__ __launch_bounds__(256) void gather_kernel(const uint32_t *idx, const uint4 *regs, uint4 *out, uint64_t rows, int deg)
 {
     const int lane = threadIdx.x & 63, q = lane & 3;
@@ -41,10 +51,18 @@ __global__ __launch_bounds__(256) void gather_kernel(const uint32_t *idx, const 
             uint4 r[UNROLL][4];
 #pragma unroll
             for (int u = 0; u < UNROLL; u++) {
-                r[u][0] = regs[(uint64_t)qb<0>(id[u]) * 4 + q];
-                r[u][1] = regs[(uint64_t)qb<1>(id[u]) * 4 + q];
-                r[u][2] = regs[(uint64_t)qb<2>(id[u]) * 4 + q];
-                r[u][3] = regs[(uint64_t)qb<3>(id[u]) * 4 + q];
+                if (MODE == 2) { // two adjacent counters (one 128-B line) per index: idx pairs (2k, 2k+1)
+                    const uint32_t a0 = qb<0>(id[u]) & ~1u, a1 = qb<2>(id[u]) & ~1u;
+                    r[u][0] = regs[(uint64_t)a0 * 4 + q];
+                    r[u][1] = regs[(uint64_t)a0 * 4 + 4 + q];
+                    r[u][2] = regs[(uint64_t)a1 * 4 + q];
+                    r[u][3] = regs[(uint64_t)a1 * 4 + 4 + q];
+                } else {
+                    r[u][0] = ld<MODE>(regs + (uint64_t)qb<0>(id[u]) * 4 + q);
+                    r[u][1] = ld<MODE>(regs + (uint64_t)qb<1>(id[u]) * 4 + q);
+                    r[u][2] = ld<MODE>(regs + (uint64_t)qb<2>(id[u]) * 4 + q);
+                    r[u][3] = ld<MODE>(regs + (uint64_t)qb<3>(id[u]) * 4 + q);
+                }
             }
 #pragma unroll
             for (int u = 0; u < UNROLL; u++)
@@ -107,12 +125,18 @@ int main(int argc, char **argv)
             for (uint64_t i = 0; i < rows * deg; i++) idx[i] = (uint32_t)(sm(s) & (c.region - 1));
         }
         CK(hipMemcpy(d_idx, idx.data(), rows * deg * 4, hipMemcpyHostToDevice));
-        for (int unroll = 2; unroll <= 4; unroll += 2) {
+        for (int variant = 0; variant < 6; variant++) {
+            const int unroll = variant;
             float best = 1e9f;
             for (int it = 0; it < 3; it++) {
                 CK(hipEventRecord(a));
-                if (unroll == 2) hipLaunchKernelGGL(gather_kernel<2>, dim3(2048), dim3(256), 0, 0, d_idx, regs, out, rows, deg);
-                else hipLaunchKernelGGL(gather_kernel<4>, dim3(2048), dim3(256), 0, 0, d_idx, regs, out, rows, deg);
+                dim3 g(2048), b2(256);
+                if (variant == 0) hipLaunchKernelGGL((gather_kernel<2, 0>), g, b2, 0, 0, d_idx, regs, out, rows, deg);
+                else if (variant == 1) hipLaunchKernelGGL((gather_kernel<4, 0>), g, b2, 0, 0, d_idx, regs, out, rows, deg);
+                else if (variant == 2) hipLaunchKernelGGL((gather_kernel<8, 0>), g, b2, 0, 0, d_idx, regs, out, rows, deg);
+                else if (variant == 3) hipLaunchKernelGGL((gather_kernel<4, 1>), g, b2, 0, 0, d_idx, regs, out, rows, deg);
+                else if (variant == 4) hipLaunchKernelGGL((gather_kernel<4, 2>), g, b2, 0, 0, d_idx, regs, out, rows, deg);
+                else hipLaunchKernelGGL((gather_kernel<4, 0>), dim3(4096), b2, 0, 0, d_idx, regs, out, rows, deg);
                 CK(hipEventRecord(b));
                 CK(hipEventSynchronize(b));
                 float ms;
@@ -120,7 +144,8 @@ int main(int argc, char **argv)
                 if (ms < best) best = ms;
             }
             double gathered = (double)rows * deg * 64, index = (double)rows * deg * 4, wr = (double)rows * 64;
-            printf("%-16s unroll %d: %8.3f ms  gathered %7.1f GB/s  (+idx+out %7.1f GB/s)  %.2f Ggather/s\n", c.name, unroll,
+            static const char *vn[] = {"u2", "u4", "u8", "u4-nt", "u4-pair128", "u4-grid4096"};
+            printf("%-16s %-12s (%d): %8.3f ms  gathered %7.1f GB/s  (+idx+out %7.1f GB/s)  %.2f Ggather/s\n", c.name, vn[variant], unroll,
                    best, gathered / best / 1e6, (gathered + index + wr) / best / 1e6, rows * deg / best / 1e6);
         }
     }

@@ -17,7 +17,7 @@ for C in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum" "TCC_EA0_RDREQ_sum TCC
     name=$(echo $C | tr ' ' '+')
     timeout 900 rocprofv3 --pmc $C -d "$OUT/pmc_$name" -o pmc -- $BENCH > "$OUT/pmc_$name.log" 2>&1
 done
-# keep what is small enough to travel back: stats + counter CSVs (kernel trace can be large)
-find "$OUT" -name "*.csv" -size +20M -delete
-python $ROOT/tools/pmc_summary.py "$OUT" "$CFG" > "$OUT/summary.json" 2> "$OUT/summary.err"
-ls -la "$OUT" "$OUT"/*/ 2>/dev/null | head -50
+# rocprofv3 writes rocpd .db files; reduce them to the small text summaries kept under profiles/
+python $ROOT/tools/export_profile.py "$OUT" "$ROOT/gpurun_out/${TAG}_${CFG}" 2>&1 | tail -2
+find "$OUT" -name "*.db" -size +8M -delete
+cat "$ROOT/gpurun_out/${TAG}_${CFG}_kernel_stats.csv" | cut -c1-200
