@@ -72,6 +72,7 @@ typedef struct hb_edge {
 #define HB_FLAG_NO_XCD_MAP    0x20u /* plain blockIdx -> work mapping                              */
 #define HB_FLAG_NO_RCCL       0x40u /* world_size > 1 bookkeeping without a communicator: the caller
                                        performs the exchange (hb_debug_merge_pending; tests)       */
+#define HB_FLAG_NO_SPARSE     0x100u /* never use the worklist-driven tail passes (debug; same results) */
 #define HB_FLAG_RCCL_SELF     0x80u /* world_size == 1 but still create a 1-rank communicator and run
                                        the collectives (exercises the RCCL call path on one GPU)   */
 
@@ -116,7 +117,7 @@ typedef struct hb_pass_stats {
     uint64_t changed;       /* nodes whose counter changed in pass t                        */
     uint64_t active_edges;  /* A_t (only with HB_FLAG_PASS_STATS, else 0)                   */
     uint64_t touched;       /* V_t (only with HB_FLAG_PASS_STATS, else 0)                   */
-    uint32_t mode;          /* 0 = dense (no frontier test), 1 = frontier                   */
+    uint32_t mode;          /* 0 = dense (no frontier test), 1 = frontier bitmap, 2 = sparse worklists */
     float    ms_gpu;        /* GPU time of the pass (all its launches + collective)         */
     float    ms_main;       /* GPU time of the dominant launch (real rows)                  */
     float    ms_collective;

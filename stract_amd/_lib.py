@@ -24,6 +24,7 @@ HB_FLAG_NO_LDS_HOT = 0x10
 HB_FLAG_NO_XCD_MAP = 0x20
 HB_FLAG_NO_RCCL = 0x40
 HB_FLAG_RCCL_SELF = 0x80
+HB_FLAG_NO_SPARSE = 0x100
 
 # numpy views of the plain-data structs
 U128 = np.dtype([("lo", "<u8"), ("hi", "<u8")])

@@ -59,6 +59,13 @@ struct hb_ctx {
     unsigned long long *d_counters = nullptr; // max_passes * 4
     double *d_raw = nullptr, *d_bias = nullptr;
     uint8_t *d_lc = nullptr;
+    // sparse (data-driven) tail passes: transposed work-row graph + worklists
+    uint64_t *d_out_ptr = nullptr;
+    uint32_t *d_out_rows = nullptr;
+    uint32_t *d_touch = nullptr;
+    uint32_t *d_list_real = nullptr, *d_list_virt = nullptr, *d_seeds = nullptr;
+    unsigned int *d_sparse_counts = nullptr;
+    bool sparse_ok = false;
     unsigned long long *h_counters = nullptr; // pinned, 4 words
     uint64_t bits_words = 0;
     uint64_t ksum_len = 0; // entries allocated for ksum (world * slice in RCCL mode)
@@ -139,6 +146,12 @@ void free_graph_buffers(hb_ctx *c)
     c->d_raw = c->d_bias = nullptr;
     c->d_lc = nullptr;
     c->d_out = nullptr;
+    c->d_out_ptr = nullptr;
+    c->d_out_rows = nullptr;
+    c->d_touch = nullptr;
+    c->d_list_real = c->d_list_virt = c->d_seeds = nullptr;
+    c->d_sparse_counts = nullptr;
+    c->sparse_ok = false;
     if (c->h_out) (void)hipHostFree(c->h_out);
     c->h_out = nullptr;
     c->h_out_len = 0;
@@ -160,6 +173,52 @@ PlanTune plan_tune(uint32_t chunk, const uint32_t *tune)
 
 bool edge_partitioned(const hb_ctx *c) { return c->opt.world_size > 1; }
 bool unfused(const hb_ctx *c) { return edge_partitioned(c) || c->comm || (c->opt.flags & HB_FLAG_UNFUSED); }
+
+// Transposed work-row graph (who reads each node / virtual row) and worklists for the sparse
+// tail passes; built on the device from the uploaded plan, prefix sum on the host.
+int build_sparse_support(hb_ctx *c)
+{
+    const Plan &p = c->plan;
+    c->sparse_ok = false;
+    if (unfused(c) || (c->opt.flags & HB_FLAG_NO_SPARSE) || p.n == 0) return HB_OK;
+    if (p.level_begin.size() > (size_t)hbk::kMaxSparseLevels + 1) return HB_OK; // very deep trees: bitmap modes only
+    const uint64_t rows_total = p.n_pad + p.nv;
+    const uint64_t entries = p.src.size();
+    int rc;
+    uint32_t *d_count = nullptr;
+    if ((rc = dev_alloc(c, &c->d_out_ptr, rows_total + 1))) return rc;
+    if ((rc = dev_alloc(c, &c->d_out_rows, entries))) return rc;
+    if ((rc = dev_alloc(c, &c->d_touch, c->bits_words))) return rc;
+    if ((rc = dev_alloc(c, &c->d_list_real, p.n_pad))) return rc;
+    if ((rc = dev_alloc(c, &c->d_list_virt, p.nv))) return rc;
+    if ((rc = dev_alloc(c, &c->d_seeds, p.n_pad))) return rc;
+    if ((rc = dev_alloc(c, &c->d_sparse_counts, 64))) return rc;
+    if ((rc = dev_alloc(c, &d_count, rows_total))) return rc; // stays allocated (small next to out_rows)
+    HB_HIP(hipMemsetAsync(d_count, 0, rows_total * sizeof(uint32_t), c->stream));
+    const unsigned blocks = (unsigned)std::min<uint64_t>((rows_total * 4 + 255) / 256, (uint64_t)c->num_cu * 16);
+    hipLaunchKernelGGL(hbk::transpose_count_kernel, dim3(blocks), dim3(256), 0, c->stream, (const uint64_t *)c->d_row_ptr,
+                       (const uint32_t *)c->d_src, rows_total, d_count);
+    HB_HIP(hipGetLastError());
+    std::vector<uint32_t> cnt(rows_total);
+    HB_HIP(hipMemcpyAsync(cnt.data(), d_count, rows_total * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    HB_HIP(hipStreamSynchronize(c->stream));
+    std::vector<uint64_t> optr(rows_total + 1);
+    uint64_t acc = 0;
+    for (uint64_t i = 0; i < rows_total; i++) {
+        optr[i] = acc;
+        acc += cnt[i];
+    }
+    optr[rows_total] = acc;
+    if (acc != entries) return fail(c, HB_ERR_HIP, "transposed plan graph: entry count mismatch");
+    HB_HIP(hipMemcpyAsync(c->d_out_ptr, optr.data(), (rows_total + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
+    HB_HIP(hipMemsetAsync(d_count, 0, rows_total * sizeof(uint32_t), c->stream));
+    hipLaunchKernelGGL(hbk::transpose_fill_kernel, dim3(blocks), dim3(256), 0, c->stream, (const uint64_t *)c->d_row_ptr,
+                       (const uint32_t *)c->d_src, rows_total, (const uint64_t *)c->d_out_ptr, d_count, c->d_out_rows);
+    HB_HIP(hipGetLastError());
+    HB_HIP(hipStreamSynchronize(c->stream));
+    c->sparse_ok = true;
+    return HB_OK;
+}
 
 // ---- plan + upload (common tail of every load entry point) -------------------------------
 int plan_and_upload(hb_ctx *c)
@@ -249,6 +308,7 @@ int plan_and_upload(hb_ctx *c)
     HB_HIP(hipMemcpyAsync(c->d_idlow, idlow.data(), p.n_pad * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
     if (n) HB_HIP(hipMemcpyAsync(c->d_dev_of, p.dev_of.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
     HB_HIP(hipStreamSynchronize(c->stream));
+    if ((rc = build_sparse_support(c))) return rc;
     // the plan's big host arrays are no longer needed
     std::vector<uint64_t>().swap(c->plan.row_ptr);
     std::vector<uint32_t>().swap(c->plan.src);
@@ -337,24 +397,59 @@ int step_local(hb_ctx *c)
     if (c->pending_local) return fail(c, HB_ERR_INVALID, "hb_step_local called twice");
     if (c->t >= c->max_passes) return fail(c, HB_ERR_LIMIT, "max_passes exceeded");
     const Plan &p = c->plan;
-    // mode: dense while most nodes still change (the frontier test would only cost), frontier after
+    // mode: dense while most nodes still change (the frontier test would only cost), frontier
+    // (bitmap) after, sparse (worklists over the transposed graph) for the convergence tail
     uint32_t thr = c->opt.tune[2] ? c->opt.tune[2] : 25; // percent of nodes changed in the previous pass
     bool frontier = !(c->opt.flags & HB_FLAG_NO_FRONTIER) && c->t > 0 &&
                     (c->last_changed * 100ull < (uint64_t)thr * p.n);
-    c->cur_mode = frontier ? 1 : 0;
+    const uint64_t sparse_div = c->opt.tune[6] ? c->opt.tune[6] : 64; // sparse when changed * div < n
+    const bool sparse = frontier && c->sparse_ok && (c->last_changed * sparse_div < p.n || c->opt.tune[6] == 1);
+    c->cur_mode = sparse ? 2 : (frontier ? 1 : 0);
     const bool fused = !unfused(c);
     hbk::PassParams pp = make_params(c);
     HB_HIP(hipEventRecord(c->ev[0], c->stream));
-    for (size_t l = 0; l + 1 < p.level_begin.size(); l++) {
-        pp.row_lo = p.level_begin[l];
-        pp.row_hi = p.level_begin[l + 1];
-        launch_pass(c, pp, false, frontier, false);
+    if (sparse) {
+        hbk::SparseParams sp{};
+        sp.p = pp;
+        sp.out_ptr = c->d_out_ptr;
+        sp.out_rows = c->d_out_rows;
+        sp.touch = c->d_touch;
+        sp.list_real = c->d_list_real;
+        sp.list_virt = c->d_list_virt;
+        sp.seeds = c->d_seeds;
+        sp.counts = c->d_sparse_counts;
+        sp.levels = (int)p.level_begin.size() - 1;
+        if (sp.levels < 0) sp.levels = 0;
+        for (size_t l = 0; l < p.level_begin.size(); l++) sp.level_begin[l] = p.level_begin[l];
+        const uint64_t real_words = p.n_pad / 32;
+        HB_HIP(hipMemsetAsync(c->d_sparse_counts, 0, 64 * sizeof(unsigned int), c->stream));
+        HB_HIP(hipMemsetAsync(c->d_touch, 0, c->bits_words * 4, c->stream));
+        HB_HIP(hipMemsetAsync(c->d_bits[c->cur ^ 1], 0, c->bits_words * 4, c->stream));           // this pass' changed bits
+        if (c->bits_words > real_words)                                                             // this pass' virtual bits
+            HB_HIP(hipMemsetAsync(c->d_bits[c->cur] + real_words, 0, (c->bits_words - real_words) * 4, c->stream));
+        const unsigned sblocks = (unsigned)std::min<uint64_t>(std::max<uint64_t>(real_words / 256, 1), (uint64_t)c->num_cu * 4);
+        hipLaunchKernelGGL(hbk::sparse_collect_kernel, dim3(sblocks), dim3(256), 0, c->stream, sp);
+        const unsigned wblocks = (unsigned)c->num_cu * 4;
+        hipLaunchKernelGGL(hbk::sparse_expand_kernel, dim3(wblocks), dim3(256), 0, c->stream, sp);
+        for (int l = 0; l < sp.levels; l++) {
+            sp.level = l;
+            hipLaunchKernelGGL(hbk::sparse_rows_kernel<false>, dim3(wblocks), dim3(256), 0, c->stream, sp);
+        }
+        HB_HIP(hipEventRecord(c->ev[1], c->stream));
+        hipLaunchKernelGGL(hbk::sparse_rows_kernel<true>, dim3(wblocks), dim3(256), 0, c->stream, sp);
+        HB_HIP(hipEventRecord(c->ev[2], c->stream));
+    } else {
+        for (size_t l = 0; l + 1 < p.level_begin.size(); l++) {
+            pp.row_lo = p.level_begin[l];
+            pp.row_hi = p.level_begin[l + 1];
+            launch_pass(c, pp, false, frontier, false);
+        }
+        HB_HIP(hipEventRecord(c->ev[1], c->stream));
+        pp.row_lo = 0;
+        pp.row_hi = p.n_pad;
+        launch_pass(c, pp, true, frontier, fused);
+        HB_HIP(hipEventRecord(c->ev[2], c->stream));
     }
-    HB_HIP(hipEventRecord(c->ev[1], c->stream));
-    pp.row_lo = 0;
-    pp.row_hi = p.n_pad;
-    launch_pass(c, pp, true, frontier, fused);
-    HB_HIP(hipEventRecord(c->ev[2], c->stream));
     HB_HIP(hipGetLastError());
     c->pending_local = true;
     return HB_OK;

@@ -416,6 +416,199 @@ __global__ __launch_bounds__(256) void pass_kernel(const PassParams p)
     }
 }
 
+// ---- sparse (data-driven) pass: the convergence tail --------------------------------------
+// When few nodes changed in the previous pass, scanning every row (even with the frontier
+// test) costs far more than the work.  The reference switches to update_changed_counters
+// (harmonic.rs:75-114: only the out-edges of the exactly-tracked changed set) in the same
+// situation.  Here: the transposed work-row graph (out_ptr/out_rows: for every node or
+// virtual row, the work rows that read it) turns the changed set into per-level worklists;
+// only listed rows are processed, with exactly the frontier-mode row semantics of
+// pass_kernel, so registers / Kahan state / changed bits are bit-identical.
+constexpr int kMaxSparseLevels = 12;
+
+struct SparseParams {
+    PassParams p;
+    const uint64_t *out_ptr;   // rows_total + 1
+    const uint32_t *out_rows;  // work rows reading each source
+    uint32_t *touch;           // 1 bit per work row: already on a worklist
+    uint32_t *list_real;       // worklist of node rows (capacity n_pad)
+    uint32_t *list_virt;       // worklists of virtual rows, level l at offset level_begin[l] - n_pad
+    uint32_t *seeds;           // nodes changed in the previous pass (capacity n_pad)
+    unsigned int *counts;      // [0] seeds, [1] real list, [2 + l] level-l list
+    uint64_t level_begin[kMaxSparseLevels + 1];
+    int levels;
+    int level;                 // level processed by this launch (sparse_rows_kernel<false>)
+};
+
+__device__ __forceinline__ void sparse_push(const SparseParams &sp, uint32_t r)
+{
+    const uint32_t bit = 1u << (r & 31u);
+    const uint32_t old = atomicOr(&sp.touch[r >> 5], bit);
+    if (old & bit) return;
+    if ((uint64_t)r < sp.p.n_pad) {
+        sp.list_real[atomicAdd(&sp.counts[1], 1u)] = r;
+    } else {
+        int l = 0;
+        while (l + 1 < sp.levels && (uint64_t)r >= sp.level_begin[l + 1]) l++;
+        sp.list_virt[(sp.level_begin[l] - sp.p.n_pad) + atomicAdd(&sp.counts[2 + l], 1u)] = r;
+    }
+}
+
+// one thread per 32 node rows: changed-in-the-previous-pass nodes become seeds (their readers are
+// expanded by sparse_expand_kernel) and, like Kahan-dirty nodes, are visited themselves.
+__global__ __launch_bounds__(256) void sparse_collect_kernel(const SparseParams sp)
+{
+    const uint64_t words = sp.p.n_pad >> 5;
+    for (uint64_t w = (uint64_t)blockIdx.x * 256 + threadIdx.x; w < words; w += (uint64_t)gridDim.x * 256) {
+        uint32_t ch = sp.p.bits_rd[w];
+        uint32_t both = ch | sp.p.kdirty[w];
+        while (both) {
+            const int b = __ffs((int)both) - 1;
+            both &= both - 1;
+            const uint32_t row = (uint32_t)(w << 5) + (uint32_t)b;
+            if ((ch >> b) & 1u) sp.seeds[atomicAdd(&sp.counts[0], 1u)] = row;
+            sparse_push(sp, row);
+        }
+    }
+}
+
+// one wave per seed: every work row that reads it goes on its level's worklist
+__global__ __launch_bounds__(256) void sparse_expand_kernel(const SparseParams sp)
+{
+    const int lane = threadIdx.x & 63;
+    const uint32_t nseeds = sp.counts[0];
+    const uint32_t wave = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
+    for (uint32_t i = wave; i < nseeds; i += nwaves) {
+        const uint32_t u = sp.seeds[i];
+        const uint64_t b = sp.out_ptr[u], e = sp.out_ptr[u + 1];
+        for (uint64_t k = b + lane; k < e; k += 64) sparse_push(sp, sp.out_rows[k]);
+    }
+}
+
+// the listed rows, one quad each; REAL: node rows (self = rd[row], fused estimator + Kahan),
+// else virtual rows of level sp.level (self = part[row - n_pad]; changed rows push their readers)
+template <bool REAL>
+__global__ __launch_bounds__(256) void sparse_rows_kernel(const SparseParams sp)
+{
+    __shared__ double s_raw[REAL ? kTableLen : 1];
+    __shared__ double s_bias[REAL ? kTableLen : 1];
+    __shared__ uint8_t s_lc[68];
+    const PassParams &p = sp.p;
+    if (REAL) {
+        for (int i = threadIdx.x; i < kTableLen; i += 256) {
+            s_raw[i] = p.raw[i];
+            s_bias[i] = p.bias[i];
+        }
+        if (threadIdx.x < 65) s_lc[threadIdx.x] = p.lc[threadIdx.x];
+        __syncthreads();
+    }
+    const int lane = threadIdx.x & 63;
+    const int g = lane >> 2, q = lane & 3, qshift = lane & ~3;
+    const uint32_t count = REAL ? sp.counts[1] : sp.counts[2 + sp.level];
+    const uint32_t *list = REAL ? sp.list_real : sp.list_virt + (sp.level_begin[sp.level] - p.n_pad);
+    const uint32_t nwaves = gridDim.x * 4;
+    unsigned long long cnt_changed = 0;
+    for (uint32_t base = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 16; base < count; base += nwaves * 16) {
+        const uint32_t li = base + (uint32_t)g;
+        const bool valid = li < count;
+        const uint64_t row = valid ? (uint64_t)list[li] : 0;
+        uint64_t beg = 0, end = 0;
+        if (valid) {
+            beg = p.row_ptr[row];
+            end = p.row_ptr[row + 1];
+        }
+        const uint4 *selfp = REAL ? (p.rd + row * 4 + q) : (p.part + (row - p.n_pad) * 4 + q);
+        Acc acc;
+        acc_zero(acc);
+        if (beg < end) {
+            const uint32_t first = p.src[beg];
+            const uint4 *srcbase = (first >= p.n_pad) ? (const uint4 *)(p.part - p.n_pad * 4) : p.rd;
+            for (uint64_t e = beg; e < end; e += 4) {
+                const uint64_t ee = e + q;
+                uint32_t idx = (ee < end) ? p.src[ee] : kNone;
+                if (idx != kNone && !((p.bits_rd[idx >> 5] >> (idx & 31u)) & 1u)) idx = kNone;
+                const uint32_t s0 = quad_bcast<0>(idx), s1 = quad_bcast<1>(idx);
+                const uint32_t s2 = quad_bcast<2>(idx), s3 = quad_bcast<3>(idx);
+                uint4 r0 = make_uint4(0, 0, 0, 0), r1 = r0, r2 = r0, r3 = r0;
+                if (s0 != kNone) r0 = srcbase[(uint64_t)s0 * 4 + q];
+                if (s1 != kNone) r1 = srcbase[(uint64_t)s1 * 4 + q];
+                if (s2 != kNone) r2 = srcbase[(uint64_t)s2 * 4 + q];
+                if (s3 != kNone) r3 = srcbase[(uint64_t)s3 * 4 + q];
+                acc_merge(acc, r0);
+                acc_merge(acc, r1);
+                acc_merge(acc, r2);
+                acc_merge(acc, r3);
+            }
+        }
+        uint4 selfv = make_uint4(0, 0, 0, 0);
+        if (valid) {
+            selfv = *selfp;
+            acc_merge(acc, selfv);
+        }
+        const uint4 accv = acc_value(acc);
+        const uint64_t bal = __ballot(valid && u4_ne(accv, selfv));
+        const bool changed = ((bal >> qshift) & 0xFull) != 0;
+        const uint32_t bit = 1u << (row & 31u);
+        if (REAL) {
+            const bool self_prev = valid && ((p.bits_rd[row >> 5] >> (row & 31u)) & 1u);
+            const bool kd = valid && ((p.kdirty[row >> 5] >> (row & 31u)) & 1u);
+            if (valid && (changed || self_prev)) p.wr[row * 4 + q] = accv; // lazy double buffer
+            if (changed && q == 0) atomicOr(&p.bits_wr[row >> 5], bit);
+            cnt_changed += __popc(pack16(bal));
+            if (valid && (changed || kd)) {
+                const uint64_t sz_old = p.size[row];
+                const uint64_t sz_new = changed ? hll_size_quad(accv, s_raw, s_bias, s_lc) : sz_old;
+                if (q == 0) {
+                    double ks = p.ksum[row], ke = p.kerr[row];
+                    kahan_update(ks, ke, sz_new, sz_old, p.t_plus_1);
+                    p.ksum[row] = ks;
+                    p.kerr[row] = ke;
+                    if (changed) p.size[row] = sz_new;
+                    const bool err_nz = (ke != 0.0);
+                    if (err_nz && !kd) atomicOr(&p.kdirty[row >> 5], bit);
+                    if (!err_nz && kd) atomicAnd(&p.kdirty[row >> 5], ~bit);
+                }
+            }
+        } else if (changed) {
+            p.part[(row - p.n_pad) * 4 + q] = accv;
+            if (q == 0) {
+                atomicOr((uint32_t *)&p.bits_rd[row >> 5], bit); // this pass' virtual changed bit
+                const uint64_t b = sp.out_ptr[row], e = sp.out_ptr[row + 1];
+                for (uint64_t k = b; k < e; k++) sparse_push(sp, sp.out_rows[k]);
+            }
+        }
+    }
+    if (REAL && lane == 0 && cnt_changed) atomicAdd(&p.counters[0], cnt_changed);
+}
+
+// ---- transposed work-row graph (built once per load) ------------------------------------------
+// count[s] = number of work rows reading s; then (after a host-side exclusive scan) fill.
+__global__ __launch_bounds__(256) void transpose_count_kernel(const uint64_t *row_ptr, const uint32_t *src, uint64_t rows,
+                                                              uint32_t *count)
+{
+    const uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    const uint64_t nq = (uint64_t)gridDim.x * 64; // quads in the grid
+    const int q = threadIdx.x & 3;
+    for (uint64_t row = t >> 2; row < rows; row += nq) {
+        const uint64_t b = row_ptr[row], e = row_ptr[row + 1];
+        for (uint64_t k = b + q; k < e; k += 4) atomicAdd(&count[src[k]], 1u);
+    }
+}
+__global__ __launch_bounds__(256) void transpose_fill_kernel(const uint64_t *row_ptr, const uint32_t *src, uint64_t rows,
+                                                             const uint64_t *out_ptr, uint32_t *cursor, uint32_t *out_rows)
+{
+    const uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    const uint64_t nq = (uint64_t)gridDim.x * 64;
+    const int q = threadIdx.x & 3;
+    for (uint64_t row = t >> 2; row < rows; row += nq) {
+        const uint64_t b = row_ptr[row], e = row_ptr[row + 1];
+        for (uint64_t k = b + q; k < e; k += 4) {
+            const uint32_t s = src[k];
+            out_rows[out_ptr[s] + atomicAdd(&cursor[s], 1u)] = (uint32_t)row;
+        }
+    }
+}
+
 // ---- unfused epilogue (edge-partition mode, after the all-reduce) ----------------------
 // changed detection over ALL rows (every rank needs the full next frontier), estimator and
 // Kahan only for the rows this rank owns.

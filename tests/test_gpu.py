@@ -134,6 +134,9 @@ VARIANTS = {
     "unfused_frontier_always": dict(flags=_lib.HB_FLAG_UNFUSED, tune=(0, 0, 101), chunk=8),
     "pass_stats": dict(flags=_lib.HB_FLAG_PASS_STATS),
     "few_blocks": dict(tune=(1,)),
+    "sparse_always_multilevel": dict(chunk=8, tune=(0, 0, 101, 0, 0, 0, 1)),
+    "sparse_always_banded": dict(chunk=16, tune=(0, 0, 101, 6, 4, 0, 1)),
+    "no_sparse": dict(flags=_lib.HB_FLAG_NO_SPARSE),
     "banded_chunks": dict(chunk=16, tune=(0, 0, 0, 6, 4)),
     "banded_frontier_small_direct": dict(chunk=32, tune=(0, 0, 101, 5, 8, 8)),
 }
@@ -199,8 +202,11 @@ def test_hub_rows_and_isolated_nodes(gpu_ctx_factory):
     tuples += [(1, 5000, 0), (9001, 9002, graphs.NOFOLLOW), (9003, 1, graphs.TAG)]
     e = EdgeListGraph.from_tuples(tuples)
     fids, fvals, fst = hbo.faithful_run(e.host_edges())
-    for kw in (dict(chunk=8), dict(), dict(chunk=8, flags=_lib.HB_FLAG_UNFUSED)):
+    for kw in (dict(chunk=8), dict(), dict(chunk=8, flags=_lib.HB_FLAG_UNFUSED), dict(chunk=8, tune=(0, 0, 101, 0, 0, 0, 1)),
+               dict(flags=_lib.HB_FLAG_NO_SPARSE)):
         hc = HarmonicCentrality.calculate(e, **kw)
+        if not kw.get("flags"):
+            assert any(ps["mode"] == 2 for ps in hc.pass_stats)  # the worklist-driven tail ran
         ids, vals = hc.arrays()
         assert hc.stats["passes"] == fst["passes"] and hc.stats["n"] == fst["n"]
         assert np.array_equal(ids, fids) and np.array_equal(vals.view(np.uint64), fvals.view(np.uint64)), kw
