@@ -63,9 +63,10 @@ struct hb_ctx {
     uint64_t *d_out_ptr = nullptr;
     uint32_t *d_out_rows = nullptr;
     uint32_t *d_touch = nullptr;
-    uint32_t *d_list_real = nullptr, *d_list_virt = nullptr, *d_seeds = nullptr;
+    uint32_t *d_list_real = nullptr, *d_list_virt = nullptr, *d_seeds = nullptr, *d_heavy = nullptr;
     unsigned int *d_sparse_counts = nullptr;
     bool sparse_ok = false;
+    uint64_t plan_entries = 0; // entries of all work rows' source lists
     unsigned long long *h_counters = nullptr; // pinned, 4 words
     uint64_t bits_words = 0;
     uint64_t ksum_len = 0; // entries allocated for ksum (world * slice in RCCL mode)
@@ -77,6 +78,7 @@ struct hb_ctx {
     bool has_changes = false;
     bool pending_local = false; // between hb_step_local and hb_step_finish
     uint64_t last_changed = 0;
+    uint64_t last_readers = ~0ull; // work rows reading the nodes that changed in the previous pass
     uint32_t max_passes = 4096;
     std::vector<hb_pass_stats> pstats;
     hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -149,7 +151,7 @@ void free_graph_buffers(hb_ctx *c)
     c->d_out_ptr = nullptr;
     c->d_out_rows = nullptr;
     c->d_touch = nullptr;
-    c->d_list_real = c->d_list_virt = c->d_seeds = nullptr;
+    c->d_list_real = c->d_list_virt = c->d_seeds = c->d_heavy = nullptr;
     c->d_sparse_counts = nullptr;
     c->sparse_ok = false;
     if (c->h_out) (void)hipHostFree(c->h_out);
@@ -184,6 +186,7 @@ int build_sparse_support(hb_ctx *c)
     if (p.level_begin.size() > (size_t)hbk::kMaxSparseLevels + 1) return HB_OK; // very deep trees: bitmap modes only
     const uint64_t rows_total = p.n_pad + p.nv;
     const uint64_t entries = p.src.size();
+    c->plan_entries = entries;
     int rc;
     uint32_t *d_count = nullptr;
     if ((rc = dev_alloc(c, &c->d_out_ptr, rows_total + 1))) return rc;
@@ -192,6 +195,7 @@ int build_sparse_support(hb_ctx *c)
     if ((rc = dev_alloc(c, &c->d_list_real, p.n_pad))) return rc;
     if ((rc = dev_alloc(c, &c->d_list_virt, p.nv))) return rc;
     if ((rc = dev_alloc(c, &c->d_seeds, p.n_pad))) return rc;
+    if ((rc = dev_alloc(c, &c->d_heavy, p.n_pad))) return rc;
     if ((rc = dev_alloc(c, &c->d_sparse_counts, 64))) return rc;
     if ((rc = dev_alloc(c, &d_count, rows_total))) return rc; // stays allocated (small next to out_rows)
     HB_HIP(hipMemsetAsync(d_count, 0, rows_total * sizeof(uint32_t), c->stream));
@@ -375,6 +379,7 @@ hbk::PassParams make_params(hb_ctx *c)
     pp.kerr = c->d_kerr;
     pp.size = c->d_size;
     pp.counters = c->d_counters + 4 * c->t;
+    pp.out_ptr = c->sparse_ok ? c->d_out_ptr : nullptr;
     pp.raw = c->d_raw;
     pp.bias = c->d_bias;
     pp.lc = c->d_lc;
@@ -402,8 +407,10 @@ int step_local(hb_ctx *c)
     uint32_t thr = c->opt.tune[2] ? c->opt.tune[2] : 25; // percent of nodes changed in the previous pass
     bool frontier = !(c->opt.flags & HB_FLAG_NO_FRONTIER) && c->t > 0 &&
                     (c->last_changed * 100ull < (uint64_t)thr * p.n);
-    const uint64_t sparse_div = c->opt.tune[6] ? c->opt.tune[6] : 64; // sparse when changed * div < n
-    const bool sparse = frontier && c->sparse_ok && (c->last_changed * sparse_div < p.n || c->opt.tune[6] == 1);
+    // sparse when (work rows reading a changed node) * div < all source-list entries
+    const uint64_t sparse_div = c->opt.tune[6] ? c->opt.tune[6] : 64;
+    const bool sparse = frontier && c->sparse_ok && c->last_readers != ~0ull &&
+                        (c->last_readers * sparse_div < c->plan_entries || c->opt.tune[6] == 1);
     c->cur_mode = sparse ? 2 : (frontier ? 1 : 0);
     const bool fused = !unfused(c);
     hbk::PassParams pp = make_params(c);
@@ -417,6 +424,7 @@ int step_local(hb_ctx *c)
         sp.list_real = c->d_list_real;
         sp.list_virt = c->d_list_virt;
         sp.seeds = c->d_seeds;
+        sp.heavy = c->d_heavy;
         sp.counts = c->d_sparse_counts;
         sp.levels = (int)p.level_begin.size() - 1;
         if (sp.levels < 0) sp.levels = 0;
@@ -431,6 +439,7 @@ int step_local(hb_ctx *c)
         hipLaunchKernelGGL(hbk::sparse_collect_kernel, dim3(sblocks), dim3(256), 0, c->stream, sp);
         const unsigned wblocks = (unsigned)c->num_cu * 4;
         hipLaunchKernelGGL(hbk::sparse_expand_kernel, dim3(wblocks), dim3(256), 0, c->stream, sp);
+        hipLaunchKernelGGL(hbk::sparse_expand_heavy_kernel, dim3(wblocks), dim3(256), 0, c->stream, sp);
         for (int l = 0; l < sp.levels; l++) {
             sp.level = l;
             hipLaunchKernelGGL(hbk::sparse_rows_kernel<false>, dim3(wblocks), dim3(256), 0, c->stream, sp);
@@ -501,6 +510,7 @@ int step_finish(hb_ctx *c, int *has_changes)
     c->pstats.push_back(ps);
     // counters.step(); changed_nodes = new_changed_nodes; t += 1 (harmonic.rs:273-275)
     c->last_changed = ps.changed;
+    c->last_readers = c->sparse_ok ? c->h_counters[3] : ~0ull;
     c->has_changes = ps.changed != 0;
     c->cur ^= 1;
     c->t += 1;
@@ -720,6 +730,7 @@ int hb_begin(hb_ctx *c)
     c->cur = 0;
     c->has_changes = true; // harmonic.rs:232
     c->last_changed = p.n;
+    c->last_readers = ~0ull;
     c->pending_local = false;
     c->pstats.clear();
     c->begun = true;

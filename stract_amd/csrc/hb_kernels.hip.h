@@ -39,7 +39,8 @@ struct PassParams {
     double *ksum;
     double *kerr;
     uint64_t *size;           // cached size() of rd[row]
-    unsigned long long *counters; // [0] changed rows, [1] active edges, [2] rows processed
+    unsigned long long *counters; // [0] changed rows, [1] active edges, [2] rows processed, [3] readers of changed rows
+    const uint64_t *out_ptr;  // transposed work-row graph offsets (NULL when not built)
     const double *raw;        // HLL64_RAW_ESTIMATE (global copy, staged to LDS)
     const double *bias;       // HLL64_BIAS
     const uint8_t *lc;        // linear-counting table, 65 entries (index = zero registers)
@@ -261,7 +262,7 @@ __global__ __launch_bounds__(256) void pass_kernel(const PassParams p)
     const int g = lane >> 2, q = lane & 3;
     const int qshift = lane & ~3;
     const uint64_t ntiles = (p.row_hi - p.row_lo + 63) >> 6;
-    unsigned long long cnt_changed = 0, cnt_active = 0, cnt_rows = 0;
+    unsigned long long cnt_changed = 0, cnt_active = 0, cnt_rows = 0, cnt_readers = 0;
 
     for (uint64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const uint64_t row16 = p.row_lo + (tile << 6) + ((uint64_t)wave << 4); // first row of this wave
@@ -378,7 +379,10 @@ __global__ __launch_bounds__(256) void pass_kernel(const PassParams p)
             uint16_t *dst = REAL ? (uint16_t *)p.bits_wr : (uint16_t *)p.bits_rd;
             if (lane == 0 && row16 < p.row_hi) dst[row16 >> 4] = (uint16_t)ch16;
         }
-        if (REAL && FUSED) cnt_changed += __popc(ch16);
+        if (REAL && FUSED) {
+            cnt_changed += __popc(ch16);
+            if (changed && q == 0 && p.out_ptr) cnt_readers += p.out_ptr[row + 1] - p.out_ptr[row];
+        }
         if (STATS) cnt_rows += (need && q == 0);
         if (REAL && FUSED) {
             bool err_nz = false;
@@ -402,6 +406,11 @@ __global__ __launch_bounds__(256) void pass_kernel(const PassParams p)
     if (REAL) {
         // cnt_changed is identical in all lanes of the wave (derived from a ballot)
         if (lane == 0 && cnt_changed) atomicAdd(&p.counters[0], cnt_changed);
+        if (FUSED && p.out_ptr) {
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) cnt_readers += __shfl_down(cnt_readers, off);
+            if (lane == 0 && cnt_readers) atomicAdd(&p.counters[3], cnt_readers);
+        }
     }
     if (STATS) {
 #pragma unroll
@@ -425,6 +434,8 @@ __global__ __launch_bounds__(256) void pass_kernel(const PassParams p)
 // only listed rows are processed, with exactly the frontier-mode row semantics of
 // pass_kernel, so registers / Kahan state / changed bits are bit-identical.
 constexpr int kMaxSparseLevels = 12;
+constexpr int kHeavySlot = 32;          // index into SparseParams::counts
+constexpr uint64_t kHeavyReaders = 2048; // a seed with more readers than this is expanded grid-wide
 
 struct SparseParams {
     PassParams p;
@@ -434,7 +445,8 @@ struct SparseParams {
     uint32_t *list_real;       // worklist of node rows (capacity n_pad)
     uint32_t *list_virt;       // worklists of virtual rows, level l at offset level_begin[l] - n_pad
     uint32_t *seeds;           // nodes changed in the previous pass (capacity n_pad)
-    unsigned int *counts;      // [0] seeds, [1] real list, [2 + l] level-l list
+    uint32_t *heavy;           // seeds with long reader lists (expanded by the whole grid)
+    unsigned int *counts;      // [0] seeds, [1] real list, [2 + l] level-l list, [kHeavySlot] heavy seeds
     uint64_t level_begin[kMaxSparseLevels + 1];
     int levels;
     int level;                 // level processed by this launch (sparse_rows_kernel<false>)
@@ -443,6 +455,7 @@ struct SparseParams {
 __device__ __forceinline__ void sparse_push(const SparseParams &sp, uint32_t r)
 {
     const uint32_t bit = 1u << (r & 31u);
+    if (__builtin_nontemporal_load(&sp.touch[r >> 5]) & bit) return; // cheap pre-test (a stale miss is re-checked below)
     const uint32_t old = atomicOr(&sp.touch[r >> 5], bit);
     if (old & bit) return;
     if ((uint64_t)r < sp.p.n_pad) {
@@ -481,7 +494,22 @@ __global__ __launch_bounds__(256) void sparse_expand_kernel(const SparseParams s
     for (uint32_t i = wave; i < nseeds; i += nwaves) {
         const uint32_t u = sp.seeds[i];
         const uint64_t b = sp.out_ptr[u], e = sp.out_ptr[u + 1];
+        if (e - b > kHeavyReaders) { // hubs stay in the changed set longest: spread them over the grid
+            if (lane == 0) sp.heavy[atomicAdd(&sp.counts[kHeavySlot], 1u)] = u;
+            continue;
+        }
         for (uint64_t k = b + lane; k < e; k += 64) sparse_push(sp, sp.out_rows[k]);
+    }
+}
+
+__global__ __launch_bounds__(256) void sparse_expand_heavy_kernel(const SparseParams sp)
+{
+    const uint32_t nheavy = sp.counts[kHeavySlot];
+    const uint64_t tid = (uint64_t)blockIdx.x * 256 + threadIdx.x, nthreads = (uint64_t)gridDim.x * 256;
+    for (uint32_t i = 0; i < nheavy; i++) {
+        const uint32_t u = sp.heavy[i];
+        const uint64_t b = sp.out_ptr[u], e = sp.out_ptr[u + 1];
+        for (uint64_t k = b + tid; k < e; k += nthreads) sparse_push(sp, sp.out_rows[k]);
     }
 }
 
@@ -507,7 +535,7 @@ __global__ __launch_bounds__(256) void sparse_rows_kernel(const SparseParams sp)
     const uint32_t count = REAL ? sp.counts[1] : sp.counts[2 + sp.level];
     const uint32_t *list = REAL ? sp.list_real : sp.list_virt + (sp.level_begin[sp.level] - p.n_pad);
     const uint32_t nwaves = gridDim.x * 4;
-    unsigned long long cnt_changed = 0;
+    unsigned long long cnt_changed = 0, cnt_readers = 0;
     for (uint32_t base = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 16; base < count; base += nwaves * 16) {
         const uint32_t li = base + (uint32_t)g;
         const bool valid = li < count;
@@ -553,7 +581,10 @@ __global__ __launch_bounds__(256) void sparse_rows_kernel(const SparseParams sp)
             const bool self_prev = valid && ((p.bits_rd[row >> 5] >> (row & 31u)) & 1u);
             const bool kd = valid && ((p.kdirty[row >> 5] >> (row & 31u)) & 1u);
             if (valid && (changed || self_prev)) p.wr[row * 4 + q] = accv; // lazy double buffer
-            if (changed && q == 0) atomicOr(&p.bits_wr[row >> 5], bit);
+            if (changed && q == 0) {
+                atomicOr(&p.bits_wr[row >> 5], bit);
+                cnt_readers += sp.out_ptr[row + 1] - sp.out_ptr[row];
+            }
             cnt_changed += __popc(pack16(bal));
             if (valid && (changed || kd)) {
                 const uint64_t sz_old = p.size[row];
@@ -578,7 +609,12 @@ __global__ __launch_bounds__(256) void sparse_rows_kernel(const SparseParams sp)
             }
         }
     }
-    if (REAL && lane == 0 && cnt_changed) atomicAdd(&p.counters[0], cnt_changed);
+    if (REAL) {
+        if (lane == 0 && cnt_changed) atomicAdd(&p.counters[0], cnt_changed);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) cnt_readers += __shfl_down(cnt_readers, off);
+        if (lane == 0 && cnt_readers) atomicAdd(&p.counters[3], cnt_readers);
+    }
 }
 
 // ---- transposed work-row graph (built once per load) ------------------------------------------

@@ -37,11 +37,14 @@ def main():
                 ref = sig
             dense = [p for p in ps if p["mode"] == 0]
             front = [p for p in ps if p["mode"] == 1]
+            sparse = [p for p in ps if p["mode"] == 2]
             print(json.dumps({
                 "spec": spec, "ms_loop": round(best["ms_loop"], 3), "gteps": round(g.m * best["passes"] / best["ms_loop"] / 1e6, 2),
                 "passes": best["passes"], "dense_ms_gpu": round(float(np.mean([p["ms_gpu"] for p in dense])), 3) if dense else None,
                 "dense_ms_main": round(float(np.mean([p["ms_main"] for p in dense])), 3) if dense else None,
                 "front_ms_gpu": round(float(np.mean([p["ms_gpu"] for p in front])), 3) if front else None,
+                "sparse_ms_gpu": [round(p["ms_gpu"], 3) for p in sparse],
+                "changed": [p["changed"] for p in ps],
                 "virtual_rows": best["virtual_rows"], "s_load": round(t_load, 2), "ms_plan": round(best["ms_plan"]),
                 "same_result": sig == ref}), flush=True)
 
