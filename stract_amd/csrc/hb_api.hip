@@ -78,7 +78,6 @@ struct hb_ctx {
     bool has_changes = false;
     bool pending_local = false; // between hb_step_local and hb_step_finish
     uint64_t last_changed = 0;
-    uint64_t last_readers = ~0ull; // work rows reading the nodes that changed in the previous pass
     uint32_t max_passes = 4096;
     std::vector<hb_pass_stats> pstats;
     hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -379,7 +378,6 @@ hbk::PassParams make_params(hb_ctx *c)
     pp.kerr = c->d_kerr;
     pp.size = c->d_size;
     pp.counters = c->d_counters + 4 * c->t;
-    pp.out_ptr = c->sparse_ok ? c->d_out_ptr : nullptr;
     pp.raw = c->d_raw;
     pp.bias = c->d_bias;
     pp.lc = c->d_lc;
@@ -407,10 +405,9 @@ int step_local(hb_ctx *c)
     uint32_t thr = c->opt.tune[2] ? c->opt.tune[2] : 25; // percent of nodes changed in the previous pass
     bool frontier = !(c->opt.flags & HB_FLAG_NO_FRONTIER) && c->t > 0 &&
                     (c->last_changed * 100ull < (uint64_t)thr * p.n);
-    // sparse when (work rows reading a changed node) * div < all source-list entries
-    const uint64_t sparse_div = c->opt.tune[6] ? c->opt.tune[6] : 64;
-    const bool sparse = frontier && c->sparse_ok && c->last_readers != ~0ull &&
-                        (c->last_readers * sparse_div < c->plan_entries || c->opt.tune[6] == 1);
+    // sparse when few nodes changed in the previous pass: changed * div < n
+    const uint64_t sparse_div = c->opt.tune[6] ? c->opt.tune[6] : 256;
+    const bool sparse = frontier && c->sparse_ok && (c->last_changed * sparse_div < p.n || c->opt.tune[6] == 1);
     c->cur_mode = sparse ? 2 : (frontier ? 1 : 0);
     const bool fused = !unfused(c);
     hbk::PassParams pp = make_params(c);
@@ -510,7 +507,6 @@ int step_finish(hb_ctx *c, int *has_changes)
     c->pstats.push_back(ps);
     // counters.step(); changed_nodes = new_changed_nodes; t += 1 (harmonic.rs:273-275)
     c->last_changed = ps.changed;
-    c->last_readers = c->sparse_ok ? c->h_counters[3] : ~0ull;
     c->has_changes = ps.changed != 0;
     c->cur ^= 1;
     c->t += 1;
@@ -730,7 +726,6 @@ int hb_begin(hb_ctx *c)
     c->cur = 0;
     c->has_changes = true; // harmonic.rs:232
     c->last_changed = p.n;
-    c->last_readers = ~0ull;
     c->pending_local = false;
     c->pstats.clear();
     c->begun = true;

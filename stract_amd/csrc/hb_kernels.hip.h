@@ -35,12 +35,11 @@ struct PassParams {
     uint4 *part;              // virtual (hub-chunk) rows, indexed by vid - n_pad
     const uint32_t *bits_rd;  // changed bits: real rows = previous pass, virtual rows = this pass
     uint32_t *bits_wr;        // changed bits of this pass for real rows (next frontier)
-    uint32_t *kdirty;         // per real row: Kahan compensation term != 0
+    uint32_t *kdirty;         // per real row: the last Kahan update moved (sum, err): `+= 0.0` is not yet a no-op
     double *ksum;
     double *kerr;
     uint64_t *size;           // cached size() of rd[row]
-    unsigned long long *counters; // [0] changed rows, [1] active edges, [2] rows processed, [3] readers of changed rows
-    const uint64_t *out_ptr;  // transposed work-row graph offsets (NULL when not built)
+    unsigned long long *counters; // [0] changed rows, [1] active edges, [2] rows processed
     const double *raw;        // HLL64_RAW_ESTIMATE (global copy, staged to LDS)
     const double *bias;       // HLL64_BIAS
     const uint8_t *lc;        // linear-counting table, 65 entries (index = zero registers)
@@ -224,16 +223,24 @@ __device__ __forceinline__ uint64_t hll_size_quad(const uint4 &v, const double *
     return f64_as_usize(e_star);
 }
 
-// update_centralities for one node (harmonic.rs:159-176) + KahanSum::add_assign
-__device__ __forceinline__ void kahan_update(double &sum, double &err, uint64_t sz_new, uint64_t sz_old,
+// update_centralities for one node (harmonic.rs:159-176) + KahanSum::add_assign.
+// Returns whether (sum, err) moved bitwise.  The reference applies this to every node in every
+// pass, `+= 0.0` included; a `+= 0.0` that leaves the state bitwise unchanged is a fixed point
+// (same inputs next pass), so such a node can be left alone until its counter changes again.
+// ("err != 0" is NOT that test: a compensation below half an ulp of sum survives every flush.)
+__device__ __forceinline__ bool kahan_update(double &sum, double &err, uint64_t sz_new, uint64_t sz_old,
                                              double t_plus_1)
 {
     uint64_t d = (sz_new >= sz_old) ? sz_new - sz_old : 0; // checked_sub().unwrap_or_default()
     double rhs = (double)d / t_plus_1;
     double y = rhs - err;
     double t = sum + y;
-    err = (t - sum) - y;
+    double e = (t - sum) - y;
+    const bool moved = (__double_as_longlong(t) != __double_as_longlong(sum)) ||
+                       (__double_as_longlong(e) != __double_as_longlong(err));
+    err = e;
     sum = t;
+    return moved;
 }
 
 // ---- the pass kernel --------------------------------------------------------------------
@@ -262,7 +269,7 @@ __global__ __launch_bounds__(256) void pass_kernel(const PassParams p)
     const int g = lane >> 2, q = lane & 3;
     const int qshift = lane & ~3;
     const uint64_t ntiles = (p.row_hi - p.row_lo + 63) >> 6;
-    unsigned long long cnt_changed = 0, cnt_active = 0, cnt_rows = 0, cnt_readers = 0;
+    unsigned long long cnt_changed = 0, cnt_active = 0, cnt_rows = 0;
 
     for (uint64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const uint64_t row16 = p.row_lo + (tile << 6) + ((uint64_t)wave << 4); // first row of this wave
@@ -379,10 +386,7 @@ __global__ __launch_bounds__(256) void pass_kernel(const PassParams p)
             uint16_t *dst = REAL ? (uint16_t *)p.bits_wr : (uint16_t *)p.bits_rd;
             if (lane == 0 && row16 < p.row_hi) dst[row16 >> 4] = (uint16_t)ch16;
         }
-        if (REAL && FUSED) {
-            cnt_changed += __popc(ch16);
-            if (changed && q == 0 && p.out_ptr) cnt_readers += p.out_ptr[row + 1] - p.out_ptr[row];
-        }
+        if (REAL && FUSED) cnt_changed += __popc(ch16);
         if (STATS) cnt_rows += (need && q == 0);
         if (REAL && FUSED) {
             bool err_nz = false;
@@ -391,11 +395,12 @@ __global__ __launch_bounds__(256) void pass_kernel(const PassParams p)
                 const uint64_t sz_new = changed ? hll_size_quad(accv, s_raw, s_bias, s_lc) : sz_old;
                 if (q == 0) {
                     double ks = p.ksum[row], ke = p.kerr[row];
-                    kahan_update(ks, ke, sz_new, sz_old, p.t_plus_1);
-                    p.ksum[row] = ks;
-                    p.kerr[row] = ke;
+                    err_nz = kahan_update(ks, ke, sz_new, sz_old, p.t_plus_1); // still moving -> visit again
+                    if (err_nz) {
+                        p.ksum[row] = ks;
+                        p.kerr[row] = ke;
+                    }
                     if (changed) p.size[row] = sz_new;
-                    err_nz = (ke != 0.0);
                 }
             }
             const uint32_t nk16 = pack16(__ballot(err_nz));
@@ -406,11 +411,6 @@ __global__ __launch_bounds__(256) void pass_kernel(const PassParams p)
     if (REAL) {
         // cnt_changed is identical in all lanes of the wave (derived from a ballot)
         if (lane == 0 && cnt_changed) atomicAdd(&p.counters[0], cnt_changed);
-        if (FUSED && p.out_ptr) {
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) cnt_readers += __shfl_down(cnt_readers, off);
-            if (lane == 0 && cnt_readers) atomicAdd(&p.counters[3], cnt_readers);
-        }
     }
     if (STATS) {
 #pragma unroll
@@ -535,7 +535,7 @@ __global__ __launch_bounds__(256) void sparse_rows_kernel(const SparseParams sp)
     const uint32_t count = REAL ? sp.counts[1] : sp.counts[2 + sp.level];
     const uint32_t *list = REAL ? sp.list_real : sp.list_virt + (sp.level_begin[sp.level] - p.n_pad);
     const uint32_t nwaves = gridDim.x * 4;
-    unsigned long long cnt_changed = 0, cnt_readers = 0;
+    unsigned long long cnt_changed = 0;
     for (uint32_t base = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 16; base < count; base += nwaves * 16) {
         const uint32_t li = base + (uint32_t)g;
         const bool valid = li < count;
@@ -581,21 +581,19 @@ __global__ __launch_bounds__(256) void sparse_rows_kernel(const SparseParams sp)
             const bool self_prev = valid && ((p.bits_rd[row >> 5] >> (row & 31u)) & 1u);
             const bool kd = valid && ((p.kdirty[row >> 5] >> (row & 31u)) & 1u);
             if (valid && (changed || self_prev)) p.wr[row * 4 + q] = accv; // lazy double buffer
-            if (changed && q == 0) {
-                atomicOr(&p.bits_wr[row >> 5], bit);
-                cnt_readers += sp.out_ptr[row + 1] - sp.out_ptr[row];
-            }
+            if (changed && q == 0) atomicOr(&p.bits_wr[row >> 5], bit);
             cnt_changed += __popc(pack16(bal));
             if (valid && (changed || kd)) {
                 const uint64_t sz_old = p.size[row];
                 const uint64_t sz_new = changed ? hll_size_quad(accv, s_raw, s_bias, s_lc) : sz_old;
                 if (q == 0) {
                     double ks = p.ksum[row], ke = p.kerr[row];
-                    kahan_update(ks, ke, sz_new, sz_old, p.t_plus_1);
-                    p.ksum[row] = ks;
-                    p.kerr[row] = ke;
+                    const bool err_nz = kahan_update(ks, ke, sz_new, sz_old, p.t_plus_1);
+                    if (err_nz) {
+                        p.ksum[row] = ks;
+                        p.kerr[row] = ke;
+                    }
                     if (changed) p.size[row] = sz_new;
-                    const bool err_nz = (ke != 0.0);
                     if (err_nz && !kd) atomicOr(&p.kdirty[row >> 5], bit);
                     if (!err_nz && kd) atomicAnd(&p.kdirty[row >> 5], ~bit);
                 }
@@ -609,12 +607,7 @@ __global__ __launch_bounds__(256) void sparse_rows_kernel(const SparseParams sp)
             }
         }
     }
-    if (REAL) {
-        if (lane == 0 && cnt_changed) atomicAdd(&p.counters[0], cnt_changed);
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) cnt_readers += __shfl_down(cnt_readers, off);
-        if (lane == 0 && cnt_readers) atomicAdd(&p.counters[3], cnt_readers);
-    }
+    if (REAL && lane == 0 && cnt_changed) atomicAdd(&p.counters[0], cnt_changed);
 }
 
 // ---- transposed work-row graph (built once per load) ------------------------------------------
@@ -689,11 +682,12 @@ __global__ __launch_bounds__(256) void epilogue_kernel(const PassParams p)
             const uint64_t sz_new = changed ? hll_size_quad(newv, s_raw, s_bias, s_lc) : sz_old;
             if (q == 0) {
                 double ks = p.ksum[row], ke = p.kerr[row];
-                kahan_update(ks, ke, sz_new, sz_old, p.t_plus_1);
-                p.ksum[row] = ks;
-                p.kerr[row] = ke;
+                err_nz = kahan_update(ks, ke, sz_new, sz_old, p.t_plus_1);
+                if (err_nz) {
+                    p.ksum[row] = ks;
+                    p.kerr[row] = ke;
+                }
                 if (changed) p.size[row] = sz_new;
-                err_nz = (ke != 0.0);
             }
         }
         const uint32_t nk16 = pack16(__ballot(err_nz));
