@@ -60,8 +60,10 @@ def torch_unique_id(rank, world):
     buf = torch.zeros(128, dtype=torch.uint8)
     if rank == 0:
         buf = torch.frombuffer(bytearray(_lib.rccl_unique_id()), dtype=torch.uint8).clone()
+    if td.get_backend() == "nccl":  # RCCL moves device memory only
+        buf = buf.cuda()
     td.broadcast(buf, src=0)
-    return bytes(buf.tolist())
+    return bytes(buf.cpu().tolist())
 
 
 def make_context(rank, world, device, rccl_id, **kw):
