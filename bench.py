@@ -12,8 +12,10 @@ torch.distributed.run, one rank per GPU).  Prints ONE JSON line on rank 0.
   workload  = BASELINE.json configs[2] (10M-host / 200M-edge R-MAT, the roofline config) by
               default; --config C2 selects configs[1] (1M/20M: fits the 256 MiB Infinity Cache, so
               it says little about HBM), C4 = configs[3].
-  N > 1     = the same graph edge-partitioned over the ranks (strong scaling), one
-              ncclAllReduce(max, u8) of the counters per pass.
+  N > 1     = the same graph partitioned over the ranks (strong scaling), one RCCL collective of
+              the counters per pass: --partition dest (default) = rows by owner,
+              ncclAllGather of the owned slices; --partition edge = the north-star edge partition
+              with ncclAllReduce(max, u8).
   roofline  = dominant kernel (dense pull over the hub chunks): algorithmic bytes per launch / its
               mean duration (HIP events on the library's stream) vs 8 TB/s; the whole dense pass
               (68*m_eff + 192.25*n bytes) is reported next to it.
@@ -42,6 +44,9 @@ def parse():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--config", default=os.environ.get("HB_BENCH_CONFIG", "C3"), help="C1|C2|C3|C4 or scale:m")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="CPU-baseline time bound (0 = skip)")
+    ap.add_argument("--partition", default="dest", choices=["dest", "edge"],
+                    help="N > 1: destination partition + all-gather per pass (default) or the north-star "
+                         "edge partition + all-reduce(max) per pass")
     ap.add_argument("--flags", type=int, default=0)
     ap.add_argument("--chunk", type=int, default=0)
     ap.add_argument("--tune", default="", help="comma separated hb_options.tune values")
@@ -88,11 +93,14 @@ def main():
     flags = a.flags
     if world > 1:
         rccl_id = dist.torch_unique_id(rank, world)
+        if a.partition == "dest":
+            flags |= _lib.HB_FLAG_DEST_PARTITION
     tune = tuple(int(x) for x in a.tune.split(",")) if a.tune else ()
     ctx = _lib.Context(device=local_rank, flags=flags, chunk=a.chunk, rank=rank, world_size=world, rccl_id=rccl_id,
                        tune=tune)
     if world > 1:
-        rp, src = dist.partition_dense(g.row_ptr, g.src, rank, world)
+        split = dist.partition_dense_by_dest if a.partition == "dest" else dist.partition_dense
+        rp, src = split(g.row_ptr, g.src, rank, world)
     else:
         rp, src = g.row_ptr, g.src
     t0 = time.perf_counter()
@@ -181,7 +189,9 @@ def main():
             "data": "synthetic",
             "config": {"workload": "%s %s (R-MAT scale %d, a,b,c,d=.57,.19,.19,.05, seed 0x5712AC7)" % (a.config, label, scale),
                        "n_hosts": n, "m_eff": m_eff, "passes_T": passes,
-                       "parallelism": "edge-partition x%d + allreduce(max,u8)/pass" % world if world > 1 else "1 GPU"},
+                       "parallelism": ("1 GPU" if world == 1 else
+                                       "destination-partition x%d + allgather(u8)/pass" % world if a.partition == "dest" else
+                                       "edge-partition x%d + allreduce(max,u8)/pass" % world)},
             "roofline": roof,
             "cpu_baseline": cpu,
             "detail": {"ms_loop_per_step": round(loop_ms / steps, 3), "ms_gpu_passes_per_step": round(gpu_ms / steps, 3),

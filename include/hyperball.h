@@ -71,8 +71,13 @@ typedef struct hb_edge {
 #define HB_FLAG_NO_LDS_HOT    0x10u /* do not stage the hottest counters in LDS                    */
 #define HB_FLAG_NO_XCD_MAP    0x20u /* plain blockIdx -> work mapping                              */
 #define HB_FLAG_NO_RCCL       0x40u /* world_size > 1 bookkeeping without a communicator: the caller
-                                       performs the exchange (hb_debug_merge_pending; tests)       */
+                                       performs the exchange (hb_debug_exchange; tests)       */
 #define HB_FLAG_NO_SPARSE     0x100u /* never use the worklist-driven tail passes (debug; same results) */
+#define HB_FLAG_DEST_PARTITION 0x200u /* world_size > 1: destination partition instead of edge partition -
+                                        rank r owns the nodes whose rank in ascending NodeID order is
+                                        r mod world_size and must be given ALL in-edges of those nodes
+                                        (records for other nodes are ignored); one ncclAllGather of the
+                                        owned counter slices per pass instead of an all-reduce          */
 #define HB_FLAG_RCCL_SELF     0x80u /* world_size == 1 but still create a 1-rank communicator and run
                                        the collectives (exercises the RCCL call path on one GPU)   */
 
@@ -207,12 +212,16 @@ int hb_debug_hll_size(hb_ctx *ctx, const uint8_t *regs, uint64_t count, uint64_t
 /* Reduced graph as the library sees it after ingest (ascending-NodeID indexing):
  * any pointer may be NULL; row_ptr has n+1 entries, src has m_eff. */
 int hb_debug_copy_graph(hb_ctx *ctx, hb_u128 *ids, uint64_t *row_ptr, uint32_t *src);
-/* Element-wise max of ctx's pending ("new") counters with those of `other` (same n):
- * emulates the all-reduce(max) between logical ranks living on one device. Only valid
- * between hb_step_local and hb_step_finish. */
-int hb_debug_merge_pending(hb_ctx *ctx, hb_ctx *other);
-/* Two halves of hb_step for HB_FLAG_UNFUSED contexts: local merge into the pending
- * counters; [collective or hb_debug_merge_pending]; estimator/Kahan/changed detection. */
+/* Emulates the collective of one pass between `count` logical ranks that live on ONE device
+ * (contexts created with HB_FLAG_NO_RCCL; RCCL refuses two ranks on one device).
+ *   phase 0, between hb_step_local and hb_step_finish of every context:
+ *     edge partition:        all-reduce(max) of the pending counters
+ *     destination partition: all-gather of the owned counter / changed-bit slices, sum of the
+ *                            changed counts (ctxs[i] must be rank i)
+ *   phase 1, before hb_finish: all-gather of the Kahan-sum slices. */
+int hb_debug_exchange(hb_ctx **ctxs, int count, int phase);
+/* Two halves of hb_step: local pull into the pending counters; [collective, or hb_debug_exchange];
+ * then (edge partition / HB_FLAG_UNFUSED) estimator/Kahan/changed detection, bookkeeping. */
 int hb_step_local(hb_ctx *ctx);
 int hb_step_finish(hb_ctx *ctx, int *has_changes);
 
@@ -226,7 +235,8 @@ int hb_host_ingest(const hb_u128 *node_ids, uint64_t n, const hb_edge *edges, ui
 /* The device work layout the planner would build for a reduced graph (device order +
  * hub-row splitting), so its invariants can be checked on the host.  flags: HB_FLAG_NO_REORDER.
  * Two-call pattern: sizes[0..3] = {n_pad, nv, plan_src_len, levels}; then
- * order[n], plan_row_ptr[n_pad+nv+1], plan_src[plan_src_len], level_begin[levels+1]. */
+ * order[n_pad] (0xFFFFFFFF = padding row), plan_row_ptr[n_pad+nv+1], plan_src[plan_src_len],
+ * level_begin[levels+1].  tune[7] > 1 lays the rows out as tune[7] owner slices (destination partition). */
 int hb_host_plan(uint64_t n, const uint64_t *row_ptr, const uint32_t *src, uint32_t flags,
                  uint32_t chunk, const uint32_t *tune /* hb_options.tune or NULL */, uint64_t sizes[4],
                  uint32_t *order, uint64_t *plan_row_ptr, uint32_t *plan_src, uint64_t *level_begin);

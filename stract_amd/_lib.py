@@ -25,6 +25,7 @@ HB_FLAG_NO_XCD_MAP = 0x20
 HB_FLAG_NO_RCCL = 0x40
 HB_FLAG_RCCL_SELF = 0x80
 HB_FLAG_NO_SPARSE = 0x100
+HB_FLAG_DEST_PARTITION = 0x200
 
 # numpy views of the plain-data structs
 U128 = np.dtype([("lo", "<u8"), ("hi", "<u8")])
@@ -119,7 +120,7 @@ _SIGNATURES = [
     ("hb_debug_copy_sizes", ctypes.c_int, [_P, _P]),
     ("hb_debug_hll_size", ctypes.c_int, [_P, _P, _U64, _P]),
     ("hb_debug_copy_graph", ctypes.c_int, [_P, _P, _P, _P]),
-    ("hb_debug_merge_pending", ctypes.c_int, [_P, _P]),
+    ("hb_debug_exchange", ctypes.c_int, [_P, ctypes.c_int, ctypes.c_int]),
     ("hb_step_local", ctypes.c_int, [_P]),
     ("hb_step_finish", ctypes.c_int, [_P, ctypes.POINTER(ctypes.c_int)]),
     ("hb_host_ingest", ctypes.c_int, [_P, _U64, _P, _U64, ctypes.POINTER(_U64), ctypes.POINTER(_U64),
@@ -260,8 +261,11 @@ class Context:
         self._check(self.lib.hb_step_finish(self.h, ctypes.byref(has)))
         return bool(has.value)
 
-    def merge_pending(self, other):
-        self._check(self.lib.hb_debug_merge_pending(self.h, other.h))
+    @staticmethod
+    def exchange(ctxs, phase=0):
+        """Emulated collective between logical ranks on one device (hb_debug_exchange)."""
+        arr = (ctypes.c_void_p * len(ctxs))(*[c.h for c in ctxs])
+        ctxs[0]._check(ctxs[0].lib.hb_debug_exchange(arr, len(ctxs), phase))
 
     def finish(self):
         self._check(self.lib.hb_finish(self.h))
@@ -380,7 +384,7 @@ def host_plan(row_ptr, src, flags=0, chunk=0, tune=()):
     if rc != HB_OK:
         raise HyperballError(rc, (lib.hb_last_error(None) or b"").decode())
     n_pad, nv, slen, levels = (int(x) for x in sizes)
-    order = np.zeros(n, dtype=np.uint32)
+    order = np.zeros(n_pad, dtype=np.uint32)
     prp = np.zeros(n_pad + nv + 1, dtype=np.uint64)
     psrc = np.zeros(slen, dtype=np.uint32)
     lb = np.zeros(levels + 1, dtype=np.uint64)
@@ -388,4 +392,7 @@ def host_plan(row_ptr, src, flags=0, chunk=0, tune=()):
                           _ptr(psrc), _ptr(lb))
     if rc != HB_OK:
         raise HyperballError(rc, (lib.hb_last_error(None) or b"").decode())
-    return dict(order=order, row_ptr=prp, src=psrc, level_begin=lb, n_pad=n_pad, nv=nv)
+    world = int(tn[7]) if tn[7] > 1 else 1
+    if world == 1:
+        order = order[:n]  # no padding rows inside: a permutation of the sids
+    return dict(order=order, row_ptr=prp, src=psrc, level_begin=lb, n_pad=n_pad, nv=nv, slice=n_pad // world)

@@ -56,6 +56,7 @@ struct hb_ctx {
     uint64_t *d_size = nullptr;
     uint64_t *d_idlow = nullptr;
     uint32_t *d_dev_of = nullptr;
+    uint32_t *d_sid_of = nullptr; // device row -> sid, kNone for padding rows
     unsigned long long *d_counters = nullptr; // max_passes * 4
     double *d_raw = nullptr, *d_bias = nullptr;
     uint8_t *d_lc = nullptr;
@@ -143,6 +144,7 @@ void free_graph_buffers(hb_ctx *c)
     c->d_size = nullptr;
     c->d_idlow = nullptr;
     c->d_dev_of = nullptr;
+    c->d_sid_of = nullptr;
     c->d_counters = nullptr;
     c->d_raw = c->d_bias = nullptr;
     c->d_lc = nullptr;
@@ -172,8 +174,16 @@ PlanTune plan_tune(uint32_t chunk, const uint32_t *tune)
     return t;
 }
 
-bool edge_partitioned(const hb_ctx *c) { return c->opt.world_size > 1; }
-bool unfused(const hb_ctx *c) { return edge_partitioned(c) || c->comm || (c->opt.flags & HB_FLAG_UNFUSED); }
+bool multi_rank(const hb_ctx *c) { return c->opt.world_size > 1; }
+// destination partition: this rank owns the rows (nodes) with sid % world == rank and holds all their
+// in-edges; one all-gather of the owned counter slices per pass
+bool dest_mode(const hb_ctx *c) { return multi_rank(c) && (c->opt.flags & HB_FLAG_DEST_PARTITION); }
+// edge partition: every rank holds some in-edges of every row; one all-reduce(max) of all counters per pass
+bool edge_partitioned(const hb_ctx *c) { return multi_rank(c) && !dest_mode(c); }
+bool unfused(const hb_ctx *c)
+{
+    return edge_partitioned(c) || (c->comm && !dest_mode(c)) || (c->opt.flags & HB_FLAG_UNFUSED);
+}
 
 // Transposed work-row graph (who reads each node / virtual row) and worklists for the sparse
 // tail passes; built on the device from the uploaded plan, prefix sum on the host.
@@ -181,7 +191,7 @@ int build_sparse_support(hb_ctx *c)
 {
     const Plan &p = c->plan;
     c->sparse_ok = false;
-    if (unfused(c) || (c->opt.flags & HB_FLAG_NO_SPARSE) || p.n == 0) return HB_OK;
+    if (unfused(c) || multi_rank(c) || (c->opt.flags & HB_FLAG_NO_SPARSE) || p.n == 0) return HB_OK;
     if (p.level_begin.size() > (size_t)hbk::kMaxSparseLevels + 1) return HB_OK; // very deep trees: bitmap modes only
     const uint64_t rows_total = p.n_pad + p.nv;
     const uint64_t entries = p.src.size();
@@ -238,7 +248,7 @@ int plan_and_upload(hb_ctx *c)
     // global out-degree (device order must be identical on every rank)
     std::vector<uint32_t> outdeg;
     bool reorder = !(c->opt.flags & HB_FLAG_NO_REORDER);
-    if (edge_partitioned(c) && !c->comm) reorder = false; // logical ranks without a communicator
+    if (multi_rank(c) && !c->comm) reorder = false; // logical ranks without a communicator
     if (reorder) {
         count_out_degree(c->g.row_ptr.data(), c->g.src.data(), n, &outdeg);
         if (c->comm && n) {
@@ -255,8 +265,9 @@ int plan_and_upload(hb_ctx *c)
             if (e != hipSuccess) return fail(c, HB_ERR_HIP, std::string("out-degree all-reduce: ") + hipGetErrorString(e));
         }
     }
-    std::string perr = build_plan(n, c->g.row_ptr.data(), c->g.src.data(), outdeg, reorder,
-                                  plan_tune(c->opt.chunk, c->opt.tune), &c->plan);
+    PlanTune pt = plan_tune(c->opt.chunk, c->opt.tune);
+    if (dest_mode(c)) pt.world = (uint32_t)c->opt.world_size;
+    std::string perr = build_plan(n, c->g.row_ptr.data(), c->g.src.data(), outdeg, reorder, pt, &c->plan);
     if (!perr.empty()) return fail(c, perr.find("memory") != std::string::npos ? HB_ERR_NOMEM : HB_ERR_LIMIT, perr);
     c->stats.ms_plan = now_ms() - t0;
     const Plan &p = c->plan;
@@ -280,13 +291,14 @@ int plan_and_upload(hb_ctx *c)
     if ((rc = dev_alloc(c, &c->d_kdirty, p.n_pad / 32 + 2))) return rc;
     // Kahan ownership: one contiguous slice of rows per rank (multiple of 64 rows)
     const uint64_t world = c->comm ? (uint64_t)c->opt.world_size : 1;
-    c->slice_rows = ((p.n_pad + world - 1) / world + 63) / 64 * 64;
-    c->ksum_len = std::max<uint64_t>(c->slice_rows * world, p.n_pad);
+    c->slice_rows = dest_mode(c) ? p.slice : ((p.n_pad + world - 1) / world + 63) / 64 * 64;
+    c->ksum_len = std::max<uint64_t>(c->slice_rows * (dest_mode(c) ? (uint64_t)c->opt.world_size : world), p.n_pad);
     if ((rc = dev_alloc(c, &c->d_ksum, c->ksum_len))) return rc;
     if ((rc = dev_alloc(c, &c->d_kerr, p.n_pad))) return rc;
     if ((rc = dev_alloc(c, &c->d_size, p.n_pad))) return rc;
     if ((rc = dev_alloc(c, &c->d_idlow, p.n_pad))) return rc;
     if ((rc = dev_alloc(c, &c->d_dev_of, n))) return rc;
+    if ((rc = dev_alloc(c, &c->d_sid_of, p.n_pad))) return rc;
     if ((rc = dev_alloc(c, &c->d_counters, (size_t)c->max_passes * 4))) return rc;
     if ((rc = dev_alloc(c, &c->d_raw, HLL64_TABLE_LEN))) return rc;
     if ((rc = dev_alloc(c, &c->d_bias, HLL64_TABLE_LEN))) return rc;
@@ -307,8 +319,11 @@ int plan_and_upload(hb_ctx *c)
     if (!p.src.empty())
         HB_HIP(hipMemcpyAsync(c->d_src, p.src.data(), p.src.size() * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
     std::vector<uint64_t> idlow(p.n_pad, 0);
-    for (uint64_t d = 0; d < n; d++) idlow[d] = c->g.ids[p.order[d]].lo;
+    for (uint64_t d = 0; d < p.n_pad; d++)
+        if (p.order[d] != kNone) idlow[d] = c->g.ids[p.order[d]].lo;
     HB_HIP(hipMemcpyAsync(c->d_idlow, idlow.data(), p.n_pad * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
+    if (p.n_pad)
+        HB_HIP(hipMemcpyAsync(c->d_sid_of, p.order.data(), p.n_pad * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
     if (n) HB_HIP(hipMemcpyAsync(c->d_dev_of, p.dev_of.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
     HB_HIP(hipStreamSynchronize(c->stream));
     if ((rc = build_sparse_support(c))) return rc;
@@ -383,7 +398,7 @@ hbk::PassParams make_params(hb_ctx *c)
     pp.lc = c->d_lc;
     pp.n = p.n;
     pp.n_pad = p.n_pad;
-    if (c->comm) {
+    if (c->comm || dest_mode(c)) {
         pp.slice_lo = (uint64_t)c->opt.rank * c->slice_rows;
         pp.slice_hi = std::min<uint64_t>(pp.slice_lo + c->slice_rows, p.n_pad);
     } else {
@@ -451,8 +466,8 @@ int step_local(hb_ctx *c)
             launch_pass(c, pp, false, frontier, false);
         }
         HB_HIP(hipEventRecord(c->ev[1], c->stream));
-        pp.row_lo = 0;
-        pp.row_hi = p.n_pad;
+        pp.row_lo = dest_mode(c) ? pp.slice_lo : 0; // destination partition: only the owned rows
+        pp.row_hi = dest_mode(c) ? pp.slice_hi : p.n_pad;
         launch_pass(c, pp, true, frontier, fused);
         HB_HIP(hipEventRecord(c->ev[2], c->stream));
     }
@@ -482,7 +497,20 @@ int step_finish(hb_ctx *c, int *has_changes)
         }
         HB_HIP(hipGetLastError());
     }
+    if (dest_mode(c) && c->comm) {
+        // every rank produced the final counters, changed bits and changed count of ITS rows (fused
+        // kernel): all-gather the slices in place; sum the counts
+        hbk::PassParams pp = make_params(c);
+        const uint64_t S = c->slice_rows, r = (uint64_t)c->opt.rank;
+        HB_NCCL(ncclGroupStart());
+        HB_NCCL(ncclAllGather(pp.wr + r * S * 4, pp.wr, S * 64, ncclUint8, c->comm, c->stream));
+        HB_NCCL(ncclAllGather(pp.bits_wr + r * (S / 32), pp.bits_wr, S / 32, ncclUint32, c->comm, c->stream));
+        HB_NCCL(ncclAllReduce(pp.counters, pp.counters, 1, ncclUint64, ncclSum, c->comm, c->stream));
+        HB_NCCL(ncclGroupEnd());
+        HB_HIP(hipEventRecord(c->ev[3], c->stream));
+    }
     hipEvent_t ev_end = c->ev[2];
+    if (dest_mode(c) && c->comm) ev_end = c->ev[3];
     if (unfused(c)) {
         // events: [0] start, [1] after virtual levels, [2] after local merge, [3] after collective,
         // [4] after the epilogue
@@ -491,7 +519,7 @@ int step_finish(hb_ctx *c, int *has_changes)
     }
     HB_HIP(hipMemcpyAsync(c->h_counters, c->d_counters + 4 * c->t, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
     HB_HIP(hipStreamSynchronize(c->stream));
-    if (unfused(c)) HB_HIP(hipEventElapsedTime(&ms_coll, c->ev[2], c->ev[3]));
+    if (unfused(c) || (dest_mode(c) && c->comm)) HB_HIP(hipEventElapsedTime(&ms_coll, c->ev[2], c->ev[3]));
     hb_pass_stats ps{};
     ps.pass = c->t;
     ps.changed = c->h_counters[0];
@@ -649,6 +677,7 @@ int hb_load_edges(hb_ctx *c, const hb_u128 *node_ids, uint64_t n, const hb_edge 
     double t0 = now_ms();
     std::string e = ingest_edges(node_ids, n, edges, m, &c->g);
     if (!e.empty()) return fail(c, e.find("memory") != std::string::npos ? HB_ERR_NOMEM : HB_ERR_LIMIT, e);
+    if (dest_mode(c)) keep_owned_rows(&c->g, (uint64_t)c->opt.world_size, (uint64_t)c->opt.rank);
     c->stats.ms_ingest = now_ms() - t0;
     double ing = c->stats.ms_ingest;
     rc = plan_and_upload(c);
@@ -695,6 +724,7 @@ int hb_load_dense(hb_ctx *c, const hb_u128 *sorted_ids, uint64_t n, const uint64
     }
     c->g.m_input = m_eff;
     c->g.m_unique = m_eff;
+    if (dest_mode(c)) keep_owned_rows(&c->g, (uint64_t)c->opt.world_size, (uint64_t)c->opt.rank);
     double ing = now_ms() - t0;
     rc = plan_and_upload(c);
     c->stats.ms_ingest = ing;
@@ -716,7 +746,7 @@ int hb_begin(hb_ctx *c)
     HB_HIP(hipMemsetAsync(c->d_ksum, 0, c->ksum_len * sizeof(double), c->stream));
     if (p.n_pad) {
         unsigned blocks = (unsigned)((p.n_pad * 4 + 255) / 256);
-        hipLaunchKernelGGL(hbk::init_kernel, dim3(blocks), dim3(256), 0, c->stream, c->d_idlow, p.n, p.n_pad,
+        hipLaunchKernelGGL(hbk::init_kernel, dim3(blocks), dim3(256), 0, c->stream, c->d_idlow, (const uint32_t *)c->d_sid_of, p.n_pad,
                            c->d_regs[0], c->d_regs[1], c->d_ksum, c->d_kerr, c->d_size, c->d_bits[0], c->d_kdirty,
                            c->d_raw, c->d_bias, c->d_lc);
         HB_HIP(hipGetLastError());
@@ -985,33 +1015,81 @@ int hb_host_plan(uint64_t n, const uint64_t *row_ptr, const uint32_t *src, uint3
     if (n == 0) row_ptr = &zero;
     if (reorder) count_out_degree(row_ptr, src, n, &outdeg);
     Plan p;
-    std::string e = build_plan(n, row_ptr, src, outdeg, reorder, plan_tune(chunk, tune), &p);
+    PlanTune pt = plan_tune(chunk, tune);
+    if (tune && tune[7] > 1) pt.world = tune[7]; // destination-partition layout (test hook)
+    std::string e = build_plan(n, row_ptr, src, outdeg, reorder, pt, &p);
     if (!e.empty()) return fail(c, HB_ERR_LIMIT, e);
     sizes[0] = p.n_pad;
     sizes[1] = p.nv;
     sizes[2] = p.src.size();
     sizes[3] = p.level_begin.size() ? p.level_begin.size() - 1 : 0;
-    if (order && n) std::memcpy(order, p.order.data(), n * sizeof(uint32_t));
+    if (order && p.n_pad) std::memcpy(order, p.order.data(), p.n_pad * sizeof(uint32_t));
     if (plan_row_ptr) std::memcpy(plan_row_ptr, p.row_ptr.data(), p.row_ptr.size() * sizeof(uint64_t));
     if (plan_src && !p.src.empty()) std::memcpy(plan_src, p.src.data(), p.src.size() * sizeof(uint32_t));
     if (level_begin) std::memcpy(level_begin, p.level_begin.data(), p.level_begin.size() * sizeof(uint64_t));
     return HB_OK;
 }
 
-int hb_debug_merge_pending(hb_ctx *c, hb_ctx *other)
+int hb_debug_exchange(hb_ctx **ctxs, int count, int phase)
 {
-    if (!c || !other) return HB_ERR_INVALID;
-    if (!c->pending_local || !other->pending_local) return fail(c, HB_ERR_INVALID, "both contexts must be between hb_step_local and hb_step_finish");
-    if (c->plan.n_pad != other->plan.n_pad || c->device != other->device) return fail(c, HB_ERR_INVALID, "contexts differ in size or device");
+    if (!ctxs || count < 1 || !ctxs[0]) return HB_ERR_INVALID;
+    hb_ctx *c = ctxs[0];
+    for (int i = 0; i < count; i++) {
+        hb_ctx *o = ctxs[i];
+        if (!o) return fail(c, HB_ERR_INVALID, "NULL context");
+        if (o->plan.n_pad != c->plan.n_pad || o->device != c->device || dest_mode(o) != dest_mode(c))
+            return fail(c, HB_ERR_INVALID, "contexts differ in size, device or partition mode");
+        if (phase == 0 && !o->pending_local)
+            return fail(c, HB_ERR_INVALID, "every context must be between hb_step_local and hb_step_finish");
+        if (dest_mode(c) && (o->opt.rank != i || o->opt.world_size != count))
+            return fail(c, HB_ERR_INVALID, "destination partition: ctxs[i] must be rank i of `count`");
+    }
     int rc = set_device(c);
     if (rc) return rc;
-    HB_HIP(hipStreamSynchronize(other->stream));
-    HB_HIP(hipStreamSynchronize(c->stream));
-    const uint64_t count4 = c->plan.n_pad * 4;
-    if (count4) {
-        hipLaunchKernelGGL(hbk::merge_max_kernel, dim3(2048), dim3(256), 0, c->stream, c->d_regs[c->cur ^ 1],
-                           (const uint4 *)other->d_regs[other->cur ^ 1], count4);
-        HB_HIP(hipGetLastError());
+    for (int i = 0; i < count; i++) HB_HIP(hipStreamSynchronize(ctxs[i]->stream));
+    const Plan &p = c->plan;
+    const uint64_t S = c->slice_rows;
+    if (phase == 1) {
+        // what hb_finish's ncclAllGather of the Kahan-sum slices does
+        for (int i = 0; i < count; i++)
+            for (int j = 0; j < count; j++)
+                if (i != j && S)
+                    HB_HIP(hipMemcpyAsync(ctxs[i]->d_ksum + (uint64_t)j * S, ctxs[j]->d_ksum + (uint64_t)j * S, S * sizeof(double),
+                                          hipMemcpyDeviceToDevice, c->stream));
+        HB_HIP(hipStreamSynchronize(c->stream));
+        return HB_OK;
+    }
+    if (!dest_mode(c)) {
+        // all-reduce(max) of the pending counters: fold everything into ctxs[0], then copy out
+        const uint64_t count4 = p.n_pad * 4;
+        for (int i = 1; i < count && count4; i++) {
+            hipLaunchKernelGGL(hbk::merge_max_kernel, dim3(2048), dim3(256), 0, c->stream, c->d_regs[c->cur ^ 1],
+                               (const uint4 *)ctxs[i]->d_regs[ctxs[i]->cur ^ 1], count4);
+            HB_HIP(hipGetLastError());
+        }
+        for (int i = 1; i < count && count4; i++)
+            HB_HIP(hipMemcpyAsync(ctxs[i]->d_regs[ctxs[i]->cur ^ 1], c->d_regs[c->cur ^ 1], count4 * 16, hipMemcpyDeviceToDevice, c->stream));
+    } else {
+        // all-gather of the owned slices (counters, changed bits) + sum of the changed counts
+        unsigned long long total = 0;
+        std::vector<unsigned long long> cnt(count, 0);
+        for (int i = 0; i < count; i++) {
+            HB_HIP(hipMemcpyAsync(&cnt[i], ctxs[i]->d_counters + 4 * ctxs[i]->t, sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+        }
+        HB_HIP(hipStreamSynchronize(c->stream));
+        for (int i = 0; i < count; i++) total += cnt[i];
+        for (int i = 0; i < count; i++) {
+            hb_ctx *d = ctxs[i];
+            for (int j = 0; j < count; j++) {
+                if (i == j || !S) continue;
+                hb_ctx *o = ctxs[j];
+                HB_HIP(hipMemcpyAsync(d->d_regs[d->cur ^ 1] + (uint64_t)j * S * 4, o->d_regs[o->cur ^ 1] + (uint64_t)j * S * 4, S * 64,
+                                      hipMemcpyDeviceToDevice, c->stream));
+                HB_HIP(hipMemcpyAsync(d->d_bits[d->cur ^ 1] + (uint64_t)j * (S / 32), o->d_bits[o->cur ^ 1] + (uint64_t)j * (S / 32), S / 8,
+                                      hipMemcpyDeviceToDevice, c->stream));
+            }
+            HB_HIP(hipMemcpyAsync(d->d_counters + 4 * d->t, &total, sizeof(unsigned long long), hipMemcpyHostToDevice, c->stream));
+        }
     }
     HB_HIP(hipStreamSynchronize(c->stream));
     return HB_OK;

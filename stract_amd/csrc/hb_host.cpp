@@ -156,6 +156,25 @@ std::string ingest_edges(const hb_u128 *node_ids, uint64_t n_in, const hb_edge *
     return "";
 }
 
+// destination partition: rank `rank` keeps the in-edges of the rows with sid % world == rank only
+void keep_owned_rows(DenseGraph *g, uint64_t world, uint64_t rank)
+{
+    const uint64_t n = g->ids.size();
+    if (world <= 1 || n == 0) return;
+    uint64_t w = 0;
+    std::vector<uint64_t> rp(n + 1, 0);
+    for (uint64_t v = 0; v < n; v++) {
+        rp[v] = w;
+        if (v % world != rank) continue;
+        const uint64_t b = g->row_ptr[v], e = g->row_ptr[v + 1];
+        if (w != b) std::memmove(g->src.data() + w, g->src.data() + b, (e - b) * sizeof(uint32_t));
+        w += e - b;
+    }
+    rp[n] = w;
+    g->src.resize(w);
+    g->row_ptr.swap(rp);
+}
+
 std::string check_dense(const hb_u128 *ids, uint64_t n, const uint64_t *row_ptr, const uint32_t *src,
                         uint64_t m)
 {
@@ -206,43 +225,67 @@ std::string build_plan(uint64_t n, const uint64_t *row_ptr, const uint32_t *src,
     if (chunk > 4096) chunk = 4096;
     if (tune.direct_max == 0 || tune.direct_max > chunk) tune.direct_max = chunk;
     if (tune.minc == 0) tune.minc = 16;
+    const uint64_t world = tune.world > 1 ? tune.world : 1;
     p->n = n;
-    p->n_pad = (n + kRowAlign - 1) / kRowAlign * kRowAlign;
+    // one contiguous slice of rows per owner (destination partition: owner(sid) = sid % world),
+    // every slice padded to the same multiple of kRowAlign so that slices can be all-gathered
+    const uint64_t slice = ((n + world - 1) / world + kRowAlign - 1) / kRowAlign * kRowAlign;
+    p->slice = slice;
+    p->n_pad = slice * world;
     p->chunk = chunk;
     p->m_eff = n ? row_ptr[n] : 0;
-    p->order.resize(n);
+    p->order.assign(p->n_pad, kNone);
     p->dev_of.resize(n);
     p->level_begin.clear();
+    const uint64_t n_pad = p->n_pad;
+    // hotness rank of a device position: position j of every slice is equally hot
+    auto hot_rank = [&](uint32_t idx) -> uint32_t { return (uint32_t)(((uint64_t)idx % slice) * world + (uint64_t)idx / slice); };
+    auto from_hot = [&](uint32_t hr) -> uint32_t { return (uint32_t)(((uint64_t)hr % world) * slice + (uint64_t)hr / world); };
     try {
-        // ---- device order
+        // ---- device order: inside each owner's slice by descending (global) out-degree
         if (reorder && n) {
-            std::vector<uint64_t> keys(n);
+            std::vector<std::pair<uint64_t, uint32_t>> kv(n);
 #pragma omp parallel for schedule(static)
             for (int64_t s = 0; s < (int64_t)n; s++)
-                keys[s] = ((uint64_t)(0xFFFFFFFFu - out_degree[s]) << 32) | (uint64_t)s;
-            HB_SORT(keys.begin(), keys.end());
-#pragma omp parallel for schedule(static)
-            for (int64_t d = 0; d < (int64_t)n; d++) p->order[d] = (uint32_t)keys[d];
+                kv[s] = {(((uint64_t)s % world) << 32) | (uint64_t)(0xFFFFFFFFu - out_degree[s]), (uint32_t)s};
+            HB_SORT(kv.begin(), kv.end());
+            uint64_t pos = 0, cur_owner = 0;
+            for (uint64_t i = 0; i < n; i++) {
+                const uint64_t owner = kv[i].first >> 32;
+                if (owner != cur_owner) {
+                    cur_owner = owner;
+                    pos = owner * slice;
+                }
+                p->order[pos++] = kv[i].second;
+            }
         } else {
-            std::iota(p->order.begin(), p->order.end(), 0u);
+            std::vector<uint64_t> fill(world, 0);
+            for (uint64_t s = 0; s < n; s++) {
+                const uint64_t owner = s % world;
+                p->order[owner * slice + fill[owner]++] = (uint32_t)s;
+            }
         }
 #pragma omp parallel for schedule(static)
-        for (int64_t d = 0; d < (int64_t)n; d++) p->dev_of[p->order[d]] = (uint32_t)d;
+        for (int64_t d = 0; d < (int64_t)n_pad; d++)
+            if (p->order[d] != kNone) p->dev_of[p->order[d]] = (uint32_t)d;
 
-        // ---- rows in device order, sources relabelled and sorted
-        std::vector<uint64_t> rp(n + 1, 0);
-        for (uint64_t d = 0; d < n; d++) {
+        // ---- rows in device order; sources relabelled to hotness ranks and sorted (hottest first)
+        std::vector<uint64_t> rp(n_pad + 1, 0);
+        for (uint64_t d = 0; d < n_pad; d++) {
             uint32_t s = p->order[d];
-            rp[d + 1] = rp[d] + (row_ptr[s + 1] - row_ptr[s]);
+            rp[d + 1] = rp[d] + (s == kNone ? 0 : (row_ptr[s + 1] - row_ptr[s]));
         }
         std::vector<uint32_t> rs(p->m_eff);
 #pragma omp parallel for schedule(dynamic, 1024)
-        for (int64_t d = 0; d < (int64_t)n; d++) {
+        for (int64_t d = 0; d < (int64_t)n_pad; d++) {
             uint32_t s = p->order[d];
+            if (s == kNone) continue;
             uint64_t b = row_ptr[s], e = row_ptr[s + 1], o = rp[d];
-            for (uint64_t k = b; k < e; k++) rs[o + (k - b)] = p->dev_of[src[k]];
+            for (uint64_t k = b; k < e; k++) rs[o + (k - b)] = hot_rank(p->dev_of[src[k]]);
             std::sort(rs.begin() + o, rs.begin() + o + (e - b));
         }
+        // from here on `rs` holds hotness ranks; they are mapped back to device positions when the
+        // lists are emitted (from_hot), so band_of() below works on ranks
 
         // ---- hub splitting, level by level
         // Level 1: a hub row's (ascending = hottest-first) source list is cut into chunks of
@@ -255,7 +298,7 @@ std::string build_plan(uint64_t n, const uint64_t *row_ptr, const uint32_t *src,
         std::vector<uint64_t> vrow_ptr; // offsets of virtual rows' lists in vsrc
         std::vector<uint32_t> vsrc;
         vrow_ptr.push_back(0);
-        std::vector<uint8_t> is_split(n, 0);
+        std::vector<uint8_t> is_split(n_pad, 0);
         uint64_t next_vid = p->n_pad;
         p->level_begin.push_back(next_vid);
         auto band_of = [&](uint32_t idx) -> uint32_t {
@@ -267,7 +310,7 @@ std::string build_plan(uint64_t n, const uint64_t *row_ptr, const uint32_t *src,
         std::vector<uint32_t> hub_rows;          // split rows, ascending
         std::vector<uint64_t> hub_first;         // first chunk (creation order) of each split row, +1 sentinel
         const uint32_t minc = std::max<uint32_t>(1, std::min(tune.minc, chunk));
-        for (uint64_t d = 0; d < n; d++) {
+        for (uint64_t d = 0; d < n_pad; d++) {
             const uint64_t b = rp[d], e = rp[d + 1];
             if (e - b <= tune.direct_max) continue;
             is_split[d] = 1;
@@ -300,7 +343,7 @@ std::string build_plan(uint64_t n, const uint64_t *row_ptr, const uint32_t *src,
         for (size_t k = 0; k < corder.size(); k++) {
             const Chunk &c = chunks[corder[k]];
             vid_of[corder[k]] = (uint32_t)(next_vid + k);
-            vsrc.insert(vsrc.end(), rs.begin() + c.beg, rs.begin() + c.beg + c.len);
+            for (uint64_t i = 0; i < c.len; i++) vsrc.push_back(from_hot(rs[c.beg + i]));
             vrow_ptr.push_back(vsrc.size());
         }
         next_vid += chunks.size();
@@ -354,29 +397,29 @@ std::string build_plan(uint64_t n, const uint64_t *row_ptr, const uint32_t *src,
         p->nv = next_vid - p->n_pad;
         if (next_vid >= (uint64_t)kNone) return "row id space exhausted (n + virtual rows >= 2^32 - 1)";
         // hub index of a split row (for the assembly below)
-        std::vector<uint32_t> hub_index(n, 0);
+        std::vector<uint32_t> hub_index(n_pad, 0);
         for (size_t h = 0; h < hub_rows.size(); h++) hub_index[hub_rows[h]] = (uint32_t)h;
 
         // ---- assemble: real rows [0, n_pad), then virtual rows
         const uint64_t rows_total = p->n_pad + p->nv;
         p->row_ptr.assign(rows_total + 1, 0);
         uint64_t total = 0;
-        for (uint64_t d = 0; d < n; d++) {
+        for (uint64_t d = 0; d < n_pad; d++) {
             p->row_ptr[d] = total;
             total += is_split[d] ? (lptr[hub_index[d] + 1] - lptr[hub_index[d]]) : (rp[d + 1] - rp[d]);
         }
-        for (uint64_t d = n; d <= p->n_pad; d++) p->row_ptr[d] = total;
+        p->row_ptr[n_pad] = total;
         const uint64_t real_total = total;
         for (uint64_t k = 0; k < p->nv; k++) p->row_ptr[p->n_pad + k + 1] = real_total + vrow_ptr[k + 1];
         p->src.resize(real_total + vsrc.size());
 #pragma omp parallel for schedule(dynamic, 4096)
-        for (int64_t d = 0; d < (int64_t)n; d++) {
+        for (int64_t d = 0; d < (int64_t)n_pad; d++) {
             uint64_t o = p->row_ptr[d];
             if (is_split[d]) {
                 const uint64_t b = lptr[hub_index[d]], e = lptr[hub_index[d] + 1];
                 std::memcpy(p->src.data() + o, lids.data() + b, (e - b) * sizeof(uint32_t));
             } else {
-                std::memcpy(p->src.data() + o, rs.data() + rp[d], (rp[d + 1] - rp[d]) * sizeof(uint32_t));
+                for (uint64_t k = rp[d]; k < rp[d + 1]; k++) p->src[o + (k - rp[d])] = from_hot(rs[k]);
             }
         }
         if (!vsrc.empty()) std::memcpy(p->src.data() + real_total, vsrc.data(), vsrc.size() * sizeof(uint32_t));

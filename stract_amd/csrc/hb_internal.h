@@ -32,11 +32,12 @@ struct DenseGraph {
 // Device work layout produced by the planner.
 struct Plan {
     uint64_t n = 0;          // real nodes
-    uint64_t n_pad = 0;      // round_up(n, kRowAlign): virtual row ids start here
+    uint64_t n_pad = 0;      // world * slice: virtual row ids start here
+    uint64_t slice = 0;      // rows per owner slice (multiple of kRowAlign); == n_pad when world == 1
     uint64_t nv = 0;         // virtual rows (incl. padding rows)
     uint64_t m_eff = 0;      // real edges
     uint32_t chunk = kDefaultChunk;
-    std::vector<uint32_t> order;      // device index -> sid
+    std::vector<uint32_t> order;      // device index -> sid (n_pad entries, kNone = padding row)
     std::vector<uint32_t> dev_of;     // sid -> device index
     std::vector<uint64_t> row_ptr;    // (n_pad + nv) + 1 offsets into src
     std::vector<uint32_t> src;        // device indices (real < n_pad <= virtual ids)
@@ -49,6 +50,8 @@ struct PlanTune {
     uint32_t band_w = 1u << 16;     // hottest band of the source index space, in counters (0 = no banding)
     uint32_t minc = 16;             // a band cut needs at least this many sources in the chunk
     uint32_t direct_max = 0;        // rows with at most this many sources are not split (0 = chunk)
+    uint32_t world = 1;             // destination partition: rows are laid out as `world` equal slices,
+                                    // slice g = the nodes with sid % world == g
 };
 
 // --- hb_host.cpp ---------------------------------------------------------------------
@@ -56,6 +59,7 @@ struct PlanTune {
 // (store.rs:313), then rel-flag filter (harmonic.rs:131).  Returns "" or an error text.
 std::string ingest_edges(const hb_u128 *node_ids, uint64_t n, const hb_edge *edges, uint64_t m,
                          DenseGraph *out);
+void keep_owned_rows(DenseGraph *g, uint64_t world, uint64_t rank);
 std::string check_dense(const hb_u128 *sorted_ids, uint64_t n, const uint64_t *row_ptr,
                         const uint32_t *src, uint64_t m);
 // out_degree[sid] over the local edges.

@@ -699,7 +699,7 @@ __global__ __launch_bounds__(256) void epilogue_kernel(const PassParams p)
 // ---- initialisation: counter = HLL::default(); add_u128(id) (harmonic.rs:60-66) ----------
 // HyperLogLog::add, hyperloglog.rs:4385-4396 with FastHasher (:4311-4313); only the low 64
 // bits of the id are hashed (:4398-4400).
-__global__ __launch_bounds__(256) void init_kernel(const uint64_t *id_low, uint64_t n, uint64_t n_pad, uint4 *a,
+__global__ __launch_bounds__(256) void init_kernel(const uint64_t *id_low, const uint32_t *sid_of, uint64_t n_pad, uint4 *a,
                                                    uint4 *b, double *ksum, double *kerr, uint64_t *size,
                                                    uint32_t *bits, uint32_t *kdirty, const double *raw,
                                                    const double *bias, const uint8_t *lc)
@@ -708,8 +708,9 @@ __global__ __launch_bounds__(256) void init_kernel(const uint64_t *id_low, uint6
     const uint64_t row = t >> 2;
     const int q = (int)(t & 3);
     if (row >= n_pad) return; // n_pad is a multiple of 64, so whole quads/waves exit together
+    const bool real = sid_of[row] != kNone; // padding rows: all-zero counter, never changed
     uint4 v = make_uint4(0, 0, 0, 0);
-    if (row < n) {
+    if (real) {
         const uint64_t hash = id_low[row] * 11400714819323198549ull;
         const uint32_t j = (uint32_t)(hash >> 58);
         const uint64_t w = hash << 6;
@@ -727,14 +728,13 @@ __global__ __launch_bounds__(256) void init_kernel(const uint64_t *id_low, uint6
     if (q == 0) {
         ksum[row] = 0.0;
         kerr[row] = 0.0;
-        size[row] = (row < n) ? sz : 0;
+        size[row] = real ? sz : 0;
     }
-    // every node starts in the changed set (harmonic.rs:221-225)
-    if ((row & 31) == 0 && q == 0) {
-        uint32_t m = 0xFFFFFFFFu;
-        if (row + 32 > n) m = (row >= n) ? 0u : (uint32_t)((1ull << (n - row)) - 1ull);
-        bits[row >> 5] = m;
-        kdirty[row >> 5] = 0;
+    // every node starts in the changed set (harmonic.rs:221-225): 16 rows per wave
+    const uint32_t m16 = pack16(__ballot(real));
+    if ((threadIdx.x & 63) == 0) {
+        ((uint16_t *)bits)[row >> 4] = (uint16_t)m16;
+        ((uint16_t *)kdirty)[row >> 4] = 0;
     }
 }
 

@@ -52,6 +52,33 @@ def partition_dense(row_ptr, src, rank, world):
     return before.astype(np.uint64), np.ascontiguousarray(src[mine])
 
 
+def partition_dense_by_dest(row_ptr, src, rank, world):
+    """Destination partition (HB_FLAG_DEST_PARTITION): rank r gets ALL in-edges of the nodes whose
+    index in ascending-NodeID order is r mod world, nothing else.  Returns (row_ptr, src) over ALL rows."""
+    if world <= 1:
+        return row_ptr, src
+    rp = row_ptr.astype(np.int64)
+    deg = np.diff(rp)
+    mine = (np.arange(len(deg)) % world) == rank
+    keep_deg = np.where(mine, deg, 0)
+    out_rp = np.zeros(len(rp), dtype=np.uint64)
+    np.cumsum(keep_deg, out=out_rp[1:])
+    # edge mask: edges of owned rows
+    edge_owner_row = np.repeat(mine, deg)
+    return out_rp, np.ascontiguousarray(src[edge_owner_row])
+
+
+def dest_owner_of_edges(edges, sorted_ids, world):
+    """Owner rank of each raw SmallEdge record under the destination partition: the rank of its `to`
+    id in the ascending node list, mod world (records may also simply be given to every rank: the
+    library ignores records whose destination it does not own)."""
+    to = edges["to"]
+    key_ids = sorted_ids["hi"].astype(object) * (1 << 64) + sorted_ids["lo"].astype(object)
+    key_to = to["hi"].astype(object) * (1 << 64) + to["lo"].astype(object)
+    pos = np.searchsorted(key_ids, key_to)
+    return (pos % world).astype(np.int64)
+
+
 def torch_unique_id(rank, world):
     """Distribute rank 0's ncclUniqueId with torch.distributed (any backend)."""
     import torch

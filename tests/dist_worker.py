@@ -17,16 +17,30 @@ def main():
     from stract_amd import dist, synth
 
     scale, m, out_dir = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3]
+    mode = sys.argv[4] if len(sys.argv) > 4 else "edge"
     td.init_process_group("gloo")
     rank, world = td.get_rank(), td.get_world_size()
     g = synth.RmatGraph(scale, m, threads=1)
-    rp, src = dist.partition_dense(g.row_ptr, g.src, rank, world)
+    split = dist.partition_dense_by_dest if mode == "dest" else dist.partition_dense
+    rp, src = split(g.row_ptr, g.src, rank, world)
     o = hbo.Dense(g.id_low64(), rp, src, threads=1)
     has, passes = True, 0
     while has:
         o.step_local(hbo.FRONTIER)
         pend = torch.from_numpy(o.pending())
-        td.all_reduce(pend, op=td.ReduceOp.MAX)  # in place on the oracle's pending counters
+        if mode == "dest":
+            # all-gather of the owned rows (rank r owns the rows r, r + world, ...), padded to equal length
+            per = (g.n + world - 1) // world
+            mine = torch.zeros((per, 64), dtype=torch.uint8)
+            own = pend[rank::world]
+            mine[:len(own)] = own
+            parts = [torch.zeros_like(mine) for _ in range(world)]
+            td.all_gather(parts, mine)
+            for r in range(world):
+                cnt = len(range(r, g.n, world))
+                pend[r::world] = parts[r][:cnt]
+        else:
+            td.all_reduce(pend, op=td.ReduceOp.MAX)  # in place on the oracle's pending counters
         has, _ = o.step_finish(hbo.FRONTIER)
         passes += 1
     vals, keep, k = o.finish()

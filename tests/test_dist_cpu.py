@@ -1,4 +1,5 @@
-"""world_size-2 CPU test of the edge-partitioned algorithm with the
+"""world_size-2 CPU tests of the two multi-GPU decompositions (edge partition + all-reduce(max);
+destination partition + all-gather of the owned rows).  Edge-partitioned algorithm with the
 `gloo` backend: each rank pulls over its own edge subset (oracle arithmetic), the pending
 counters are all-reduced with MAX, every rank finishes the pass; the result must be
 bit-identical to the single-process run.  This is the decomposition the GPU path uses
@@ -22,7 +23,11 @@ def _free_port():
     return p
 
 
-def test_edge_partition_allreduce_max_is_exact(tmp_path):
+import pytest
+
+
+@pytest.mark.parametrize("mode", ["edge", "dest"])
+def test_partitioned_pass_is_exact(tmp_path, mode):
     from oracle import hbo
     from stract_amd import synth
 
@@ -30,7 +35,7 @@ def test_edge_partition_allreduce_max_is_exact(tmp_path):
     env = dict(os.environ, OMP_NUM_THREADS="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
-           os.path.join(ROOT, "tests", "dist_worker.py"), str(scale), str(m), str(tmp_path)]
+           os.path.join(ROOT, "tests", "dist_worker.py"), str(scale), str(m), str(tmp_path), mode]
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     g = synth.RmatGraph(scale, m)

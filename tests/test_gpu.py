@@ -213,17 +213,20 @@ def test_hub_rows_and_isolated_nodes(gpu_ctx_factory):
 
 
 # ---- edge-partition mode ------------------------------------------------------------------------
-@pytest.mark.parametrize("world", [2, 3])
-def test_logical_ranks_on_one_device(gpu_ctx_factory, world):
-    """SURVEY.md §8(e) caveat: R logical ranks on one device, the all-reduce(max) emulated by
-    hb_debug_merge_pending; every rank must reproduce the single-GPU result bit for bit."""
+@pytest.mark.parametrize("world,mode", [(2, "edge"), (3, "edge"), (2, "dest"), (3, "dest"), (4, "dest")])
+def test_logical_ranks_on_one_device(gpu_ctx_factory, world, mode):
+    """SURVEY.md §8(e) caveat: R logical ranks on one device, the collective emulated by
+    hb_debug_exchange (edge partition: all-reduce(max); destination partition: all-gather of the
+    owned slices); every rank must reproduce the single-GPU result bit for bit."""
     g = synth.RmatGraph(12, 40_000)
     o, T, vals, keep, k = _oracle_dense(g.ids, g.row_ptr, g.src)
+    flags = _lib.HB_FLAG_NO_RCCL | (_lib.HB_FLAG_DEST_PARTITION if mode == "dest" else 0)
+    split = dist.partition_dense_by_dest if mode == "dest" else dist.partition_dense
     ctxs = []
     try:
         for r in range(world):
-            c = gpu_ctx_factory(rank=r, world_size=world, flags=_lib.HB_FLAG_NO_RCCL, chunk=16)
-            rp, src = dist.partition_dense(g.row_ptr, g.src, r, world)
+            c = gpu_ctx_factory(rank=r, world_size=world, flags=flags, chunk=16, tune=(0, 0, 0, 7, 4))
+            rp, src = split(g.row_ptr, g.src, r, world)
             c.load_dense(g.ids, rp, src)
             c.begin()
             ctxs.append(c)
@@ -231,19 +234,51 @@ def test_logical_ranks_on_one_device(gpu_ctx_factory, world):
         while has:
             for c in ctxs:
                 c.step_local()
+            _lib.Context.exchange(ctxs, 0)
+            flags_out = [c.step_finish() for c in ctxs]
+            assert len(set(flags_out)) == 1
+            has = flags_out[0]
             for c in ctxs[1:]:
-                ctxs[0].merge_pending(c)
-            for c in ctxs[1:]:
-                c.merge_pending(ctxs[0])
-            flags = [c.step_finish() for c in ctxs]
-            assert len(set(flags)) == 1
-            has = flags[0]
+                assert np.array_equal(c.registers(), ctxs[0].registers())
             t += 1
         assert t == T
+        assert np.array_equal(ctxs[0].registers(), o.registers())
+        _lib.Context.exchange(ctxs, 1)
         for c in ctxs:
             c.finish()
-            assert np.array_equal(c.registers(), o.registers())
             _check_final(c, g.ids, T, vals, keep, c.stats())
+    finally:
+        for c in ctxs:
+            c.close()
+
+
+def test_dest_partition_ignores_foreign_records(gpu_ctx_factory):
+    """Destination partition with raw records: every rank may be handed ALL records; it keeps the
+    in-edges of the nodes it owns (rank of the id in ascending order mod world)."""
+    g = synth.RmatGraph(11, 12_000)
+    e = g.edges(salt=1, salt_seed=9)
+    fids, fvals, fst = hbo.faithful_run(e)
+    world = 2
+    flags = _lib.HB_FLAG_NO_RCCL | _lib.HB_FLAG_DEST_PARTITION
+    ctxs = []
+    try:
+        for r in range(world):
+            c = gpu_ctx_factory(rank=r, world_size=world, flags=flags)
+            c.load_edges(e)
+            c.begin()
+            ctxs.append(c)
+        has = True
+        while has:
+            for c in ctxs:
+                c.step_local()
+            _lib.Context.exchange(ctxs, 0)
+            has = [c.step_finish() for c in ctxs][0]
+        _lib.Context.exchange(ctxs, 1)
+        for c in ctxs:
+            c.finish()
+            ids, vals = c.results()
+            assert np.array_equal(ids, fids) and np.array_equal(vals.view(np.uint64), fvals.view(np.uint64))
+        assert sum(c.stats()["m_eff"] for c in ctxs) == fst["m_eff"]
     finally:
         for c in ctxs:
             c.close()

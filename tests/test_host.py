@@ -154,6 +154,34 @@ def test_planner_invariants(chunk, flags, tune):
         assert sorted(_expand(plan, d, n_pad)) == want        # the tree covers exactly the row's in-edges
 
 
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_planner_owner_slices(world):
+    """Destination partition layout: `world` equal slices, slice g = the sids with sid % world == g in
+    descending out-degree order; the trees still cover exactly every row's in-edges."""
+    g = synth.RmatGraph(11, 15_000)
+    plan = _lib.host_plan(g.row_ptr, g.src, 0, 16, (0, 0, 0, 6, 4, 0, 0, world))
+    n, n_pad, S = g.n, plan["n_pad"], plan["slice"]
+    order = plan["order"].astype(np.int64)
+    assert n_pad == S * world and S % 64 == 0 and len(order) == n_pad
+    real = order != 0xFFFFFFFF
+    assert sorted(order[real].tolist()) == list(range(n))
+    outdeg = np.bincount(g.src, minlength=n)
+    for r in range(world):
+        sl = order[r * S:(r + 1) * S]
+        sids = sl[sl != 0xFFFFFFFF]
+        assert np.all(sids % world == r)
+        assert np.all(sl[len(sids):] == 0xFFFFFFFF)          # padding rows at the end of each slice
+        assert np.all(np.diff(outdeg[sids]) <= 0)
+    dev_of = np.zeros(n, np.int64)
+    dev_of[order[real]] = np.nonzero(real)[0]
+    for d in np.nonzero(real)[0][::7]:
+        sid = order[d]
+        want = sorted(dev_of[g.src[int(g.row_ptr[sid]):int(g.row_ptr[sid + 1])]].tolist())
+        assert sorted(_expand(plan, int(d), n_pad)) == want
+    for d in np.nonzero(~real)[0]:
+        assert plan["row_ptr"][d] == plan["row_ptr"][d + 1]
+
+
 def test_planner_deep_hub():
     # one destination with 5000 in-edges and chunk 4 needs a 6-level tree
     n = 5001
@@ -187,3 +215,17 @@ def test_partition_helpers():
             assert np.array_equal(s[int(rp[v]):int(rp[v + 1])], full[idx % 3 == r])
         tot.append(len(s))
     assert sum(tot) == g.m
+    # destination partition: rank r holds exactly the rows r mod world, complete
+    tot = 0
+    for r in range(3):
+        rp, s = dist.partition_dense_by_dest(g.row_ptr, g.src, r, 3)
+        assert rp[0] == 0 and rp[-1] == len(s)
+        for v in range(0, g.n, 97):
+            mine = s[int(rp[v]):int(rp[v + 1])]
+            full = g.src[int(g.row_ptr[v]):int(g.row_ptr[v + 1])]
+            assert np.array_equal(mine, full if v % 3 == r else full[:0])
+        tot += len(s)
+    assert tot == g.m
+    ids = g.ids
+    owner = dist.dest_owner_of_edges(e, np.unique(np.concatenate([e["from"], e["to"]])), 3)
+    assert owner.min() >= 0 and owner.max() <= 2
