@@ -204,26 +204,43 @@ hbo_dense *hbo_dense_create(uint64_t n, const uint64_t *id_low64, const uint64_t
     s->threads = threads;
     s->bsearch = HBO_BSEARCH_RUST_1_82;
     size_t nn = n ? n : 1;
-    s->old_regs = (uint8_t *)calloc(nn, 64);
-    s->new_regs = (uint8_t *)calloc(nn, 64);
+    /* malloc + parallel first touch below: on a multi-socket host the pages of the big arrays
+     * end up spread over the NUMA nodes instead of all on the creating thread's node */
+    s->old_regs = (uint8_t *)malloc(nn * 64);
+    s->new_regs = (uint8_t *)malloc(nn * 64);
     s->changed_prev = (uint8_t *)malloc(nn);
-    s->changed_next = (uint8_t *)calloc(nn, 1);
-    s->ksum = (double *)calloc(nn, sizeof(double));
-    s->kerr = (double *)calloc(nn, sizeof(double));
-    s->size_old = (uint64_t *)calloc(nn, sizeof(uint64_t));
+    s->changed_next = (uint8_t *)malloc(nn);
+    s->ksum = (double *)malloc(nn * sizeof(double));
+    s->kerr = (double *)malloc(nn * sizeof(double));
+    s->size_old = (uint64_t *)malloc(nn * sizeof(uint64_t));
     if (!s->old_regs || !s->new_regs || !s->changed_prev || !s->changed_next || !s->ksum ||
         !s->kerr || !s->size_old) {
         hbo_dense_destroy(s);
         return NULL;
     }
-    /* initialize (harmonic.rs:53-73): counter = HLL::default(); add_u128(id); new = old.clone() */
-    for (uint64_t v = 0; v < n; v++) {
-        hbo_hll_add(s->old_regs + 64 * v, id_low64[v]);
-        s->size_old[v] = hbo_hll_size_ex(s->old_regs + 64 * v, s->bsearch, NULL, NULL);
+    /* initialize (harmonic.rs:53-73): counter = HLL::default(); add_u128(id); new = old.clone();
+     * harmonic.rs:221-225: every node starts in the changed set */
+    if (n == 0) {
+        memset(s->old_regs, 0, 64);
+        memset(s->new_regs, 0, 64);
+        s->changed_prev[0] = 1; s->changed_next[0] = 0;
+        s->ksum[0] = s->kerr[0] = 0.0; s->size_old[0] = 0;
     }
-    memcpy(s->new_regs, s->old_regs, n * 64);
-    /* harmonic.rs:221-225: every node starts in the changed set */
-    memset(s->changed_prev, 1, nn);
+#ifdef _OPENMP
+    int nt0 = threads > 0 ? threads : omp_get_max_threads();
+#pragma omp parallel for schedule(static) num_threads(nt0)
+#endif
+    for (int64_t vi = 0; vi < (int64_t)n; vi++) {
+        const uint64_t v = (uint64_t)vi;
+        memset(s->old_regs + 64 * v, 0, 64);
+        hbo_hll_add(s->old_regs + 64 * v, id_low64[v]);
+        memcpy(s->new_regs + 64 * v, s->old_regs + 64 * v, 64);
+        s->size_old[v] = hbo_hll_size_ex(s->old_regs + 64 * v, s->bsearch, NULL, NULL);
+        s->changed_prev[v] = 1;
+        s->changed_next[v] = 0;
+        s->ksum[v] = 0.0;
+        s->kerr[v] = 0.0;
+    }
     s->has_changes = 1; /* harmonic.rs:232 */
     return s;
 }
@@ -263,13 +280,15 @@ void hbo_dense_step_local(hbo_dense *s, int flags)
         memcpy(acc, ov, 64); /* new[v] == old[v] on entry (Counters::step, harmonic.rs:210-212) */
         uint64_t act = 0;
         /* The merge is a per-register max, so edge order is irrelevant (App. A-5). */
-        for (uint64_t e = s->row_ptr[v]; e < s->row_ptr[v + 1]; e++) {
+        const uint64_t e_end = s->row_ptr[v + 1];
+        for (uint64_t e = s->row_ptr[v]; e < e_end; e++) {
             uint32_t u = s->src[e];
+            /* the gathers are random 64-byte reads: keep a few cache misses in flight */
+            if (e + 8 < e_end) __builtin_prefetch(s->old_regs + 64 * (uint64_t)s->src[e + 8], 0, 0);
             if (s->changed_prev[u]) act++;
             else if (frontier) continue; /* bloom / exact set: results-inert (App. C-1) */
             const uint8_t *ou = s->old_regs + 64 * (uint64_t)u;
-            for (int i = 0; i < 64; i++)
-                if (ou[i] > acc[i]) acc[i] = ou[i];
+            for (int i = 0; i < 64; i++) acc[i] = ou[i] > acc[i] ? ou[i] : acc[i]; /* -O3: pmaxub */
         }
         memcpy(s->new_regs + 64 * v, acc, 64);
         active += act;

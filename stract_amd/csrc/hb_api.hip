@@ -739,6 +739,10 @@ int hb_begin(hb_ctx *c)
     int rc = set_device(c);
     if (rc) return rc;
     const Plan &p = c->plan;
+    {
+        hipError_t stale = hipGetLastError(); // an unchecked failure of an earlier call on this thread
+        if (stale != hipSuccess) return fail(c, HB_ERR_HIP, std::string("stale HIP error before hb_begin: ") + hipGetErrorString(stale));
+    }
     HB_HIP(hipMemsetAsync(c->d_part, 0, std::max<size_t>(p.nv * 64, 256), c->stream));
     HB_HIP(hipMemsetAsync(c->d_bits[0], 0, c->bits_words * 4, c->stream));
     HB_HIP(hipMemsetAsync(c->d_bits[1], 0, c->bits_words * 4, c->stream));
@@ -1050,7 +1054,9 @@ int hb_debug_exchange(hb_ctx **ctxs, int count, int phase)
     const Plan &p = c->plan;
     const uint64_t S = c->slice_rows;
     if (phase == 1) {
-        // what hb_finish's ncclAllGather of the Kahan-sum slices does
+        // what hb_finish's ncclAllGather of the Kahan-sum slices does (edge partition without a
+        // communicator: every logical rank already holds all sums)
+        if (!dest_mode(c)) return HB_OK;
         for (int i = 0; i < count; i++)
             for (int j = 0; j < count; j++)
                 if (i != j && S)

@@ -13,6 +13,8 @@
 #include <algorithm>
 #include <chrono>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <numeric>
 
@@ -202,7 +204,12 @@ void count_out_degree(const uint64_t *row_ptr, const uint32_t *src, uint64_t n, 
 {
     deg->assign(n, 0);
     const uint64_t m = n ? row_ptr[n] : 0;
-    for (uint64_t e = 0; e < m; e++) (*deg)[src[e]]++;
+    uint32_t *d = deg->data();
+#pragma omp parallel for schedule(static)
+    for (int64_t e = 0; e < (int64_t)m; e++) {
+#pragma omp atomic
+        d[src[e]]++;
+    }
 }
 
 // ---------------------------------------------------------------------------------------
@@ -226,6 +233,14 @@ std::string build_plan(uint64_t n, const uint64_t *row_ptr, const uint32_t *src,
     if (tune.direct_max == 0 || tune.direct_max > chunk) tune.direct_max = chunk;
     if (tune.minc == 0) tune.minc = 16;
     const uint64_t world = tune.world > 1 ? tune.world : 1;
+    const bool timing = std::getenv("HB_PLAN_TIMING") != nullptr;
+    double tmark = now_ms();
+    auto lap = [&](const char *what) {
+        if (!timing) return;
+        double t = now_ms();
+        std::fprintf(stderr, "[plan] %-28s %8.1f ms\n", what, t - tmark);
+        tmark = t;
+    };
     p->n = n;
     // one contiguous slice of rows per owner (destination partition: owner(sid) = sid % world),
     // every slice padded to the same multiple of kRowAlign so that slices can be all-gathered
@@ -269,6 +284,7 @@ std::string build_plan(uint64_t n, const uint64_t *row_ptr, const uint32_t *src,
         for (int64_t d = 0; d < (int64_t)n_pad; d++)
             if (p->order[d] != kNone) p->dev_of[p->order[d]] = (uint32_t)d;
 
+        lap("device order");
         // ---- rows in device order; sources relabelled to hotness ranks and sorted (hottest first)
         std::vector<uint64_t> rp(n_pad + 1, 0);
         for (uint64_t d = 0; d < n_pad; d++) {
@@ -284,6 +300,7 @@ std::string build_plan(uint64_t n, const uint64_t *row_ptr, const uint32_t *src,
             for (uint64_t k = b; k < e; k++) rs[o + (k - b)] = hot_rank(p->dev_of[src[k]]);
             std::sort(rs.begin() + o, rs.begin() + o + (e - b));
         }
+        lap("relabel + sort rows");
         // from here on `rs` holds hotness ranks; they are mapped back to device positions when the
         // lists are emitted (from_hot), so band_of() below works on ranks
 
@@ -331,6 +348,7 @@ std::string build_plan(uint64_t n, const uint64_t *row_ptr, const uint32_t *src,
             }
         }
         hub_first.push_back(chunks.size());
+        lap("cut chunks");
         // order: band ascending, longer chunks first inside a band (wave-uniform trip counts)
         std::vector<uint32_t> corder(chunks.size());
         std::iota(corder.begin(), corder.end(), 0u);
@@ -338,15 +356,28 @@ std::string build_plan(uint64_t n, const uint64_t *row_ptr, const uint32_t *src,
             if (chunks[a].key != chunks[b2].key) return chunks[a].key < chunks[b2].key;
             return chunks[a].len > chunks[b2].len;
         });
+        lap("sort chunks");
         std::vector<uint32_t> vid_of(chunks.size());
-        vsrc.reserve(p->m_eff);
-        for (size_t k = 0; k < corder.size(); k++) {
-            const Chunk &c = chunks[corder[k]];
-            vid_of[corder[k]] = (uint32_t)(next_vid + k);
-            for (uint64_t i = 0; i < c.len; i++) vsrc.push_back(from_hot(rs[c.beg + i]));
-            vrow_ptr.push_back(vsrc.size());
+        {
+            // offsets of the level-1 lists in emission (= band) order, then a parallel fill
+            vrow_ptr.resize(chunks.size() + 1);
+            uint64_t off = 0;
+            for (size_t k = 0; k < corder.size(); k++) {
+                vrow_ptr[k] = off;
+                off += chunks[corder[k]].len;
+                vid_of[corder[k]] = (uint32_t)(next_vid + k);
+            }
+            vrow_ptr[chunks.size()] = off;
+            vsrc.resize(off);
+#pragma omp parallel for schedule(static, 4096)
+            for (int64_t k = 0; k < (int64_t)corder.size(); k++) {
+                const Chunk &c = chunks[corder[k]];
+                uint32_t *dst = vsrc.data() + vrow_ptr[k];
+                for (uint64_t i = 0; i < c.len; i++) dst[i] = from_hot(rs[c.beg + i]);
+            }
         }
         next_vid += chunks.size();
+        lap("emit level-1 lists");
         // per split row: the list of virtual ids it currently reads (flat, CSR-like)
         std::vector<uint64_t> lptr(hub_rows.size() + 1, 0);
         std::vector<uint32_t> lids(chunks.size());
@@ -400,6 +431,7 @@ std::string build_plan(uint64_t n, const uint64_t *row_ptr, const uint32_t *src,
         std::vector<uint32_t> hub_index(n_pad, 0);
         for (size_t h = 0; h < hub_rows.size(); h++) hub_index[hub_rows[h]] = (uint32_t)h;
 
+        lap("upper levels");
         // ---- assemble: real rows [0, n_pad), then virtual rows
         const uint64_t rows_total = p->n_pad + p->nv;
         p->row_ptr.assign(rows_total + 1, 0);
@@ -422,6 +454,7 @@ std::string build_plan(uint64_t n, const uint64_t *row_ptr, const uint32_t *src,
                 for (uint64_t k = rp[d]; k < rp[d + 1]; k++) p->src[o + (k - rp[d])] = from_hot(rs[k]);
             }
         }
+        lap("assemble");
         if (!vsrc.empty()) std::memcpy(p->src.data() + real_total, vsrc.data(), vsrc.size() * sizeof(uint32_t));
     } catch (const std::bad_alloc &) {
         return "out of host memory in the planner";
