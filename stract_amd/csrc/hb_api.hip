@@ -57,6 +57,9 @@ struct hb_ctx {
     uint64_t *d_idlow = nullptr;
     uint32_t *d_dev_of = nullptr;
     uint32_t *d_sid_of = nullptr; // device row -> sid, kNone for padding rows
+    uint32_t *d_outdeg = nullptr; // device row -> (global) out-degree
+    uint64_t m_global = 0;        // edges of the whole graph (all ranks)
+    uint64_t last_active = 0;     // out-degree sum of the nodes changed in the previous pass
     unsigned long long *d_counters = nullptr; // max_passes * 4
     double *d_raw = nullptr, *d_bias = nullptr;
     uint8_t *d_lc = nullptr;
@@ -145,6 +148,7 @@ void free_graph_buffers(hb_ctx *c)
     c->d_idlow = nullptr;
     c->d_dev_of = nullptr;
     c->d_sid_of = nullptr;
+    c->d_outdeg = nullptr;
     c->d_counters = nullptr;
     c->d_raw = c->d_bias = nullptr;
     c->d_lc = nullptr;
@@ -249,7 +253,7 @@ int plan_and_upload(hb_ctx *c)
     std::vector<uint32_t> outdeg;
     bool reorder = !(c->opt.flags & HB_FLAG_NO_REORDER);
     if (multi_rank(c) && !c->comm) reorder = false; // logical ranks without a communicator
-    if (reorder) {
+    {
         count_out_degree(c->g.row_ptr.data(), c->g.src.data(), n, &outdeg);
         if (c->comm && n) {
             uint32_t *d_deg = nullptr;
@@ -299,6 +303,7 @@ int plan_and_upload(hb_ctx *c)
     if ((rc = dev_alloc(c, &c->d_idlow, p.n_pad))) return rc;
     if ((rc = dev_alloc(c, &c->d_dev_of, n))) return rc;
     if ((rc = dev_alloc(c, &c->d_sid_of, p.n_pad))) return rc;
+    if ((rc = dev_alloc(c, &c->d_outdeg, p.n_pad))) return rc;
     if ((rc = dev_alloc(c, &c->d_counters, (size_t)c->max_passes * 4))) return rc;
     if ((rc = dev_alloc(c, &c->d_raw, HLL64_TABLE_LEN))) return rc;
     if ((rc = dev_alloc(c, &c->d_bias, HLL64_TABLE_LEN))) return rc;
@@ -324,6 +329,15 @@ int plan_and_upload(hb_ctx *c)
     HB_HIP(hipMemcpyAsync(c->d_idlow, idlow.data(), p.n_pad * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
     if (p.n_pad)
         HB_HIP(hipMemcpyAsync(c->d_sid_of, p.order.data(), p.n_pad * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+    std::vector<uint32_t> outdeg_dev(p.n_pad, 0);
+    c->m_global = 0;
+    for (uint64_t d = 0; d < p.n_pad; d++)
+        if (p.order[d] != kNone) {
+            outdeg_dev[d] = outdeg[p.order[d]];
+            c->m_global += outdeg[p.order[d]];
+        }
+    if (p.n_pad)
+        HB_HIP(hipMemcpyAsync(c->d_outdeg, outdeg_dev.data(), p.n_pad * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
     if (n) HB_HIP(hipMemcpyAsync(c->d_dev_of, p.dev_of.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
     HB_HIP(hipStreamSynchronize(c->stream));
     if ((rc = build_sparse_support(c))) return rc;
@@ -393,6 +407,7 @@ hbk::PassParams make_params(hb_ctx *c)
     pp.kerr = c->d_kerr;
     pp.size = c->d_size;
     pp.counters = c->d_counters + 4 * c->t;
+    pp.outdeg = c->d_outdeg;
     pp.raw = c->d_raw;
     pp.bias = c->d_bias;
     pp.lc = c->d_lc;
@@ -417,12 +432,15 @@ int step_local(hb_ctx *c)
     const Plan &p = c->plan;
     // mode: dense while most nodes still change (the frontier test would only cost), frontier
     // (bitmap) after, sparse (worklists over the transposed graph) for the convergence tail
-    uint32_t thr = c->opt.tune[2] ? c->opt.tune[2] : 25; // percent of nodes changed in the previous pass
-    bool frontier = !(c->opt.flags & HB_FLAG_NO_FRONTIER) && c->t > 0 &&
-                    (c->last_changed * 100ull < (uint64_t)thr * p.n);
-    // sparse when few nodes changed in the previous pass: changed * div < n
-    const uint64_t sparse_div = c->opt.tune[6] ? c->opt.tune[6] : 256;
-    const bool sparse = frontier && c->sparse_ok && (c->last_changed * sparse_div < p.n || c->opt.tune[6] == 1);
+    // A_t = edges whose source changed in the previous pass (= out-degree sum of those nodes, counted by
+    // the previous pass).  dense: every source is gathered (no test); frontier: every index is read and
+    // bit-tested, only active sources are gathered (pays while A_t < ~half of the edges); sparse: only the
+    // work rows that read a changed node are visited at all.
+    const uint32_t thr = c->opt.tune[2] ? c->opt.tune[2] : 50; // frontier when A_t < thr % of the edges
+    const bool frontier = !(c->opt.flags & HB_FLAG_NO_FRONTIER) && c->t > 0 &&
+                          (c->last_active * 100ull < (uint64_t)thr * c->m_global || thr > 100);
+    const uint64_t sparse_div = c->opt.tune[6] ? c->opt.tune[6] : 64; // sparse when A_t * div < edges
+    const bool sparse = frontier && c->sparse_ok && (c->last_active * sparse_div < c->m_global || c->opt.tune[6] == 1);
     c->cur_mode = sparse ? 2 : (frontier ? 1 : 0);
     const bool fused = !unfused(c);
     hbk::PassParams pp = make_params(c);
@@ -505,7 +523,7 @@ int step_finish(hb_ctx *c, int *has_changes)
         HB_NCCL(ncclGroupStart());
         HB_NCCL(ncclAllGather(pp.wr + r * S * 4, pp.wr, S * 64, ncclUint8, c->comm, c->stream));
         HB_NCCL(ncclAllGather(pp.bits_wr + r * (S / 32), pp.bits_wr, S / 32, ncclUint32, c->comm, c->stream));
-        HB_NCCL(ncclAllReduce(pp.counters, pp.counters, 1, ncclUint64, ncclSum, c->comm, c->stream));
+        HB_NCCL(ncclAllReduce(pp.counters, pp.counters, 4, ncclUint64, ncclSum, c->comm, c->stream));
         HB_NCCL(ncclGroupEnd());
         HB_HIP(hipEventRecord(c->ev[3], c->stream));
     }
@@ -523,7 +541,7 @@ int step_finish(hb_ctx *c, int *has_changes)
     hb_pass_stats ps{};
     ps.pass = c->t;
     ps.changed = c->h_counters[0];
-    ps.active_edges = c->h_counters[1];
+    ps.active_edges = (c->opt.flags & HB_FLAG_PASS_STATS) ? c->h_counters[1] : c->last_active; // A_t
     ps.touched = c->h_counters[2];
     ps.mode = c->cur_mode;
     float ms_all = 0.f, ms_main = 0.f;
@@ -535,6 +553,7 @@ int step_finish(hb_ctx *c, int *has_changes)
     c->pstats.push_back(ps);
     // counters.step(); changed_nodes = new_changed_nodes; t += 1 (harmonic.rs:273-275)
     c->last_changed = ps.changed;
+    c->last_active = c->h_counters[3];
     c->has_changes = ps.changed != 0;
     c->cur ^= 1;
     c->t += 1;
@@ -760,6 +779,7 @@ int hb_begin(hb_ctx *c)
     c->cur = 0;
     c->has_changes = true; // harmonic.rs:232
     c->last_changed = p.n;
+    c->last_active = c->m_global;
     c->pending_local = false;
     c->pstats.clear();
     c->begun = true;
@@ -1077,13 +1097,14 @@ int hb_debug_exchange(hb_ctx **ctxs, int count, int phase)
             HB_HIP(hipMemcpyAsync(ctxs[i]->d_regs[ctxs[i]->cur ^ 1], c->d_regs[c->cur ^ 1], count4 * 16, hipMemcpyDeviceToDevice, c->stream));
     } else {
         // all-gather of the owned slices (counters, changed bits) + sum of the changed counts
-        unsigned long long total = 0;
-        std::vector<unsigned long long> cnt(count, 0);
+        unsigned long long total[4] = {0, 0, 0, 0};
+        std::vector<unsigned long long> cnt((size_t)count * 4, 0);
         for (int i = 0; i < count; i++) {
-            HB_HIP(hipMemcpyAsync(&cnt[i], ctxs[i]->d_counters + 4 * ctxs[i]->t, sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+            HB_HIP(hipMemcpyAsync(&cnt[(size_t)i * 4], ctxs[i]->d_counters + 4 * ctxs[i]->t, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
         }
         HB_HIP(hipStreamSynchronize(c->stream));
-        for (int i = 0; i < count; i++) total += cnt[i];
+        for (int i = 0; i < count; i++)
+            for (int k = 0; k < 4; k++) total[k] += cnt[(size_t)i * 4 + k];
         for (int i = 0; i < count; i++) {
             hb_ctx *d = ctxs[i];
             for (int j = 0; j < count; j++) {
@@ -1094,7 +1115,7 @@ int hb_debug_exchange(hb_ctx **ctxs, int count, int phase)
                 HB_HIP(hipMemcpyAsync(d->d_bits[d->cur ^ 1] + (uint64_t)j * (S / 32), o->d_bits[o->cur ^ 1] + (uint64_t)j * (S / 32), S / 8,
                                       hipMemcpyDeviceToDevice, c->stream));
             }
-            HB_HIP(hipMemcpyAsync(d->d_counters + 4 * d->t, &total, sizeof(unsigned long long), hipMemcpyHostToDevice, c->stream));
+            HB_HIP(hipMemcpyAsync(d->d_counters + 4 * d->t, total, 4 * sizeof(unsigned long long), hipMemcpyHostToDevice, c->stream));
         }
     }
     HB_HIP(hipStreamSynchronize(c->stream));

@@ -39,7 +39,9 @@ struct PassParams {
     double *ksum;
     double *kerr;
     uint64_t *size;           // cached size() of rd[row]
-    unsigned long long *counters; // [0] changed rows, [1] active edges, [2] rows processed
+    unsigned long long *counters; // [0] changed rows, [1] active edges, [2] rows processed,
+                                  // [3] out-degree sum of the changed rows = active edges of the NEXT pass
+    const uint32_t *outdeg;   // per node row: (global) out-degree
     const double *raw;        // HLL64_RAW_ESTIMATE (global copy, staged to LDS)
     const double *bias;       // HLL64_BIAS
     const uint8_t *lc;        // linear-counting table, 65 entries (index = zero registers)
@@ -269,7 +271,7 @@ __global__ __launch_bounds__(256) void pass_kernel(const PassParams p)
     const int g = lane >> 2, q = lane & 3;
     const int qshift = lane & ~3;
     const uint64_t ntiles = (p.row_hi - p.row_lo + 63) >> 6;
-    unsigned long long cnt_changed = 0, cnt_active = 0, cnt_rows = 0;
+    unsigned long long cnt_changed = 0, cnt_active = 0, cnt_rows = 0, cnt_out = 0;
 
     for (uint64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const uint64_t row16 = p.row_lo + (tile << 6) + ((uint64_t)wave << 4); // first row of this wave
@@ -386,7 +388,10 @@ __global__ __launch_bounds__(256) void pass_kernel(const PassParams p)
             uint16_t *dst = REAL ? (uint16_t *)p.bits_wr : (uint16_t *)p.bits_rd;
             if (lane == 0 && row16 < p.row_hi) dst[row16 >> 4] = (uint16_t)ch16;
         }
-        if (REAL && FUSED) cnt_changed += __popc(ch16);
+        if (REAL && FUSED) {
+            cnt_changed += __popc(ch16);
+            if (changed && q == 0) cnt_out += p.outdeg[row];
+        }
         if (STATS) cnt_rows += (need && q == 0);
         if (REAL && FUSED) {
             bool err_nz = false;
@@ -411,6 +416,11 @@ __global__ __launch_bounds__(256) void pass_kernel(const PassParams p)
     if (REAL) {
         // cnt_changed is identical in all lanes of the wave (derived from a ballot)
         if (lane == 0 && cnt_changed) atomicAdd(&p.counters[0], cnt_changed);
+        if (FUSED) {
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) cnt_out += __shfl_down(cnt_out, off);
+            if (lane == 0 && cnt_out) atomicAdd(&p.counters[3], cnt_out);
+        }
     }
     if (STATS) {
 #pragma unroll
@@ -535,7 +545,7 @@ __global__ __launch_bounds__(256) void sparse_rows_kernel(const SparseParams sp)
     const uint32_t count = REAL ? sp.counts[1] : sp.counts[2 + sp.level];
     const uint32_t *list = REAL ? sp.list_real : sp.list_virt + (sp.level_begin[sp.level] - p.n_pad);
     const uint32_t nwaves = gridDim.x * 4;
-    unsigned long long cnt_changed = 0;
+    unsigned long long cnt_changed = 0, cnt_out = 0;
     for (uint32_t base = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 16; base < count; base += nwaves * 16) {
         const uint32_t li = base + (uint32_t)g;
         const bool valid = li < count;
@@ -581,7 +591,10 @@ __global__ __launch_bounds__(256) void sparse_rows_kernel(const SparseParams sp)
             const bool self_prev = valid && ((p.bits_rd[row >> 5] >> (row & 31u)) & 1u);
             const bool kd = valid && ((p.kdirty[row >> 5] >> (row & 31u)) & 1u);
             if (valid && (changed || self_prev)) p.wr[row * 4 + q] = accv; // lazy double buffer
-            if (changed && q == 0) atomicOr(&p.bits_wr[row >> 5], bit);
+            if (changed && q == 0) {
+                atomicOr(&p.bits_wr[row >> 5], bit);
+                cnt_out += p.outdeg[row];
+            }
             cnt_changed += __popc(pack16(bal));
             if (valid && (changed || kd)) {
                 const uint64_t sz_old = p.size[row];
@@ -607,7 +620,12 @@ __global__ __launch_bounds__(256) void sparse_rows_kernel(const SparseParams sp)
             }
         }
     }
-    if (REAL && lane == 0 && cnt_changed) atomicAdd(&p.counters[0], cnt_changed);
+    if (REAL) {
+        if (lane == 0 && cnt_changed) atomicAdd(&p.counters[0], cnt_changed);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) cnt_out += __shfl_down(cnt_out, off);
+        if (lane == 0 && cnt_out) atomicAdd(&p.counters[3], cnt_out);
+    }
 }
 
 // ---- transposed work-row graph (built once per load) ------------------------------------------
@@ -655,7 +673,7 @@ __global__ __launch_bounds__(256) void epilogue_kernel(const PassParams p)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int g = lane >> 2, q = lane & 3, qshift = lane & ~3;
     const uint64_t ntiles = (p.row_hi - p.row_lo + 63) >> 6;
-    unsigned long long cnt_changed = 0;
+    unsigned long long cnt_changed = 0, cnt_out = 0;
     for (uint64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const uint64_t row16 = p.row_lo + (tile << 6) + ((uint64_t)wave << 4);
         const uint64_t row = row16 + (uint64_t)g;
@@ -675,6 +693,7 @@ __global__ __launch_bounds__(256) void epilogue_kernel(const PassParams p)
         const uint32_t ch16 = pack16(bal);
         if (lane == 0 && row16 < p.row_hi) ((uint16_t *)p.bits_wr)[row16 >> 4] = (uint16_t)ch16;
         cnt_changed += __popc(ch16);
+        if (changed && q == 0) cnt_out += p.outdeg[row];
         bool err_nz = false;
         const bool mine = valid && row >= p.slice_lo && row < p.slice_hi;
         if (mine && (changed || kd)) {
@@ -694,6 +713,9 @@ __global__ __launch_bounds__(256) void epilogue_kernel(const PassParams p)
         if (lane == 0 && row16 < p.row_hi && (nk16 | kd16)) ((uint16_t *)p.kdirty)[row16 >> 4] = (uint16_t)nk16;
     }
     if (lane == 0 && cnt_changed) atomicAdd(&p.counters[0], cnt_changed);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) cnt_out += __shfl_down(cnt_out, off);
+    if (lane == 0 && cnt_out) atomicAdd(&p.counters[3], cnt_out);
 }
 
 // ---- initialisation: counter = HLL::default(); add_u128(id) (harmonic.rs:60-66) ----------

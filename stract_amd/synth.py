@@ -83,5 +83,5 @@ CONFIGS = {
     "C1": dict(scale=14, m=100_000, label="10k-host / 100k-edge"),
     "C2": dict(scale=21, m=20_000_000, label="1M-host / 20M-edge"),
     "C3": dict(scale=24, m=200_000_000, label="10M-host / 200M-edge"),
-    "C4": dict(scale=27, m=2_000_000_000, label="100M-host / 2B-edge"),
+    "C4": dict(scale=28, m=2_000_000_000, label="100M-host / 2B-edge"),
 }

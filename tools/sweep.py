@@ -44,7 +44,8 @@ def main():
                 "dense_ms_main": round(float(np.mean([p["ms_main"] for p in dense])), 3) if dense else None,
                 "front_ms_gpu": round(float(np.mean([p["ms_gpu"] for p in front])), 3) if front else None,
                 "sparse_ms_gpu": [round(p["ms_gpu"], 3) for p in sparse],
-                "changed": [p["changed"] for p in ps],
+                "changed": [p["changed"] for p in ps], "active_pct": [round(100.0 * p["active_edges"] / g.m, 1) for p in ps],
+                "modes": [p["mode"] for p in ps], "ms": [round(p["ms_gpu"], 2) for p in ps],
                 "virtual_rows": best["virtual_rows"], "s_load": round(t_load, 2), "ms_plan": round(best["ms_plan"]),
                 "same_result": sig == ref}), flush=True)
 
