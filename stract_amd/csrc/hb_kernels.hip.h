@@ -462,18 +462,41 @@ struct SparseParams {
     int level;                 // level processed by this launch (sparse_rows_kernel<false>)
 };
 
-__device__ __forceinline__ void sparse_push(const SparseParams &sp, uint32_t r)
+// Wave-aggregated append: every lane of the wave calls this (has = lane has a row to offer).  A row is
+// appended to its level's worklist the first time its touch bit is set; one atomicAdd per wave and
+// list instead of one per row (a single hot counter sustains only ~90 atomics/us).
+__device__ __forceinline__ void sparse_push(const SparseParams &sp, bool has, uint32_t r)
 {
-    const uint32_t bit = 1u << (r & 31u);
-    if (__builtin_nontemporal_load(&sp.touch[r >> 5]) & bit) return; // cheap pre-test (a stale miss is re-checked below)
-    const uint32_t old = atomicOr(&sp.touch[r >> 5], bit);
-    if (old & bit) return;
-    if ((uint64_t)r < sp.p.n_pad) {
-        sp.list_real[atomicAdd(&sp.counts[1], 1u)] = r;
-    } else {
-        int l = 0;
-        while (l + 1 < sp.levels && (uint64_t)r >= sp.level_begin[l + 1]) l++;
-        sp.list_virt[(sp.level_begin[l] - sp.p.n_pad) + atomicAdd(&sp.counts[2 + l], 1u)] = r;
+    int lid = -1; // 0 = node rows, 1 + l = virtual level l
+    if (has) {
+        const uint32_t bit = 1u << (r & 31u);
+        bool fresh = !(__builtin_nontemporal_load(&sp.touch[r >> 5]) & bit); // cheap pre-test
+        if (fresh) fresh = !(atomicOr(&sp.touch[r >> 5], bit) & bit);
+        if (fresh) {
+            if ((uint64_t)r < sp.p.n_pad) {
+                lid = 0;
+            } else {
+                int l = 0;
+                while (l + 1 < sp.levels && (uint64_t)r >= sp.level_begin[l + 1]) l++;
+                lid = 1 + l;
+            }
+        }
+    }
+    const int lane = threadIdx.x & 63;
+    uint64_t todo = __ballot(lid >= 0);
+    while (todo) {
+        const int leader = __ffsll((long long)todo) - 1;
+        const int cur = __shfl(lid, leader);
+        const uint64_t mask = __ballot(lid == cur);
+        uint32_t base = 0;
+        if (lane == leader) base = atomicAdd(&sp.counts[cur == 0 ? 1 : 1 + cur], (unsigned)__popcll(mask));
+        base = __shfl(base, leader);
+        if (lid == cur) {
+            const uint32_t pos = base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+            if (cur == 0) sp.list_real[pos] = r;
+            else sp.list_virt[(sp.level_begin[cur - 1] - sp.p.n_pad) + pos] = r;
+        }
+        todo &= ~mask;
     }
 }
 
@@ -482,15 +505,41 @@ __device__ __forceinline__ void sparse_push(const SparseParams &sp, uint32_t r)
 __global__ __launch_bounds__(256) void sparse_collect_kernel(const SparseParams sp)
 {
     const uint64_t words = sp.p.n_pad >> 5;
-    for (uint64_t w = (uint64_t)blockIdx.x * 256 + threadIdx.x; w < words; w += (uint64_t)gridDim.x * 256) {
-        uint32_t ch = sp.p.bits_rd[w];
-        uint32_t both = ch | sp.p.kdirty[w];
+    const int lane = threadIdx.x & 63;
+    const uint64_t stride = (uint64_t)gridDim.x * 256;
+    for (uint64_t w0 = (uint64_t)blockIdx.x * 256; w0 < words; w0 += stride) { // wave-uniform trip count
+        const uint64_t w = w0 + threadIdx.x;
+        uint32_t ch = 0, both = 0;
+        if (w < words) {
+            ch = sp.p.bits_rd[w];
+            both = ch | sp.p.kdirty[w];
+            if (both) sp.touch[w] = both; // first writer of these words (the buffer was just cleared)
+        }
+        // wave-aggregated reservation in the seed list and in the node-row worklist
+        uint32_t nch = __popc(ch), nb = __popc(both);
+        uint32_t pch = nch, pb = nb; // inclusive prefix sums over the wave
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t a = __shfl_up(pch, off), b = __shfl_up(pb, off);
+            if (lane >= off) {
+                pch += a;
+                pb += b;
+            }
+        }
+        const uint32_t tot_ch = __shfl(pch, 63), tot_b = __shfl(pb, 63);
+        uint32_t base_ch = 0, base_b = 0;
+        if (lane == 0) {
+            if (tot_ch) base_ch = atomicAdd(&sp.counts[0], tot_ch);
+            if (tot_b) base_b = atomicAdd(&sp.counts[1], tot_b);
+        }
+        base_ch = __shfl(base_ch, 0) + pch - nch;
+        base_b = __shfl(base_b, 0) + pb - nb;
         while (both) {
             const int b = __ffs((int)both) - 1;
             both &= both - 1;
             const uint32_t row = (uint32_t)(w << 5) + (uint32_t)b;
-            if ((ch >> b) & 1u) sp.seeds[atomicAdd(&sp.counts[0], 1u)] = row;
-            sparse_push(sp, row);
+            if ((ch >> b) & 1u) sp.seeds[base_ch++] = row;
+            sp.list_real[base_b++] = row;
         }
     }
 }
@@ -508,18 +557,27 @@ __global__ __launch_bounds__(256) void sparse_expand_kernel(const SparseParams s
             if (lane == 0) sp.heavy[atomicAdd(&sp.counts[kHeavySlot], 1u)] = u;
             continue;
         }
-        for (uint64_t k = b + lane; k < e; k += 64) sparse_push(sp, sp.out_rows[k]);
+        for (uint64_t k0 = b; k0 < e; k0 += 64) {
+            const uint64_t k = k0 + lane;
+            const bool has = k < e;
+            sparse_push(sp, has, has ? sp.out_rows[k] : 0u);
+        }
     }
 }
 
 __global__ __launch_bounds__(256) void sparse_expand_heavy_kernel(const SparseParams sp)
 {
     const uint32_t nheavy = sp.counts[kHeavySlot];
-    const uint64_t tid = (uint64_t)blockIdx.x * 256 + threadIdx.x, nthreads = (uint64_t)gridDim.x * 256;
+    const uint64_t wbase = ((uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 64, nthreads = (uint64_t)gridDim.x * 256;
+    const int lane = threadIdx.x & 63;
     for (uint32_t i = 0; i < nheavy; i++) {
         const uint32_t u = sp.heavy[i];
         const uint64_t b = sp.out_ptr[u], e = sp.out_ptr[u + 1];
-        for (uint64_t k = b + tid; k < e; k += nthreads) sparse_push(sp, sp.out_rows[k]);
+        for (uint64_t k0 = b + wbase; k0 < e; k0 += nthreads) { // wave-uniform trip count
+            const uint64_t k = k0 + lane;
+            const bool has = k < e;
+            sparse_push(sp, has, has ? sp.out_rows[k] : 0u);
+        }
     }
 }
 
@@ -611,12 +669,22 @@ __global__ __launch_bounds__(256) void sparse_rows_kernel(const SparseParams sp)
                     if (!err_nz && kd) atomicAnd(&p.kdirty[row >> 5], ~bit);
                 }
             }
-        } else if (changed) {
-            p.part[(row - p.n_pad) * 4 + q] = accv;
-            if (q == 0) {
-                atomicOr((uint32_t *)&p.bits_rd[row >> 5], bit); // this pass' virtual changed bit
-                const uint64_t b = sp.out_ptr[row], e = sp.out_ptr[row + 1];
-                for (uint64_t k = b; k < e; k++) sparse_push(sp, sp.out_rows[k]);
+        } else {
+            if (changed) {
+                p.part[(row - p.n_pad) * 4 + q] = accv;
+                if (q == 0) atomicOr((uint32_t *)&p.bits_rd[row >> 5], bit); // this pass' virtual changed bit
+            }
+            // the readers (normally exactly one parent) of the changed rows join their level's worklist
+            const bool pusher = changed && q == 0;
+            uint64_t pb = 0, pe = 0;
+            if (pusher) {
+                pb = sp.out_ptr[row];
+                pe = sp.out_ptr[row + 1];
+            }
+            while (__ballot(pb < pe)) {
+                const bool has = pb < pe;
+                sparse_push(sp, has, has ? sp.out_rows[pb] : 0u);
+                pb++;
             }
         }
     }
