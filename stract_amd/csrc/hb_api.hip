@@ -67,7 +67,7 @@ struct hb_ctx {
     uint64_t *d_out_ptr = nullptr;
     uint32_t *d_out_rows = nullptr;
     uint32_t *d_touch = nullptr;
-    uint32_t *d_list_real = nullptr, *d_list_virt = nullptr, *d_seeds = nullptr, *d_heavy = nullptr;
+    uint32_t *d_list_real = nullptr, *d_list_virt = nullptr, *d_seeds = nullptr, *d_heavy = nullptr, *d_medium = nullptr;
     unsigned int *d_sparse_counts = nullptr;
     bool sparse_ok = false;
     uint64_t plan_entries = 0; // entries of all work rows' source lists
@@ -156,7 +156,7 @@ void free_graph_buffers(hb_ctx *c)
     c->d_out_ptr = nullptr;
     c->d_out_rows = nullptr;
     c->d_touch = nullptr;
-    c->d_list_real = c->d_list_virt = c->d_seeds = c->d_heavy = nullptr;
+    c->d_list_real = c->d_list_virt = c->d_seeds = c->d_heavy = c->d_medium = nullptr;
     c->d_sparse_counts = nullptr;
     c->sparse_ok = false;
     if (c->h_out) (void)hipHostFree(c->h_out);
@@ -209,6 +209,7 @@ int build_sparse_support(hb_ctx *c)
     if ((rc = dev_alloc(c, &c->d_list_virt, p.nv))) return rc;
     if ((rc = dev_alloc(c, &c->d_seeds, p.n_pad))) return rc;
     if ((rc = dev_alloc(c, &c->d_heavy, p.n_pad))) return rc;
+    if ((rc = dev_alloc(c, &c->d_medium, p.n_pad))) return rc;
     if ((rc = dev_alloc(c, &c->d_sparse_counts, 64))) return rc;
     if ((rc = dev_alloc(c, &d_count, rows_total))) return rc; // stays allocated (small next to out_rows)
     HB_HIP(hipMemsetAsync(d_count, 0, rows_total * sizeof(uint32_t), c->stream));
@@ -455,6 +456,7 @@ int step_local(hb_ctx *c)
         sp.list_virt = c->d_list_virt;
         sp.seeds = c->d_seeds;
         sp.heavy = c->d_heavy;
+        sp.medium = c->d_medium;
         sp.counts = c->d_sparse_counts;
         sp.levels = (int)p.level_begin.size() - 1;
         if (sp.levels < 0) sp.levels = 0;
@@ -469,6 +471,7 @@ int step_local(hb_ctx *c)
         hipLaunchKernelGGL(hbk::sparse_collect_kernel, dim3(sblocks), dim3(256), 0, c->stream, sp);
         const unsigned wblocks = (unsigned)c->num_cu * 4;
         hipLaunchKernelGGL(hbk::sparse_expand_kernel, dim3(wblocks), dim3(256), 0, c->stream, sp);
+        hipLaunchKernelGGL(hbk::sparse_expand_medium_kernel, dim3(wblocks), dim3(256), 0, c->stream, sp);
         hipLaunchKernelGGL(hbk::sparse_expand_heavy_kernel, dim3(wblocks), dim3(256), 0, c->stream, sp);
         for (int l = 0; l < sp.levels; l++) {
             sp.level = l;

@@ -278,9 +278,11 @@ __global__ __launch_bounds__(256) void pass_kernel(const PassParams p)
         const uint64_t row = row16 + (uint64_t)g;
         const bool valid = row < p.row_hi;
         uint64_t beg = 0, end = 0;
+        uint32_t od = 0; // out-degree of the row's node: issued with the row pointers, used in the epilogue
         if (valid) {
             beg = p.row_ptr[row];
             end = p.row_ptr[row + 1];
+            if (REAL && FUSED) od = p.outdeg[row];
         }
         const uint4 *selfp = REAL ? (p.rd + row * 4 + q) : (p.part + (row - p.n_pad) * 4 + q);
         uint4 selfv = make_uint4(0, 0, 0, 0);
@@ -390,7 +392,7 @@ __global__ __launch_bounds__(256) void pass_kernel(const PassParams p)
         }
         if (REAL && FUSED) {
             cnt_changed += __popc(ch16);
-            if (changed && q == 0) cnt_out += p.outdeg[row];
+            if (changed && q == 0) cnt_out += od;
         }
         if (STATS) cnt_rows += (need && q == 0);
         if (REAL && FUSED) {
@@ -445,6 +447,8 @@ __global__ __launch_bounds__(256) void pass_kernel(const PassParams p)
 // pass_kernel, so registers / Kahan state / changed bits are bit-identical.
 constexpr int kMaxSparseLevels = 12;
 constexpr int kHeavySlot = 32;          // index into SparseParams::counts
+constexpr int kMediumSlot = 33;
+constexpr uint64_t kLightReaders = 8;   // a seed with at most this many readers is expanded by one lane
 constexpr uint64_t kHeavyReaders = 2048; // a seed with more readers than this is expanded grid-wide
 
 struct SparseParams {
@@ -456,6 +460,7 @@ struct SparseParams {
     uint32_t *list_virt;       // worklists of virtual rows, level l at offset level_begin[l] - n_pad
     uint32_t *seeds;           // nodes changed in the previous pass (capacity n_pad)
     uint32_t *heavy;           // seeds with long reader lists (expanded by the whole grid)
+    uint32_t *medium;          // seeds expanded by one wave each
     unsigned int *counts;      // [0] seeds, [1] real list, [2 + l] level-l list, [kHeavySlot] heavy seeds
     uint64_t level_begin[kMaxSparseLevels + 1];
     int levels;
@@ -544,16 +549,52 @@ __global__ __launch_bounds__(256) void sparse_collect_kernel(const SparseParams 
     }
 }
 
-// one wave per seed: every work row that reads it goes on its level's worklist
+// Seeds -> worklists in three tiers by reader count: <= kLightReaders inline, one LANE per seed
+// (most late changers are read by one or two rows); up to kHeavyReaders one WAVE per seed
+// (sparse_expand_medium_kernel); beyond that the whole grid (hubs stay in the changed set longest).
 __global__ __launch_bounds__(256) void sparse_expand_kernel(const SparseParams sp)
 {
     const int lane = threadIdx.x & 63;
     const uint32_t nseeds = sp.counts[0];
     const uint32_t wave = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
-    for (uint32_t i = wave; i < nseeds; i += nwaves) {
-        const uint32_t u = sp.seeds[i];
+    for (uint32_t i0 = wave * 64; i0 < nseeds; i0 += nwaves * 64) { // wave-uniform trip count
+        const uint32_t i = i0 + lane;
+        uint64_t b = 0, e = 0;
+        uint32_t u = 0;
+        if (i < nseeds) {
+            u = sp.seeds[i];
+            b = sp.out_ptr[u];
+            e = sp.out_ptr[u + 1];
+        }
+        const bool medium = e - b > kLightReaders;
+        const uint64_t mm = __ballot(medium);
+        if (mm) {
+            uint32_t base = 0;
+            const int leader = __ffsll((long long)mm) - 1;
+            if (lane == leader) base = atomicAdd(&sp.counts[kMediumSlot], (unsigned)__popcll(mm));
+            base = __shfl(base, leader);
+            if (medium) {
+                sp.medium[base + (uint32_t)__popcll(mm & ((1ull << lane) - 1ull))] = u;
+                b = e;
+            }
+        }
+        while (__ballot(b < e)) {
+            const bool has = b < e;
+            sparse_push(sp, has, has ? sp.out_rows[b] : 0u);
+            b++;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void sparse_expand_medium_kernel(const SparseParams sp)
+{
+    const int lane = threadIdx.x & 63;
+    const uint32_t nmed = sp.counts[kMediumSlot];
+    const uint32_t wave = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
+    for (uint32_t i = wave; i < nmed; i += nwaves) {
+        const uint32_t u = sp.medium[i];
         const uint64_t b = sp.out_ptr[u], e = sp.out_ptr[u + 1];
-        if (e - b > kHeavyReaders) { // hubs stay in the changed set longest: spread them over the grid
+        if (e - b > kHeavyReaders) {
             if (lane == 0) sp.heavy[atomicAdd(&sp.counts[kHeavySlot], 1u)] = u;
             continue;
         }
