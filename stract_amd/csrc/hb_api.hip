@@ -60,7 +60,7 @@ struct hb_ctx {
     uint32_t *d_outdeg = nullptr; // device row -> (global) out-degree
     uint64_t m_global = 0;        // edges of the whole graph (all ranks)
     uint64_t last_active = 0;     // out-degree sum of the nodes changed in the previous pass
-    unsigned long long *d_counters = nullptr; // max_passes * 4
+    unsigned long long *d_counters = nullptr; // (max_passes + 1) * kCounterWords, striped (hb_kernels.hip.h)
     double *d_raw = nullptr, *d_bias = nullptr;
     uint8_t *d_lc = nullptr;
     // sparse (data-driven) tail passes: transposed work-row graph + worklists
@@ -71,7 +71,7 @@ struct hb_ctx {
     unsigned int *d_sparse_counts = nullptr;
     bool sparse_ok = false;
     uint64_t plan_entries = 0; // entries of all work rows' source lists
-    unsigned long long *h_counters = nullptr; // pinned, 4 words
+    unsigned long long *h_counters = nullptr; // pinned, kCounterWords words; [0..3] hold the stripe sums after a pass
     uint64_t bits_words = 0;
     uint64_t ksum_len = 0; // entries allocated for ksum (world * slice in RCCL mode)
     uint64_t slice_rows = 0;
@@ -305,7 +305,7 @@ int plan_and_upload(hb_ctx *c)
     if ((rc = dev_alloc(c, &c->d_dev_of, n))) return rc;
     if ((rc = dev_alloc(c, &c->d_sid_of, p.n_pad))) return rc;
     if ((rc = dev_alloc(c, &c->d_outdeg, p.n_pad))) return rc;
-    if ((rc = dev_alloc(c, &c->d_counters, (size_t)c->max_passes * 4))) return rc;
+    if ((rc = dev_alloc(c, &c->d_counters, ((size_t)c->max_passes + 1) * hbk::kCounterWords))) return rc;
     if ((rc = dev_alloc(c, &c->d_raw, HLL64_TABLE_LEN))) return rc;
     if ((rc = dev_alloc(c, &c->d_bias, HLL64_TABLE_LEN))) return rc;
     if ((rc = dev_alloc(c, &c->d_lc, 68))) return rc;
@@ -407,7 +407,7 @@ hbk::PassParams make_params(hb_ctx *c)
     pp.ksum = c->d_ksum;
     pp.kerr = c->d_kerr;
     pp.size = c->d_size;
-    pp.counters = c->d_counters + 4 * c->t;
+    pp.counters = c->d_counters + (size_t)hbk::kCounterWords * c->t;
     pp.outdeg = c->d_outdeg;
     pp.raw = c->d_raw;
     pp.bias = c->d_bias;
@@ -526,7 +526,7 @@ int step_finish(hb_ctx *c, int *has_changes)
         HB_NCCL(ncclGroupStart());
         HB_NCCL(ncclAllGather(pp.wr + r * S * 4, pp.wr, S * 64, ncclUint8, c->comm, c->stream));
         HB_NCCL(ncclAllGather(pp.bits_wr + r * (S / 32), pp.bits_wr, S / 32, ncclUint32, c->comm, c->stream));
-        HB_NCCL(ncclAllReduce(pp.counters, pp.counters, 4, ncclUint64, ncclSum, c->comm, c->stream));
+        HB_NCCL(ncclAllReduce(pp.counters, pp.counters, hbk::kCounterWords, ncclUint64, ncclSum, c->comm, c->stream));
         HB_NCCL(ncclGroupEnd());
         HB_HIP(hipEventRecord(c->ev[3], c->stream));
     }
@@ -538,8 +538,11 @@ int step_finish(hb_ctx *c, int *has_changes)
         HB_HIP(hipEventRecord(c->ev[4], c->stream));
         ev_end = c->ev[4];
     }
-    HB_HIP(hipMemcpyAsync(c->h_counters, c->d_counters + 4 * c->t, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+    HB_HIP(hipMemcpyAsync(c->h_counters, c->d_counters + (size_t)hbk::kCounterWords * c->t,
+                          hbk::kCounterWords * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
     HB_HIP(hipStreamSynchronize(c->stream));
+    for (int s = 1; s < hbk::kStripes; s++)
+        for (int k = 0; k < 4; k++) c->h_counters[k] += c->h_counters[4 * s + k];
     if (unfused(c) || (dest_mode(c) && c->comm)) HB_HIP(hipEventElapsedTime(&ms_coll, c->ev[2], c->ev[3]));
     hb_pass_stats ps{};
     ps.pass = c->t;
@@ -643,7 +646,7 @@ int hb_create(const hb_options *opt, hb_ctx **out)
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { ctx->err = "hipStreamCreate failed"; return bail(HB_ERR_HIP); }
     for (int i = 0; i < 5; i++)
         if (hipEventCreate(&ctx->ev[i]) != hipSuccess) { ctx->err = "hipEventCreate failed"; return bail(HB_ERR_HIP); }
-    if (hipHostMalloc((void **)&ctx->h_counters, 4 * sizeof(unsigned long long)) != hipSuccess) { ctx->err = "hipHostMalloc failed"; return bail(HB_ERR_NOMEM); }
+    if (hipHostMalloc((void **)&ctx->h_counters, hbk::kCounterWords * sizeof(unsigned long long)) != hipSuccess) { ctx->err = "hipHostMalloc failed"; return bail(HB_ERR_NOMEM); }
     if (o.world_size > 1 && !(o.flags & HB_FLAG_NO_RCCL)) {
         ncclUniqueId id;
         std::memcpy(&id, o.rccl_id, 128);
@@ -768,7 +771,7 @@ int hb_begin(hb_ctx *c)
     HB_HIP(hipMemsetAsync(c->d_part, 0, std::max<size_t>(p.nv * 64, 256), c->stream));
     HB_HIP(hipMemsetAsync(c->d_bits[0], 0, c->bits_words * 4, c->stream));
     HB_HIP(hipMemsetAsync(c->d_bits[1], 0, c->bits_words * 4, c->stream));
-    HB_HIP(hipMemsetAsync(c->d_counters, 0, (size_t)c->max_passes * 4 * sizeof(unsigned long long), c->stream));
+    HB_HIP(hipMemsetAsync(c->d_counters, 0, ((size_t)c->max_passes + 1) * hbk::kCounterWords * sizeof(unsigned long long), c->stream));
     HB_HIP(hipMemsetAsync(c->d_ksum, 0, c->ksum_len * sizeof(double), c->stream));
     if (p.n_pad) {
         unsigned blocks = (unsigned)((p.n_pad * 4 + 255) / 256);
@@ -832,8 +835,8 @@ int hb_finish(hb_ctx *c)
     // normalize_centralities (harmonic.rs:178-195) on the device, in ascending-NodeID order;
     // norm_factor = (num_nodes - 1) as f64 (:229)
     const double norm = (double)(p.n ? p.n - 1 : 0);
-    unsigned long long *cnt = c->d_counters + 4 * (size_t)(c->max_passes - 1) + 3; // spare word
-    HB_HIP(hipMemsetAsync(cnt, 0, sizeof(unsigned long long), c->stream));
+    unsigned long long *cnt = c->d_counters + (size_t)c->max_passes * hbk::kCounterWords; // the spare slot
+    HB_HIP(hipMemsetAsync(cnt, 0, hbk::kCounterWords * sizeof(unsigned long long), c->stream));
     if (p.n) {
         unsigned blocks = (unsigned)std::min<uint64_t>((p.n + 255) / 256, (uint64_t)c->num_cu * 8);
         hipLaunchKernelGGL(hbk::finish_kernel, dim3(blocks), dim3(256), 0, c->stream, (const double *)c->d_ksum,
@@ -841,9 +844,10 @@ int hb_finish(hb_ctx *c)
         HB_HIP(hipGetLastError());
         HB_HIP(hipMemcpyAsync(c->h_out, c->d_out, p.n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     }
-    HB_HIP(hipMemcpyAsync(c->h_counters, cnt, sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+    HB_HIP(hipMemcpyAsync(c->h_counters, cnt, hbk::kCounterWords * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
     HB_HIP(hipStreamSynchronize(c->stream));
-    c->res_count = c->h_counters[0];
+    c->res_count = 0;
+    for (int s = 0; s < hbk::kStripes; s++) c->res_count += c->h_counters[4 * s];
     c->stats.ms_d2h = now_ms() - t0;
     c->stats.results = c->res_count;
     c->stats.passes = c->t;
@@ -1100,14 +1104,14 @@ int hb_debug_exchange(hb_ctx **ctxs, int count, int phase)
             HB_HIP(hipMemcpyAsync(ctxs[i]->d_regs[ctxs[i]->cur ^ 1], c->d_regs[c->cur ^ 1], count4 * 16, hipMemcpyDeviceToDevice, c->stream));
     } else {
         // all-gather of the owned slices (counters, changed bits) + sum of the changed counts
-        unsigned long long total[4] = {0, 0, 0, 0};
-        std::vector<unsigned long long> cnt((size_t)count * 4, 0);
+        const size_t W = hbk::kCounterWords;
+        std::vector<unsigned long long> total(W, 0), cnt((size_t)count * W, 0);
         for (int i = 0; i < count; i++) {
-            HB_HIP(hipMemcpyAsync(&cnt[(size_t)i * 4], ctxs[i]->d_counters + 4 * ctxs[i]->t, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+            HB_HIP(hipMemcpyAsync(&cnt[(size_t)i * W], ctxs[i]->d_counters + W * ctxs[i]->t, W * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
         }
         HB_HIP(hipStreamSynchronize(c->stream));
         for (int i = 0; i < count; i++)
-            for (int k = 0; k < 4; k++) total[k] += cnt[(size_t)i * 4 + k];
+            for (size_t k = 0; k < W; k++) total[k] += cnt[(size_t)i * W + k];
         for (int i = 0; i < count; i++) {
             hb_ctx *d = ctxs[i];
             for (int j = 0; j < count; j++) {
@@ -1118,7 +1122,7 @@ int hb_debug_exchange(hb_ctx **ctxs, int count, int phase)
                 HB_HIP(hipMemcpyAsync(d->d_bits[d->cur ^ 1] + (uint64_t)j * (S / 32), o->d_bits[o->cur ^ 1] + (uint64_t)j * (S / 32), S / 8,
                                       hipMemcpyDeviceToDevice, c->stream));
             }
-            HB_HIP(hipMemcpyAsync(d->d_counters + 4 * d->t, total, 4 * sizeof(unsigned long long), hipMemcpyHostToDevice, c->stream));
+            HB_HIP(hipMemcpyAsync(d->d_counters + W * d->t, total.data(), W * sizeof(unsigned long long), hipMemcpyHostToDevice, c->stream));
         }
     }
     HB_HIP(hipStreamSynchronize(c->stream));

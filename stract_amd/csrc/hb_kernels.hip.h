@@ -26,6 +26,29 @@ namespace hbk {
 
 constexpr uint32_t kNone = 0xFFFFFFFFu;
 constexpr int kTableLen = 159;
+// Per-pass counters are striped: kStripes copies of 4 words, a block adds to stripe blockIdx % kStripes
+// (one same-address atomic stream sustains only ~90 updates/us; 8192 waves finishing together made a
+// 0.1 ms tail).  The host sums the stripes.
+constexpr int kStripes = 64;
+constexpr int kCounterWords = 4 * kStripes;
+
+// block-level sum of up to 4 per-wave values (lane 0 of each wave holds its wave's total), then one
+// atomic per block and word into the block's stripe
+__device__ __forceinline__ void block_add_counters(unsigned long long *counters, const unsigned long long v[4], unsigned mask)
+{
+    __shared__ unsigned long long s_part[4][4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) s_part[wave][k] = v[k];
+    }
+    __syncthreads();
+    if (threadIdx.x < 4 && ((mask >> threadIdx.x) & 1u)) {
+        const int k = threadIdx.x;
+        const unsigned long long t = s_part[0][k] + s_part[1][k] + s_part[2][k] + s_part[3][k];
+        if (t) atomicAdd(&counters[(blockIdx.x & (kStripes - 1)) * 4 + k], t);
+    }
+}
 
 struct PassParams {
     const uint64_t *row_ptr;
@@ -39,8 +62,8 @@ struct PassParams {
     double *ksum;
     double *kerr;
     uint64_t *size;           // cached size() of rd[row]
-    unsigned long long *counters; // [0] changed rows, [1] active edges, [2] rows processed,
-                                  // [3] out-degree sum of the changed rows = active edges of the NEXT pass
+    unsigned long long *counters; // kStripes x { [0] changed rows, [1] active edges, [2] rows processed,
+                                  // [3] out-degree sum of the changed rows = active edges of the NEXT pass }
     const uint32_t *outdeg;   // per node row: (global) out-degree
     const double *raw;        // HLL64_RAW_ESTIMATE (global copy, staged to LDS)
     const double *bias;       // HLL64_BIAS
@@ -414,26 +437,19 @@ __global__ __launch_bounds__(256) void pass_kernel(const PassParams p)
             if (lane == 0 && row16 < p.row_hi && (nk16 | kd16)) ((uint16_t *)p.kdirty)[row16 >> 4] = (uint16_t)nk16;
         }
     }
-    // ---- per-wave totals, one atomic each
-    if (REAL) {
-        // cnt_changed is identical in all lanes of the wave (derived from a ballot)
-        if (lane == 0 && cnt_changed) atomicAdd(&p.counters[0], cnt_changed);
-        if (FUSED) {
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) cnt_out += __shfl_down(cnt_out, off);
-            if (lane == 0 && cnt_out) atomicAdd(&p.counters[3], cnt_out);
-        }
-    }
-    if (STATS) {
+    // ---- totals: wave -> block -> one atomic per word into the block's counter stripe
+    if (REAL || STATS) {
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) {
-            cnt_active += __shfl_down(cnt_active, off);
-            cnt_rows += __shfl_down(cnt_rows, off);
+            cnt_out += __shfl_down(cnt_out, off);
+            if (STATS) {
+                cnt_active += __shfl_down(cnt_active, off);
+                cnt_rows += __shfl_down(cnt_rows, off);
+            }
         }
-        if (lane == 0) {
-            if (cnt_active) atomicAdd(&p.counters[1], cnt_active);
-            if (cnt_rows) atomicAdd(&p.counters[2], cnt_rows);
-        }
+        // cnt_changed is identical in all lanes of the wave (derived from a ballot)
+        const unsigned long long v[4] = {cnt_changed, cnt_active, cnt_rows, cnt_out};
+        block_add_counters(p.counters, v, (REAL ? 0x9u : 0u) | (STATS ? 0x6u : 0u));
     }
 }
 
@@ -730,10 +746,10 @@ __global__ __launch_bounds__(256) void sparse_rows_kernel(const SparseParams sp)
         }
     }
     if (REAL) {
-        if (lane == 0 && cnt_changed) atomicAdd(&p.counters[0], cnt_changed);
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) cnt_out += __shfl_down(cnt_out, off);
-        if (lane == 0 && cnt_out) atomicAdd(&p.counters[3], cnt_out);
+        const unsigned long long v[4] = {cnt_changed, 0, 0, cnt_out};
+        block_add_counters(p.counters, v, 0x9u);
     }
 }
 
@@ -821,10 +837,10 @@ __global__ __launch_bounds__(256) void epilogue_kernel(const PassParams p)
         const uint32_t nk16 = pack16(__ballot(err_nz));
         if (lane == 0 && row16 < p.row_hi && (nk16 | kd16)) ((uint16_t *)p.kdirty)[row16 >> 4] = (uint16_t)nk16;
     }
-    if (lane == 0 && cnt_changed) atomicAdd(&p.counters[0], cnt_changed);
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) cnt_out += __shfl_down(cnt_out, off);
-    if (lane == 0 && cnt_out) atomicAdd(&p.counters[3], cnt_out);
+    const unsigned long long v[4] = {cnt_changed, 0, 0, cnt_out};
+    block_add_counters(p.counters, v, 0x9u);
 }
 
 // ---- initialisation: counter = HLL::default(); add_u128(id) (harmonic.rs:60-66) ----------
@@ -916,7 +932,8 @@ __global__ __launch_bounds__(256) void finish_kernel(const double *ksum, const u
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) kept += __shfl_down(kept, off);
-    if ((threadIdx.x & 63) == 0 && kept) atomicAdd(count, kept);
+    const unsigned long long v[4] = {kept, 0, 0, 0};
+    block_add_counters(count, v, 0x1u); // striped: the host sums word 0 of every stripe
 }
 
 // scatter/gather between device order and ascending-NodeID order (debug exports)
