@@ -164,7 +164,7 @@ def main():
             traffic = _pmc_traffic(a.config)
             roof = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                    "kernel": "hbk::pass_kernel<false,false,false,false,2> (dense pull over hub chunks)",
+                    "kernel": "hbk::pass_kernel<false,false,false,false,4> (dense pull over hub chunks)",
                     "alg_bytes_per_launch": alg_bytes, "avg_launch_ms": round(avg_ms, 4),
                     "launches": dense_passes * levels,
                     "whole_dense_pass": {"alg_bytes": 68.0 * m_eff + 192.25 * n,
@@ -219,7 +219,7 @@ def _pmc_traffic(config):
         with open(p) as f:
             d = json.load(f)
         for k, v in d.items():
-            if "pass_kernel<false, false" in k:
+            if "pass_kernel<false, false, false, false, 4>" in k:
                 return v.get("hbm_bytes_per_dispatch")
     except Exception:
         pass

@@ -372,7 +372,7 @@ void launch_pass(hb_ctx *c, const hbk::PassParams &pp, bool real, bool frontier,
 {
     const bool stats = (c->opt.flags & HB_FLAG_PASS_STATS) != 0;
     int unroll = (int)c->opt.tune[1];
-    if (unroll != 1 && unroll != 2 && unroll != 4) unroll = 2;
+    if (unroll != 1 && unroll != 2 && unroll != 4) unroll = 4; // 16 gathers in flight per quad: best on C2/C3
     const uint64_t ntiles = (pp.row_hi - pp.row_lo + 63) / 64;
     if (ntiles == 0) return;
     uint32_t bpc = c->opt.tune[0] ? c->opt.tune[0] : 8;
