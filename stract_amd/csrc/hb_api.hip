@@ -372,7 +372,9 @@ void launch_pass(hb_ctx *c, const hbk::PassParams &pp, bool real, bool frontier,
 {
     const bool stats = (c->opt.flags & HB_FLAG_PASS_STATS) != 0;
     int unroll = (int)c->opt.tune[1];
-    if (unroll != 1 && unroll != 2 && unroll != 4) unroll = 4; // 16 gathers in flight per quad: best on C2/C3
+    // default: 16 gathers in flight per quad for the hub chunks (pure gather loops); 8 for the node rows,
+    // whose fused estimator/Kahan epilogue needs the registers (unroll 4 drops them to 4 waves/SIMD)
+    if (unroll != 1 && unroll != 2 && unroll != 4) unroll = real ? 2 : 4;
     const uint64_t ntiles = (pp.row_hi - pp.row_lo + 63) / 64;
     if (ntiles == 0) return;
     uint32_t bpc = c->opt.tune[0] ? c->opt.tune[0] : 8;
