@@ -68,8 +68,7 @@ typedef struct hb_edge {
 #define HB_FLAG_NO_REORDER    0x02u /* keep ascending-NodeID order as the device order            */
 #define HB_FLAG_UNFUSED       0x04u /* run merge and estimator/Kahan as two kernels even on 1 GPU  */
 #define HB_FLAG_PASS_STATS    0x08u /* also count active edges / touched rows per pass (A_t, V_t)  */
-#define HB_FLAG_NO_LDS_HOT    0x10u /* do not stage the hottest counters in LDS                    */
-#define HB_FLAG_NO_XCD_MAP    0x20u /* plain blockIdx -> work mapping                              */
+#define HB_FLAG_NO_XCD_MAP    0x20u /* plain blockIdx -> tile mapping, no XCD-affine chunk groups  */
 #define HB_FLAG_NO_RCCL       0x40u /* world_size > 1 bookkeeping without a communicator: the caller
                                        performs the exchange (hb_debug_exchange; tests)       */
 #define HB_FLAG_NO_SPARSE     0x100u /* never use the worklist-driven tail passes (debug; same results) */
@@ -233,7 +232,7 @@ int hb_host_ingest(const hb_u128 *node_ids, uint64_t n, const hb_edge *edges, ui
                    uint64_t *n_out, uint64_t *m_unique, uint64_t *m_eff, hb_u128 *ids,
                    uint64_t *row_ptr, uint32_t *src);
 /* The device work layout the planner would build for a reduced graph (device order +
- * hub-row splitting), so its invariants can be checked on the host.  flags: HB_FLAG_NO_REORDER.
+ * hub-row splitting), so its invariants can be checked on the host.  flags: HB_FLAG_NO_REORDER, HB_FLAG_NO_XCD_MAP.
  * Two-call pattern: sizes[0..3] = {n_pad, nv, plan_src_len, levels}; then
  * order[n_pad] (0xFFFFFFFF = padding row), plan_row_ptr[n_pad+nv+1], plan_src[plan_src_len],
  * level_begin[levels+1].  tune[7] > 1 lays the rows out as tune[7] owner slices (destination partition). */

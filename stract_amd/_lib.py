@@ -20,7 +20,6 @@ HB_FLAG_NO_FRONTIER = 0x01
 HB_FLAG_NO_REORDER = 0x02
 HB_FLAG_UNFUSED = 0x04
 HB_FLAG_PASS_STATS = 0x08
-HB_FLAG_NO_LDS_HOT = 0x10
 HB_FLAG_NO_XCD_MAP = 0x20
 HB_FLAG_NO_RCCL = 0x40
 HB_FLAG_RCCL_SELF = 0x80

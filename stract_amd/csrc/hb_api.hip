@@ -271,6 +271,7 @@ int plan_and_upload(hb_ctx *c)
         }
     }
     PlanTune pt = plan_tune(c->opt.chunk, c->opt.tune);
+    pt.xcd_map = !(c->opt.flags & HB_FLAG_NO_XCD_MAP);
     if (dest_mode(c)) pt.world = (uint32_t)c->opt.world_size;
     std::string perr = build_plan(n, c->g.row_ptr.data(), c->g.src.data(), outdeg, reorder, pt, &c->plan);
     if (!perr.empty()) return fail(c, perr.find("memory") != std::string::npos ? HB_ERR_NOMEM : HB_ERR_LIMIT, perr);
@@ -379,6 +380,7 @@ void launch_pass(hb_ctx *c, const hbk::PassParams &pp, bool real, bool frontier,
     if (ntiles == 0) return;
     uint32_t bpc = c->opt.tune[0] ? c->opt.tune[0] : 8;
     uint64_t blocks = std::min<uint64_t>(ntiles, (uint64_t)c->num_cu * bpc);
+    if (pp.xcd_map) blocks = std::max<uint64_t>((blocks + 7) / 8 * 8, 8); // 8 queues, equal shares of the grid
     dim3 grid((unsigned)blocks);
     if (real) {
         if (frontier) {
@@ -486,8 +488,14 @@ int step_local(hb_ctx *c)
         for (size_t l = 0; l + 1 < p.level_begin.size(); l++) {
             pp.row_lo = p.level_begin[l];
             pp.row_hi = p.level_begin[l + 1];
+            pp.xcd_map = (l == 0 && p.xcd_groups == 8) ? 1 : 0;
+            for (int x = 0; x < 8; x++) {
+                pp.xcd_lo[x] = p.xcd_begin[x];
+                pp.xcd_hi[x] = p.xcd_begin[x + 1];
+            }
             launch_pass(c, pp, false, frontier, false);
         }
+        pp.xcd_map = 0;
         HB_HIP(hipEventRecord(c->ev[1], c->stream));
         pp.row_lo = dest_mode(c) ? pp.slice_lo : 0; // destination partition: only the owned rows
         pp.row_hi = dest_mode(c) ? pp.slice_hi : p.n_pad;
@@ -1050,6 +1058,7 @@ int hb_host_plan(uint64_t n, const uint64_t *row_ptr, const uint32_t *src, uint3
     Plan p;
     PlanTune pt = plan_tune(chunk, tune);
     if (tune && tune[7] > 1) pt.world = tune[7]; // destination-partition layout (test hook)
+    pt.xcd_map = !(flags & HB_FLAG_NO_XCD_MAP);
     std::string e = build_plan(n, row_ptr, src, outdeg, reorder, pt, &p);
     if (!e.empty()) return fail(c, HB_ERR_LIMIT, e);
     sizes[0] = p.n_pad;

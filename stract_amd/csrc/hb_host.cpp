@@ -318,9 +318,17 @@ std::string build_plan(uint64_t n, const uint64_t *row_ptr, const uint32_t *src,
         std::vector<uint8_t> is_split(n_pad, 0);
         uint64_t next_vid = p->n_pad;
         p->level_begin.push_back(next_vid);
+        // key of a source = its slice of the hotness order: slice 0 = the band_w hottest counters (every
+        // XCD's L2 holds them), slices 1..kWarmSlices = the following band_w-wide ranges, each gathered by
+        // ONE XCD only (8 L2s cache 8 different slices instead of 8 copies of the same lines); beyond that
+        // the cold tail in doubling bands (no reuse to protect, ordered only for tidiness).
+        const uint32_t kWarmSlices = tune.xcd_map ? 64u : 0u;
         auto band_of = [&](uint32_t idx) -> uint32_t {
             if (!tune.band_w || idx < tune.band_w) return 0;
-            return 1u + (uint32_t)(63 - __builtin_clzll((uint64_t)idx / tune.band_w));
+            const uint64_t j = (uint64_t)idx / tune.band_w;
+            if (j <= kWarmSlices) return (uint32_t)j;
+            const uint64_t q = j / (kWarmSlices + 1u); // >= 1
+            return kWarmSlices + 1u + (uint32_t)(63 - __builtin_clzll(q));
         };
         struct Chunk { uint64_t beg; uint32_t len; uint32_t key; };
         std::vector<Chunk> chunks;
@@ -349,34 +357,77 @@ std::string build_plan(uint64_t n, const uint64_t *row_ptr, const uint32_t *src,
         }
         hub_first.push_back(chunks.size());
         lap("cut chunks");
-        // order: band ascending, longer chunks first inside a band (wave-uniform trip counts)
+        // XCD groups: a warm-slice chunk belongs to XCD (slice mod 8); hot (slice 0) and cold chunks fill the
+        // groups up to equal work.  Inside a group: slice ascending, longer chunks first (wave-uniform
+        // trip counts).  Without xcd_map there is one group.
+        const int groups = tune.xcd_map ? 8 : 1;
+        std::vector<uint8_t> grp(chunks.size(), 0);
         std::vector<uint32_t> corder(chunks.size());
         std::iota(corder.begin(), corder.end(), 0u);
         std::stable_sort(corder.begin(), corder.end(), [&](uint32_t a, uint32_t b2) {
             if (chunks[a].key != chunks[b2].key) return chunks[a].key < chunks[b2].key;
             return chunks[a].len > chunks[b2].len;
         });
+        if (groups > 1) {
+            uint64_t load[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            for (size_t k = 0; k < chunks.size(); k++) {
+                const uint32_t key = chunks[k].key;
+                if (key >= 1 && key <= kWarmSlices) {
+                    grp[k] = (uint8_t)(key & 7u);
+                    load[grp[k]] += chunks[k].len + 4; // +4: per-row overhead in gather units
+                }
+            }
+            // the flexible chunks, coldest first so that the hot ones (cheap: L2 hits) settle the remainder
+            for (size_t r = corder.size(); r-- > 0;) {
+                const uint32_t k = corder[r];
+                const uint32_t key = chunks[k].key;
+                if (key >= 1 && key <= kWarmSlices) continue;
+                int best = 0;
+                for (int x = 1; x < 8; x++)
+                    if (load[x] < load[best]) best = x;
+                grp[k] = (uint8_t)best;
+                load[best] += chunks[k].len + 4;
+            }
+            std::stable_sort(corder.begin(), corder.end(), [&](uint32_t a, uint32_t b2) { return grp[a] < grp[b2]; });
+        }
         lap("sort chunks");
         std::vector<uint32_t> vid_of(chunks.size());
         {
-            // offsets of the level-1 lists in emission (= band) order, then a parallel fill
-            vrow_ptr.resize(chunks.size() + 1);
+            // row ids: group after group, every group padded to whole 64-row tiles; then a parallel fill
+            std::vector<uint64_t> vrp;
+            vrp.reserve(chunks.size() + 8 * kRowAlign + 1);
+            std::vector<int64_t> row_chunk; // chunk of each emitted row, -1 = padding row
+            row_chunk.reserve(chunks.size() + 8 * kRowAlign);
             uint64_t off = 0;
-            for (size_t k = 0; k < corder.size(); k++) {
-                vrow_ptr[k] = off;
-                off += chunks[corder[k]].len;
-                vid_of[corder[k]] = (uint32_t)(next_vid + k);
+            size_t k = 0;
+            for (int x = 0; x < groups; x++) {
+                p->xcd_begin[x] = next_vid + row_chunk.size();
+                while (k < corder.size() && grp[corder[k]] == x) {
+                    vrp.push_back(off);
+                    off += chunks[corder[k]].len;
+                    vid_of[corder[k]] = (uint32_t)(next_vid + row_chunk.size());
+                    row_chunk.push_back((int64_t)corder[k]);
+                    k++;
+                }
+                while (groups > 1 && row_chunk.size() % kRowAlign) {
+                    vrp.push_back(off);
+                    row_chunk.push_back(-1);
+                }
             }
-            vrow_ptr[chunks.size()] = off;
+            for (int x = groups; x <= 8; x++) p->xcd_begin[x] = next_vid + row_chunk.size();
+            p->xcd_groups = groups;
+            vrp.push_back(off);
+            vrow_ptr.swap(vrp);
             vsrc.resize(off);
 #pragma omp parallel for schedule(static, 4096)
-            for (int64_t k = 0; k < (int64_t)corder.size(); k++) {
-                const Chunk &c = chunks[corder[k]];
-                uint32_t *dst = vsrc.data() + vrow_ptr[k];
+            for (int64_t r = 0; r < (int64_t)row_chunk.size(); r++) {
+                if (row_chunk[r] < 0) continue;
+                const Chunk &c = chunks[row_chunk[r]];
+                uint32_t *dst = vsrc.data() + vrow_ptr[r];
                 for (uint64_t i = 0; i < c.len; i++) dst[i] = from_hot(rs[c.beg + i]);
             }
+            next_vid += row_chunk.size();
         }
-        next_vid += chunks.size();
         lap("emit level-1 lists");
         // per split row: the list of virtual ids it currently reads (flat, CSR-like)
         std::vector<uint64_t> lptr(hub_rows.size() + 1, 0);

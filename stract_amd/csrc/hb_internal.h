@@ -42,6 +42,8 @@ struct Plan {
     std::vector<uint64_t> row_ptr;    // (n_pad + nv) + 1 offsets into src
     std::vector<uint32_t> src;        // device indices (real < n_pad <= virtual ids)
     std::vector<uint64_t> level_begin; // virtual level l = rows [level_begin[l], level_begin[l+1])
+    uint64_t xcd_begin[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}; // level-1 rows of XCD group x = [xcd_begin[x], xcd_begin[x+1])
+    int xcd_groups = 1;
 };
 
 // Planner knobs (hb_options.chunk / tune[3..5]).
@@ -50,6 +52,7 @@ struct PlanTune {
     uint32_t band_w = 1u << 16;     // hottest band of the source index space, in counters (0 = no banding)
     uint32_t minc = 16;             // a band cut needs at least this many sources in the chunk
     uint32_t direct_max = 0;        // rows with at most this many sources are not split (0 = chunk)
+    bool xcd_map = true;            // XCD-affine groups of level-1 chunks (HB_FLAG_NO_XCD_MAP clears it)
     uint32_t world = 1;             // destination partition: rows are laid out as `world` equal slices,
                                     // slice g = the nodes with sid % world == g
 };

@@ -69,6 +69,10 @@ struct PassParams {
     const double *bias;       // HLL64_BIAS
     const uint8_t *lc;        // linear-counting table, 65 entries (index = zero registers)
     uint64_t row_lo, row_hi;  // rows of this launch (row_lo multiple of 64)
+    // XCD-affine launch (level-1 hub chunks): workgroup b runs on XCD b % 8 (observed dispatch rule; used for
+    // speed only) and takes its tiles from group b % 8 = rows [xcd_lo[b % 8], xcd_hi[b % 8])
+    int xcd_map;
+    uint64_t xcd_lo[8], xcd_hi[8];
     uint64_t n, n_pad;
     uint64_t slice_lo, slice_hi; // rows whose Kahan state this rank owns
     double t_plus_1;          // (t + 1) as f64, harmonic.rs:174
@@ -293,13 +297,22 @@ __global__ __launch_bounds__(256) void pass_kernel(const PassParams p)
     const int wave = threadIdx.x >> 6;
     const int g = lane >> 2, q = lane & 3;
     const int qshift = lane & ~3;
-    const uint64_t ntiles = (p.row_hi - p.row_lo + 63) >> 6;
+    // tile -> workgroup map: plain grid stride, or (hub chunks) per-XCD queues
+    uint64_t row_lo = p.row_lo, row_hi = p.row_hi, tile0 = blockIdx.x, tstride = gridDim.x;
+    if (!REAL && p.xcd_map) {
+        const int x = blockIdx.x & 7;
+        row_lo = p.xcd_lo[x];
+        row_hi = p.xcd_hi[x];
+        tile0 = blockIdx.x >> 3;
+        tstride = gridDim.x >> 3; // the grid is a multiple of 8
+    }
+    const uint64_t ntiles = (row_hi - row_lo + 63) >> 6;
     unsigned long long cnt_changed = 0, cnt_active = 0, cnt_rows = 0, cnt_out = 0;
 
-    for (uint64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const uint64_t row16 = p.row_lo + (tile << 6) + ((uint64_t)wave << 4); // first row of this wave
+    for (uint64_t tile = tile0; tile < ntiles; tile += tstride) {
+        const uint64_t row16 = row_lo + (tile << 6) + ((uint64_t)wave << 4); // first row of this wave
         const uint64_t row = row16 + (uint64_t)g;
-        const bool valid = row < p.row_hi;
+        const bool valid = row < row_hi;
         uint64_t beg = 0, end = 0;
         uint32_t od = 0; // out-degree of the row's node: issued with the row pointers, used in the epilogue
         if (valid) {
@@ -411,7 +424,7 @@ __global__ __launch_bounds__(256) void pass_kernel(const PassParams p)
         if (FUSED || !REAL) {
             // changed bits: real rows -> next frontier; virtual rows -> this pass' bits
             uint16_t *dst = REAL ? (uint16_t *)p.bits_wr : (uint16_t *)p.bits_rd;
-            if (lane == 0 && row16 < p.row_hi) dst[row16 >> 4] = (uint16_t)ch16;
+            if (lane == 0 && row16 < row_hi) dst[row16 >> 4] = (uint16_t)ch16;
         }
         if (REAL && FUSED) {
             cnt_changed += __popc(ch16);
@@ -434,7 +447,7 @@ __global__ __launch_bounds__(256) void pass_kernel(const PassParams p)
                 }
             }
             const uint32_t nk16 = pack16(__ballot(err_nz));
-            if (lane == 0 && row16 < p.row_hi && (nk16 | kd16)) ((uint16_t *)p.kdirty)[row16 >> 4] = (uint16_t)nk16;
+            if (lane == 0 && row16 < row_hi && (nk16 | kd16)) ((uint16_t *)p.kdirty)[row16 >> 4] = (uint16_t)nk16;
         }
     }
     // ---- totals: wave -> block -> one atomic per word into the block's counter stripe

@@ -115,7 +115,8 @@ def _expand(plan, row, n_pad):
 
 @pytest.mark.parametrize("chunk,flags,tune", [(4, 0, ()), (16, 0, ()), (64, 0, ()), (8, _lib.HB_FLAG_NO_REORDER, ()),
                                               (16, 0, (0, 0, 0, 6, 4)), (64, 0, (0, 0, 0, 5, 8, 16)),
-                                              (32, 0, (0, 0, 0, 1))])
+                                              (32, 0, (0, 0, 0, 1)), (16, _lib.HB_FLAG_NO_XCD_MAP, (0, 0, 0, 6, 4)),
+                                              (8, 0, (0, 0, 0, 4, 2))])
 def test_planner_invariants(chunk, flags, tune):
     # tune[3] = log2 of the hottest source band (1 = banding off), tune[4] = min sources before a band
     # cut, tune[5] = largest row that is not split
