@@ -231,7 +231,7 @@ std::string build_plan(uint64_t n, const uint64_t *row_ptr, const uint32_t *src,
     if (chunk < 4) chunk = 4;
     if (chunk > 4096) chunk = 4096;
     if (tune.direct_max == 0 || tune.direct_max > chunk) tune.direct_max = chunk;
-    if (tune.minc == 0) tune.minc = 16;
+    if (tune.minc == 0) tune.minc = 8;
     const uint64_t world = tune.world > 1 ? tune.world : 1;
     const bool timing = std::getenv("HB_PLAN_TIMING") != nullptr;
     double tmark = now_ms();

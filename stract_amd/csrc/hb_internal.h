@@ -50,7 +50,7 @@ struct Plan {
 struct PlanTune {
     uint32_t chunk = kDefaultChunk; // max sources per work row
     uint32_t band_w = 1u << 16;     // hottest band of the source index space, in counters (0 = no banding)
-    uint32_t minc = 16;             // a band cut needs at least this many sources in the chunk
+    uint32_t minc = 8;              // a band cut needs at least this many sources in the chunk
     uint32_t direct_max = 0;        // rows with at most this many sources are not split (0 = chunk)
     bool xcd_map = true;            // XCD-affine groups of level-1 chunks (HB_FLAG_NO_XCD_MAP clears it)
     uint32_t world = 1;             // destination partition: rows are laid out as `world` equal slices,
