@@ -77,6 +77,8 @@ typedef struct hb_edge {
                                         r mod world_size and must be given ALL in-edges of those nodes
                                         (records for other nodes are ignored); one ncclAllGather of the
                                         owned counter slices per pass instead of an all-reduce          */
+#define HB_FLAG_HOST_INGEST   0x400u /* hb_load_edges: reduce the records on the host (hb_host.cpp) instead of
+                                        on the GPU (hb_ingest.hip); same result                      */
 #define HB_FLAG_RCCL_SELF     0x80u /* world_size == 1 but still create a 1-rank communicator and run
                                        the collectives (exercises the RCCL call path on one GPU)   */
 

@@ -710,8 +710,11 @@ int hb_load_edges(hb_ctx *c, const hb_u128 *node_ids, uint64_t n, const hb_edge 
     if (rc) return rc;
     c->stats = hb_stats{};
     double t0 = now_ms();
-    std::string e = ingest_edges(node_ids, n, edges, m, &c->g);
-    if (!e.empty()) return fail(c, e.find("memory") != std::string::npos ? HB_ERR_NOMEM : HB_ERR_LIMIT, e);
+    // node/edge-set reduction: on the GPU (hb_ingest.hip) unless the host path is forced; identical output
+    std::string e = (c->opt.flags & HB_FLAG_HOST_INGEST) ? ingest_edges(node_ids, n, edges, m, &c->g)
+                                                        : gpu_ingest_edges((void *)c->stream, node_ids, n, edges, m, &c->g);
+    if (!e.empty())
+        return fail(c, e.find("memory") != std::string::npos ? HB_ERR_NOMEM : (e.find("hip") != std::string::npos ? HB_ERR_HIP : HB_ERR_LIMIT), e);
     if (dest_mode(c)) keep_owned_rows(&c->g, (uint64_t)c->opt.world_size, (uint64_t)c->opt.rank);
     c->stats.ms_ingest = now_ms() - t0;
     double ing = c->stats.ms_ingest;

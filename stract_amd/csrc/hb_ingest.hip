@@ -1,0 +1,329 @@
+// hb_ingest.hip - the reference's node-set / edge-set semantics on the GPU.
+//
+// Same contract as the host path (hb_host.cpp: ingest_edges), bit-identical output:
+//   node set   = every from / to id of every record, flagged ones included (or the caller's list)
+//                (crates/core/src/webgraph/store.rs:338-357), ascending numeric u128 order
+//   edge set   = FIRST record of each (from,to) pair in stream order (itertools::unique_by,
+//                store.rs:313), THEN dropped when rel_flags & SKIPPED_REL != 0 (harmonic.rs:36-49,131)
+//   output     = CSR by destination over sids (rank of the id), sources ascending inside a row
+//
+// Pipeline (one HIP stream; rocPRIM device primitives for the sorts / scans / selections):
+//   records --H2D in slabs--> unpack (from, to as u128 keys; "flagged" byte)
+//   node set: radix sort of the 2m keys + unique                      (128-bit keys)
+//   endpoints -> sids: binary search in the sorted id array
+//   (to_sid, from_sid) 64-bit keys + stream position: STABLE radix sort -> the first record of
+//   every pair is the head of its run -> flag filter on the head -> select -> CSR
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include <rocprim/rocprim.hpp>
+
+#include "hb_internal.h"
+
+namespace {
+
+using u128 = rocprim::uint128_t;
+
+#define IG_HIP(call)                                                                 \
+    do {                                                                             \
+        hipError_t e_ = (call);                                                      \
+        if (e_ != hipSuccess) return std::string(#call) + ": " + hipGetErrorString(e_); \
+    } while (0)
+
+struct DevMem {
+    std::vector<void *> ptrs;
+    ~DevMem()
+    {
+        for (void *p : ptrs) (void)hipFree(p);
+    }
+    template <typename T>
+    hipError_t alloc(T **out, size_t count)
+    {
+        void *p = nullptr;
+        hipError_t e = hipMalloc(&p, std::max<size_t>(count * sizeof(T), 256));
+        if (e == hipSuccess) ptrs.push_back(p);
+        *out = (T *)p;
+        return e;
+    }
+    void release(void *p)
+    {
+        for (auto &q : ptrs)
+            if (q == p) {
+                (void)hipFree(p);
+                q = nullptr;
+            }
+    }
+};
+
+__device__ __forceinline__ u128 make_key(const hb_u128 &v) { return ((u128)v.hi << 64) | (u128)v.lo; }
+
+// one thread per record of the slab: keys[2i] = from, keys[2i+1] = to, bad[i] = flagged
+__global__ __launch_bounds__(256) void unpack_kernel(const hb_edge *slab, uint64_t count, uint64_t base, u128 *keys, uint8_t *bad)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= count) return;
+    const hb_edge e = slab[i];
+    keys[2 * (base + i)] = make_key(e.from);
+    keys[2 * (base + i) + 1] = make_key(e.to);
+    bad[base + i] = (e.rel_flags & HB_SKIPPED_REL_MASK) ? 1 : 0;
+}
+
+__global__ __launch_bounds__(256) void ids_to_keys_kernel(const hb_u128 *ids, uint64_t n, u128 *keys)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) keys[i] = make_key(ids[i]);
+}
+
+__global__ __launch_bounds__(256) void keys_to_ids_kernel(const u128 *keys, uint64_t n, hb_u128 *ids)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) {
+        hb_u128 v;
+        v.lo = (uint64_t)keys[i];
+        v.hi = (uint64_t)(keys[i] >> 64);
+        ids[i] = v;
+    }
+}
+
+__device__ __forceinline__ uint32_t find_sid(const u128 *ids, uint64_t n, u128 key)
+{
+    uint64_t lo = 0, hi = n; // first index with ids[idx] >= key
+    while (lo < hi) {
+        const uint64_t mid = (lo + hi) >> 1;
+        if (ids[mid] < key) lo = mid + 1;
+        else hi = mid;
+    }
+    return (lo < n && ids[lo] == key) ? (uint32_t)lo : 0xFFFFFFFFu;
+}
+
+// one thread per record: 64-bit pair key (to_sid, from_sid), ~0 when an endpoint is unknown
+// (harmonic.rs:135: such records are ignored), and its stream position
+__global__ __launch_bounds__(256) void pair_keys_kernel(const u128 *endpoints, uint64_t m, const u128 *ids, uint64_t n,
+                                                        uint64_t *pair, uint64_t *pos)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= m) return;
+    const uint32_t f = find_sid(ids, n, endpoints[2 * i]);
+    const uint32_t t = find_sid(ids, n, endpoints[2 * i + 1]);
+    pair[i] = (f == 0xFFFFFFFFu || t == 0xFFFFFFFFu) ? ~0ull : (((uint64_t)t << 32) | (uint64_t)f);
+    pos[i] = i;
+}
+
+// after the stable sort: head[i] = first record of its pair; keep[i] = head, known endpoints, not flagged
+__global__ __launch_bounds__(256) void heads_kernel(const uint64_t *pair, const uint64_t *pos, const uint8_t *bad, uint64_t m,
+                                                    uint8_t *keep, unsigned long long *counts, uint32_t *row_count)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    bool head = false, kept = false;
+    if (i < m) {
+        const uint64_t k = pair[i];
+        head = (k != ~0ull) && (i == 0 || pair[i - 1] != k);
+        kept = head && !bad[pos[i]];
+        keep[i] = kept ? 1 : 0;
+        if (kept) atomicAdd(&row_count[k >> 32], 1u);
+    }
+    const unsigned long long nh = __popcll(__ballot(head));
+    if ((threadIdx.x & 63) == 0 && nh) atomicAdd(&counts[blockIdx.x & 63], nh); // striped; summed on the host
+}
+
+__global__ __launch_bounds__(256) void widen_kernel(const uint32_t *in, uint64_t n, uint64_t *out)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = in[i];
+}
+
+struct LowHalf {
+    __device__ uint32_t operator()(uint64_t k) const { return (uint32_t)k; }
+};
+
+unsigned grid_for(uint64_t count) { return (unsigned)((count + 255) / 256); }
+
+} // namespace
+
+namespace hb {
+
+std::string gpu_ingest_edges(void *stream_v, const hb_u128 *node_ids, uint64_t n_in, const hb_edge *edges, uint64_t m,
+                             DenseGraph *out)
+{
+    hipStream_t stream = (hipStream_t)stream_v;
+    out->ids.clear();
+    out->row_ptr.clear();
+    out->src.clear();
+    out->m_input = m;
+    out->m_unique = 0;
+    if (m && !edges) return "edges == NULL with m > 0";
+    DevMem mem;
+    void *tmp = nullptr;
+    size_t tmp_bytes = 0;
+    auto need_tmp = [&](size_t bytes) -> hipError_t {
+        if (bytes <= tmp_bytes) return hipSuccess;
+        if (tmp) mem.release(tmp);
+        tmp_bytes = bytes + (bytes >> 3);
+        char *p = nullptr;
+        hipError_t e = mem.alloc(&p, tmp_bytes);
+        tmp = p;
+        return e;
+    };
+
+    // ---- records -> endpoint keys + flagged bytes (slab-wise H2D)
+    u128 *d_end = nullptr; // 2m endpoint keys in stream order
+    uint8_t *d_bad = nullptr;
+    IG_HIP(mem.alloc(&d_end, 2 * m));
+    IG_HIP(mem.alloc(&d_bad, m));
+    {
+        const uint64_t slab = 1ull << 22; // 4 Mi records = 160 MiB per slab, two slabs in flight
+        hb_edge *d_slab[2] = {nullptr, nullptr};
+        IG_HIP(mem.alloc(&d_slab[0], std::min<uint64_t>(slab, std::max<uint64_t>(m, 1))));
+        IG_HIP(mem.alloc(&d_slab[1], std::min<uint64_t>(slab, std::max<uint64_t>(m, 1))));
+        hipEvent_t done[2];
+        IG_HIP(hipEventCreateWithFlags(&done[0], hipEventDisableTiming));
+        IG_HIP(hipEventCreateWithFlags(&done[1], hipEventDisableTiming));
+        int b = 0;
+        for (uint64_t base = 0; base < m; base += slab, b ^= 1) {
+            const uint64_t cnt = std::min(slab, m - base);
+            IG_HIP(hipEventSynchronize(done[b])); // the kernel that last read this slab buffer has finished
+            IG_HIP(hipMemcpyAsync(d_slab[b], edges + base, cnt * sizeof(hb_edge), hipMemcpyHostToDevice, stream));
+            hipLaunchKernelGGL(unpack_kernel, dim3(grid_for(cnt)), dim3(256), 0, stream, (const hb_edge *)d_slab[b], cnt, base, d_end, d_bad);
+            IG_HIP(hipGetLastError());
+            IG_HIP(hipEventRecord(done[b], stream));
+        }
+        IG_HIP(hipStreamSynchronize(stream));
+        (void)hipEventDestroy(done[0]);
+        (void)hipEventDestroy(done[1]);
+        mem.release(d_slab[0]);
+        mem.release(d_slab[1]);
+    }
+
+    // ---- node set: sorted unique u128 keys
+    const uint64_t cand = (node_ids && n_in) ? n_in : 2 * m;
+    u128 *d_keys = nullptr, *d_sorted = nullptr, *d_ids = nullptr;
+    uint64_t n = 0;
+    if (cand) {
+        IG_HIP(mem.alloc(&d_keys, cand));
+        IG_HIP(mem.alloc(&d_sorted, cand));
+        if (node_ids && n_in) {
+            hb_u128 *d_raw = nullptr;
+            IG_HIP(mem.alloc(&d_raw, n_in));
+            IG_HIP(hipMemcpyAsync(d_raw, node_ids, n_in * sizeof(hb_u128), hipMemcpyHostToDevice, stream));
+            hipLaunchKernelGGL(ids_to_keys_kernel, dim3(grid_for(n_in)), dim3(256), 0, stream, (const hb_u128 *)d_raw, n_in, d_keys);
+            IG_HIP(hipGetLastError());
+            IG_HIP(hipStreamSynchronize(stream));
+            mem.release(d_raw);
+        } else {
+            IG_HIP(hipMemcpyAsync(d_keys, d_end, cand * sizeof(u128), hipMemcpyDeviceToDevice, stream));
+        }
+        size_t bytes = 0;
+        IG_HIP(rocprim::radix_sort_keys(nullptr, bytes, d_keys, d_sorted, (size_t)cand, 0, 128, stream));
+        IG_HIP(need_tmp(bytes));
+        IG_HIP(rocprim::radix_sort_keys(tmp, bytes, d_keys, d_sorted, (size_t)cand, 0, 128, stream));
+        // unique -> d_keys (reused as the output), count on the device
+        uint64_t *d_n = nullptr;
+        IG_HIP(mem.alloc(&d_n, 1));
+        bytes = 0;
+        IG_HIP(rocprim::unique(nullptr, bytes, d_sorted, d_keys, d_n, (size_t)cand, rocprim::equal_to<u128>(), stream));
+        IG_HIP(need_tmp(bytes));
+        IG_HIP(rocprim::unique(tmp, bytes, d_sorted, d_keys, d_n, (size_t)cand, rocprim::equal_to<u128>(), stream));
+        IG_HIP(hipMemcpyAsync(&n, d_n, sizeof(uint64_t), hipMemcpyDeviceToHost, stream));
+        IG_HIP(hipStreamSynchronize(stream));
+        mem.release(d_sorted);
+        d_ids = d_keys;
+    }
+    if (n >= 0xFFFFFFFFull - (1u << 20)) return "too many nodes (n must be < 2^32 - 2^20)";
+    try {
+        out->ids.resize(n);
+        out->row_ptr.assign(n + 1, 0);
+    } catch (const std::bad_alloc &) {
+        return "out of host memory for the node set";
+    }
+    if (n) {
+        hb_u128 *d_out_ids = nullptr;
+        IG_HIP(mem.alloc(&d_out_ids, n));
+        hipLaunchKernelGGL(keys_to_ids_kernel, dim3(grid_for(n)), dim3(256), 0, stream, (const u128 *)d_ids, n, d_out_ids);
+        IG_HIP(hipGetLastError());
+        IG_HIP(hipMemcpyAsync(out->ids.data(), d_out_ids, n * sizeof(hb_u128), hipMemcpyDeviceToHost, stream));
+        IG_HIP(hipStreamSynchronize(stream));
+        mem.release(d_out_ids);
+    }
+    if (n == 0 || m == 0) return "";
+
+    // ---- pair keys, stable sort by (to, from): the first record of every pair heads its run
+    uint64_t *d_pair = nullptr, *d_pos = nullptr, *d_pair_s = nullptr, *d_pos_s = nullptr;
+    IG_HIP(mem.alloc(&d_pair, m));
+    IG_HIP(mem.alloc(&d_pos, m));
+    hipLaunchKernelGGL(pair_keys_kernel, dim3(grid_for(m)), dim3(256), 0, stream, (const u128 *)d_end, m, (const u128 *)d_ids, n, d_pair, d_pos);
+    IG_HIP(hipGetLastError());
+    IG_HIP(hipStreamSynchronize(stream));
+    mem.release(d_end);
+    mem.release(d_ids);
+    IG_HIP(mem.alloc(&d_pair_s, m));
+    IG_HIP(mem.alloc(&d_pos_s, m));
+    {
+        size_t bytes = 0;
+        IG_HIP(rocprim::radix_sort_pairs(nullptr, bytes, d_pair, d_pair_s, d_pos, d_pos_s, (size_t)m, 0, 64, stream));
+        IG_HIP(need_tmp(bytes));
+        IG_HIP(rocprim::radix_sort_pairs(tmp, bytes, d_pair, d_pair_s, d_pos, d_pos_s, (size_t)m, 0, 64, stream));
+    }
+    IG_HIP(hipStreamSynchronize(stream));
+    mem.release(d_pair);
+    mem.release(d_pos);
+
+    // ---- heads, flag filter, row counts
+    uint8_t *d_keep = nullptr;
+    unsigned long long *d_counts = nullptr;
+    uint32_t *d_row_count = nullptr;
+    IG_HIP(mem.alloc(&d_keep, m));
+    IG_HIP(mem.alloc(&d_counts, 64));
+    IG_HIP(mem.alloc(&d_row_count, n + 1));
+    IG_HIP(hipMemsetAsync(d_counts, 0, 64 * sizeof(unsigned long long), stream));
+    IG_HIP(hipMemsetAsync(d_row_count, 0, (n + 1) * sizeof(uint32_t), stream));
+    hipLaunchKernelGGL(heads_kernel, dim3(grid_for(m)), dim3(256), 0, stream, (const uint64_t *)d_pair_s, (const uint64_t *)d_pos_s,
+                       (const uint8_t *)d_bad, m, d_keep, d_counts, d_row_count);
+    IG_HIP(hipGetLastError());
+    unsigned long long h_counts[64];
+    IG_HIP(hipMemcpyAsync(h_counts, d_counts, sizeof(h_counts), hipMemcpyDeviceToHost, stream));
+
+    // ---- sources of the kept records, in (to, from) order
+    uint32_t *d_src = nullptr;
+    uint64_t *d_meff = nullptr;
+    IG_HIP(mem.alloc(&d_src, m));
+    IG_HIP(mem.alloc(&d_meff, 1));
+    {
+        auto low = rocprim::make_transform_iterator(d_pair_s, LowHalf());
+        size_t bytes = 0;
+        IG_HIP(rocprim::select(nullptr, bytes, low, d_keep, d_src, d_meff, (size_t)m, stream));
+        IG_HIP(need_tmp(bytes));
+        IG_HIP(rocprim::select(tmp, bytes, low, d_keep, d_src, d_meff, (size_t)m, stream));
+    }
+    uint64_t m_eff = 0;
+    IG_HIP(hipMemcpyAsync(&m_eff, d_meff, sizeof(uint64_t), hipMemcpyDeviceToHost, stream));
+
+    // ---- row pointers: exclusive scan of the per-destination counts
+    uint64_t *d_cnt64 = nullptr, *d_row_ptr = nullptr;
+    IG_HIP(mem.alloc(&d_cnt64, n + 1));
+    IG_HIP(mem.alloc(&d_row_ptr, n + 1));
+    hipLaunchKernelGGL(widen_kernel, dim3(grid_for(n + 1)), dim3(256), 0, stream, (const uint32_t *)d_row_count, n + 1, d_cnt64);
+    IG_HIP(hipGetLastError());
+    {
+        size_t bytes = 0;
+        IG_HIP(rocprim::exclusive_scan(nullptr, bytes, d_cnt64, d_row_ptr, (uint64_t)0, (size_t)(n + 1), rocprim::plus<uint64_t>(), stream));
+        IG_HIP(need_tmp(bytes));
+        IG_HIP(rocprim::exclusive_scan(tmp, bytes, d_cnt64, d_row_ptr, (uint64_t)0, (size_t)(n + 1), rocprim::plus<uint64_t>(), stream));
+    }
+    IG_HIP(hipStreamSynchronize(stream));
+    for (int s = 0; s < 64; s++) out->m_unique += h_counts[s];
+    try {
+        out->src.resize(m_eff);
+    } catch (const std::bad_alloc &) {
+        return "out of host memory for the edge set";
+    }
+    IG_HIP(hipMemcpyAsync(out->row_ptr.data(), d_row_ptr, (n + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost, stream));
+    if (m_eff) IG_HIP(hipMemcpyAsync(out->src.data(), d_src, m_eff * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+    IG_HIP(hipStreamSynchronize(stream));
+    if (out->row_ptr[n] != m_eff) return "gpu ingest: row pointer / edge count mismatch";
+    return "";
+}
+
+} // namespace hb

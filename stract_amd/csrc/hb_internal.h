@@ -63,6 +63,9 @@ struct PlanTune {
 std::string ingest_edges(const hb_u128 *node_ids, uint64_t n, const hb_edge *edges, uint64_t m,
                          DenseGraph *out);
 void keep_owned_rows(DenseGraph *g, uint64_t world, uint64_t rank);
+// --- hb_ingest.hip: the same reduction on the GPU (stream = hipStream_t); identical output
+std::string gpu_ingest_edges(void *stream, const hb_u128 *node_ids, uint64_t n, const hb_edge *edges, uint64_t m,
+                             DenseGraph *out);
 std::string check_dense(const hb_u128 *sorted_ids, uint64_t n, const uint64_t *row_ptr,
                         const uint32_t *src, uint64_t m);
 // out_degree[sid] over the local edges.

@@ -884,7 +884,12 @@ __global__ __launch_bounds__(256) void init_kernel(const uint64_t *id_low, const
     }
     a[row * 4 + q] = v;
     b[row * 4 + q] = v;
-    const uint64_t sz = hll_size_quad(v, raw, bias, lc);
+    // size() of a counter with exactly one register set: 63 zero registers -> the linear-counting branch
+    // (hyperloglog.rs:4504-4515) -> lc[63]; the general estimator gives the same value by construction
+    // (tests/test_gpu.py compares the cached sizes with the oracle's after hb_begin)
+    (void)raw;
+    (void)bias;
+    const uint64_t sz = (uint64_t)lc[63];
     if (q == 0) {
         ksum[row] = 0.0;
         kerr[row] = 0.0;

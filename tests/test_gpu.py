@@ -200,6 +200,32 @@ def test_salted_edge_records_match_faithful_oracle(gpu_ctx_factory):
     assert np.array_equal(ids2, fids) and np.array_equal(vals2.view(np.uint64), fvals.view(np.uint64))
 
 
+def test_gpu_ingest_equals_host_ingest(gpu_ctx_factory):
+    """hb_ingest.hip (rocPRIM sorts on the device) against hb_host.cpp and the plain-Python statement of
+    store.rs:297-357 + harmonic.rs:131: node set, first-occurrence de-duplication, flag filter, CSR."""
+    g = synth.RmatGraph(12, 30_000)
+    e = g.edges(salt=1, salt_seed=11)
+    cases = [(e, None), (e[:0], None), (e[:1], None)]
+    # explicit node list (any order, duplicates, one endpoint of some records missing from it)
+    ids_h, rp_h, src_h, mu_h = _lib.host_ingest(e)
+    cases.append((e, np.concatenate([ids_h[::-1], ids_h[:7]])))
+    cases.append((e, ids_h[: len(ids_h) // 2]))
+    for edges, nodes in cases:
+        got = []
+        for flags in (0, _lib.HB_FLAG_HOST_INGEST):
+            with gpu_ctx_factory(flags=flags) as ctx:
+                ctx.load_edges(edges, nodes)
+                st = ctx.stats()
+                got.append((ctx.graph(), st["n"], st["m_unique"], st["m_eff"], st["m_input"]))
+        (ga, *sa), (gb, *sb) = got
+        assert sa == sb
+        for x, y in zip(ga, gb):
+            assert np.array_equal(x, y)
+        ref = _lib.host_ingest(edges, nodes)
+        assert np.array_equal(ga[0], ref[0]) and np.array_equal(ga[1], ref[1]) and np.array_equal(ga[2], ref[2])
+        assert sa[1] == ref[3]
+
+
 def test_hub_rows_and_isolated_nodes(gpu_ctx_factory):
     # a 3000-source star (multi-level virtual rows at chunk 8), a long chain (many passes in
     # frontier mode) and nodes that only appear on flagged edges (count in n, no output row)
