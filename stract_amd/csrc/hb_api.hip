@@ -255,19 +255,30 @@ int plan_and_upload(hb_ctx *c)
     bool reorder = !(c->opt.flags & HB_FLAG_NO_REORDER);
     if (multi_rank(c) && !c->comm) reorder = false; // logical ranks without a communicator
     {
-        count_out_degree(c->g.row_ptr.data(), c->g.src.data(), n, &outdeg);
-        if (c->comm && n) {
-            uint32_t *d_deg = nullptr;
+        // out-degree histogram on the device (the host version is a scatter of m random increments)
+        const uint64_t m_local = n ? c->g.row_ptr[n] : 0;
+        outdeg.assign(n, 0);
+        if (n) {
+            uint32_t *d_deg = nullptr, *d_rawsrc = nullptr;
             HB_HIP(hipMalloc((void **)&d_deg, n * sizeof(uint32_t)));
-            hipError_t e = hipMemcpyAsync(d_deg, outdeg.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream);
+            hipError_t e = hipMalloc((void **)&d_rawsrc, std::max<uint64_t>(m_local, 1) * sizeof(uint32_t));
             ncclResult_t r = ncclSuccess;
-            if (e == hipSuccess) r = ncclAllReduce(d_deg, d_deg, n, ncclUint32, ncclSum, c->comm, c->stream);
+            if (e == hipSuccess) e = hipMemsetAsync(d_deg, 0, n * sizeof(uint32_t), c->stream);
+            if (e == hipSuccess && m_local)
+                e = hipMemcpyAsync(d_rawsrc, c->g.src.data(), m_local * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream);
+            if (e == hipSuccess && m_local) {
+                const unsigned blocks = (unsigned)std::min<uint64_t>((m_local + 255) / 256, (uint64_t)c->num_cu * 16);
+                hipLaunchKernelGGL(hbk::histogram_kernel, dim3(blocks), dim3(256), 0, c->stream, (const uint32_t *)d_rawsrc, m_local, d_deg);
+                e = hipGetLastError();
+            }
+            if (e == hipSuccess && c->comm) r = ncclAllReduce(d_deg, d_deg, n, ncclUint32, ncclSum, c->comm, c->stream);
             if (e == hipSuccess && r == ncclSuccess)
                 e = hipMemcpyAsync(outdeg.data(), d_deg, n * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream);
             if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
             (void)hipFree(d_deg);
+            if (d_rawsrc) (void)hipFree(d_rawsrc);
             if (r != ncclSuccess) return fail(c, HB_ERR_RCCL, std::string("out-degree all-reduce: ") + ncclGetErrorString(r));
-            if (e != hipSuccess) return fail(c, HB_ERR_HIP, std::string("out-degree all-reduce: ") + hipGetErrorString(e));
+            if (e != hipSuccess) return fail(c, HB_ERR_HIP, std::string("out-degree histogram: ") + hipGetErrorString(e));
         }
     }
     PlanTune pt = plan_tune(c->opt.chunk, c->opt.tune);

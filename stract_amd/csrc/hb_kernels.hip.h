@@ -766,6 +766,12 @@ __global__ __launch_bounds__(256) void sparse_rows_kernel(const SparseParams sp)
     }
 }
 
+// out-degree histogram of a source list (load time)
+__global__ __launch_bounds__(256) void histogram_kernel(const uint32_t *src, uint64_t m, uint32_t *count)
+{
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < m; i += (uint64_t)gridDim.x * 256) atomicAdd(&count[src[i]], 1u);
+}
+
 // ---- transposed work-row graph (built once per load) ------------------------------------------
 // count[s] = number of work rows reading s; then (after a host-side exclusive scan) fill.
 __global__ __launch_bounds__(256) void transpose_count_kernel(const uint64_t *row_ptr, const uint32_t *src, uint64_t rows,
