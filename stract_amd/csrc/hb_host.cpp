@@ -23,9 +23,11 @@
 #include <parallel/algorithm>
 #define HB_SORT(b, e) __gnu_parallel::sort((b), (e))
 #define HB_SORT_CMP(b, e, c) __gnu_parallel::sort((b), (e), (c))
+#define HB_STABLE_SORT_CMP(b, e, c) __gnu_parallel::stable_sort((b), (e), (c))
 #else
 #define HB_SORT(b, e) std::sort((b), (e))
 #define HB_SORT_CMP(b, e, c) std::sort((b), (e), (c))
+#define HB_STABLE_SORT_CMP(b, e, c) std::stable_sort((b), (e), (c))
 #endif
 
 namespace hb {
@@ -292,7 +294,8 @@ std::string build_plan(uint64_t n, const uint64_t *row_ptr, const uint32_t *src,
             rp[d + 1] = rp[d] + (s == kNone ? 0 : (row_ptr[s + 1] - row_ptr[s]));
         }
         std::vector<uint32_t> rs(p->m_eff);
-#pragma omp parallel for schedule(dynamic, 1024)
+        // small dynamic chunks: in device order the biggest hubs sit next to each other at the front
+#pragma omp parallel for schedule(dynamic, 32)
         for (int64_t d = 0; d < (int64_t)n_pad; d++) {
             uint32_t s = p->order[d];
             if (s == kNone) continue;
@@ -364,7 +367,7 @@ std::string build_plan(uint64_t n, const uint64_t *row_ptr, const uint32_t *src,
         std::vector<uint8_t> grp(chunks.size(), 0);
         std::vector<uint32_t> corder(chunks.size());
         std::iota(corder.begin(), corder.end(), 0u);
-        std::stable_sort(corder.begin(), corder.end(), [&](uint32_t a, uint32_t b2) {
+        HB_STABLE_SORT_CMP(corder.begin(), corder.end(), [&](uint32_t a, uint32_t b2) {
             if (chunks[a].key != chunks[b2].key) return chunks[a].key < chunks[b2].key;
             return chunks[a].len > chunks[b2].len;
         });
@@ -388,7 +391,7 @@ std::string build_plan(uint64_t n, const uint64_t *row_ptr, const uint32_t *src,
                 grp[k] = (uint8_t)best;
                 load[best] += chunks[k].len + 4;
             }
-            std::stable_sort(corder.begin(), corder.end(), [&](uint32_t a, uint32_t b2) { return grp[a] < grp[b2]; });
+            HB_STABLE_SORT_CMP(corder.begin(), corder.end(), [&](uint32_t a, uint32_t b2) { return grp[a] < grp[b2]; });
         }
         lap("sort chunks");
         std::vector<uint32_t> vid_of(chunks.size());
