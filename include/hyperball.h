@@ -188,6 +188,12 @@ int hb_result_count(hb_ctx *ctx, uint64_t *count);
  * Writes min(count, cap) entries; ids or vals may be NULL. */
 int hb_result_copy(hb_ctx *ctx, hb_u128 *ids, double *vals, uint64_t cap);
 
+/* The second half of store_harmonic (centrality/mod.rs:92-103): ranks[j] = position of the j-th result
+ * (hb_result_copy order) when all results are sorted by (Reverse(f64::total_cmp(centrality)), NodeID
+ * ascending) - the value written to the "harmonic_rank" store.  Computed on the GPU (stable radix sort).
+ * cap must be >= hb_result_count. */
+int hb_result_ranks(hb_ctx *ctx, uint64_t *ranks, uint64_t cap);
+
 /* ---- multi-GPU (one process per GPU, RCCL over xGMI) -------------------------------------- */
 /* Rank 0 calls this and distributes the 128 bytes (e.g. torch.distributed broadcast);
  * every rank puts them in hb_options.rccl_id. */

@@ -671,3 +671,40 @@ uint64_t hbo_faithful_run(const hbo_edge *edges, uint64_t m, hbo_u128 *out_ids, 
     if (stats) *stats = st;
     return overflow ? (uint64_t)-1 : k;
 }
+
+/* ------------------------------------------------------------------------------- */
+/* harmonic_rank: the second half of store_harmonic (centrality/mod.rs:92-103)        */
+/* ------------------------------------------------------------------------------- */
+/* ranks[j] = position of result j when the results (given in ascending NodeID order) are sorted
+ * by (Reverse(SortableFloat(centrality)), NodeID): SortableFloat::cmp = f64::total_cmp
+ * (crates/core/src/lib.rs:259-263). */
+typedef struct { uint64_t key; uint64_t idx; } hbo_rank_item;
+
+static uint64_t total_cmp_key(double v)
+{
+    /* f64::total_cmp: compare the bit patterns as sign-magnitude integers */
+    uint64_t b;
+    memcpy(&b, &v, 8);
+    return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+}
+
+static int rank_item_cmp(const void *pa, const void *pb)
+{
+    const hbo_rank_item *a = (const hbo_rank_item *)pa, *b = (const hbo_rank_item *)pb;
+    if (a->key != b->key) return a->key > b->key ? -1 : 1; /* Reverse: larger centrality first */
+    return a->idx < b->idx ? -1 : (a->idx > b->idx ? 1 : 0); /* then NodeID ascending */
+}
+
+int hbo_rank_results(const double *vals, uint64_t k, uint64_t *ranks)
+{
+    hbo_rank_item *items = (hbo_rank_item *)malloc((k ? k : 1) * sizeof(*items));
+    if (!items) return -1;
+    for (uint64_t i = 0; i < k; i++) {
+        items[i].key = total_cmp_key(vals[i]);
+        items[i].idx = i;
+    }
+    qsort(items, k, sizeof(*items), rank_item_cmp);
+    for (uint64_t r = 0; r < k; r++) ranks[items[r].idx] = r;
+    free(items);
+    return 0;
+}

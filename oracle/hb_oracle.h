@@ -137,6 +137,10 @@ uint64_t hbo_faithful_run(const hbo_edge *edges, uint64_t m, hbo_u128 *out_ids,
 uint64_t hbo_bloom_num_bits(uint64_t estimated_items, double fp);
 uint64_t hbo_bloom_estimate_card(uint64_t num_bits, uint64_t num_ones);
 
+/* harmonic_rank as store_harmonic computes it (centrality/mod.rs:92-103): results in ascending
+ * NodeID order in, ranks[j] = position in the (Reverse(total_cmp(centrality)), NodeID) order. */
+int hbo_rank_results(const double *vals, uint64_t k, uint64_t *ranks);
+
 #ifdef __cplusplus
 }
 #endif

@@ -100,6 +100,17 @@ def hll_sizes(regs, variant=BSEARCH_RUST_1_82):
     return out
 
 
+def rank_results(vals):
+    """harmonic_rank of results given in ascending NodeID order (store_harmonic, centrality/mod.rs:92-103)."""
+    L = load()
+    vals = np.ascontiguousarray(vals, dtype=np.float64)
+    out = np.zeros(len(vals), dtype=np.uint64)
+    L.hbo_rank_results.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p]
+    L.hbo_rank_results.restype = ctypes.c_int
+    assert L.hbo_rank_results(vals.ctypes.data if len(vals) else None, len(vals), out.ctypes.data if len(vals) else None) == 0
+    return out
+
+
 def kahan_sum(values):
     s, e = ctypes.c_double(0.0), ctypes.c_double(0.0)
     L = load()

@@ -111,6 +111,7 @@ _SIGNATURES = [
     ("hb_get_pass_stats", ctypes.c_int, [_P, _U64, ctypes.POINTER(HbPassStats)]),
     ("hb_result_count", ctypes.c_int, [_P, ctypes.POINTER(_U64)]),
     ("hb_result_copy", ctypes.c_int, [_P, _P, _P, _U64]),
+    ("hb_result_ranks", ctypes.c_int, [_P, _P, _U64]),
     ("hb_rccl_unique_id", ctypes.c_int, [_P]),
     ("hb_device_count", ctypes.c_int, [ctypes.POINTER(ctypes.c_int)]),
     ("hb_device_name", ctypes.c_int, [_P, ctypes.c_char_p, _U64]),
@@ -302,6 +303,14 @@ class Context:
         vals = np.zeros(k.value, dtype=np.float64)
         self._check(self.lib.hb_result_copy(self.h, _ptr(ids), _ptr(vals), k.value))
         return ids, vals
+
+    def ranks(self):
+        """harmonic_rank of every result (store_harmonic order), aligned with results()."""
+        k = ctypes.c_uint64(0)
+        self._check(self.lib.hb_result_count(self.h, ctypes.byref(k)))
+        out = np.zeros(k.value, dtype=np.uint64)
+        self._check(self.lib.hb_result_ranks(self.h, _ptr(out), k.value))
+        return out
 
     # -- debug exports
     def n(self):

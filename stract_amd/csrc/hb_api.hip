@@ -941,6 +941,18 @@ int hb_result_copy(hb_ctx *c, hb_u128 *ids, double *vals, uint64_t cap)
     return HB_OK;
 }
 
+int hb_result_ranks(hb_ctx *c, uint64_t *ranks, uint64_t cap)
+{
+    if (!c || (cap && !ranks)) return HB_ERR_INVALID;
+    if (!c->finished) return fail(c, HB_ERR_INVALID, "no results: hb_run / hb_finish not called");
+    if (cap < c->res_count) return fail(c, HB_ERR_INVALID, "hb_result_ranks: cap < hb_result_count");
+    int rc = set_device(c);
+    if (rc) return rc;
+    std::string e = gpu_rank_results((void *)c->stream, c->d_out, c->plan.n, c->res_count, ranks);
+    if (!e.empty()) return fail(c, HB_ERR_HIP, e);
+    return HB_OK;
+}
+
 // ---- debug exports ------------------------------------------------------------------------
 int hb_debug_copy_registers(hb_ctx *c, uint8_t *out)
 {

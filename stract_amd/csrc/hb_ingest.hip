@@ -135,6 +135,26 @@ __global__ __launch_bounds__(256) void widen_kernel(const uint32_t *in, uint64_t
     if (i < n) out[i] = in[i];
 }
 
+// position of every kept result in the order (Reverse(total_cmp(centrality)), NodeID ascending)
+// - the rank that store_harmonic writes to the "harmonic_rank" store
+// (crates/core/src/webgraph/centrality/mod.rs:92-103, SortableFloat = f64::total_cmp, lib.rs:259-263).
+// vals: one f64 per node in ascending-NodeID order, negative = absent (hb_finish).
+__global__ __launch_bounds__(256) void rank_keys_kernel(const double *vals, uint64_t n, uint64_t *key, uint8_t *keep)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const double v = vals[i];
+    keep[i] = v >= 0.0 ? 1 : 0;
+    uint64_t b = (uint64_t)__double_as_longlong(v);
+    b ^= (b >> 63) ? ~0ull : 0x8000000000000000ull; // total_cmp order as unsigned order
+    key[i] = ~b;                                    // Reverse(...)
+}
+__global__ __launch_bounds__(256) void rank_scatter_kernel(const uint64_t *sorted_idx, uint64_t k, uint64_t *rank)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < k) rank[sorted_idx[i]] = i;
+}
+
 struct LowHalf {
     __device__ uint32_t operator()(uint64_t k) const { return (uint32_t)k; }
 };
@@ -323,6 +343,54 @@ std::string gpu_ingest_edges(void *stream_v, const hb_u128 *node_ids, uint64_t n
     if (m_eff) IG_HIP(hipMemcpyAsync(out->src.data(), d_src, m_eff * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
     IG_HIP(hipStreamSynchronize(stream));
     if (out->row_ptr[n] != m_eff) return "gpu ingest: row pointer / edge count mismatch";
+    return "";
+}
+
+// ranks[j] for the j-th kept result (ascending NodeID): its position in the store_harmonic order.
+std::string gpu_rank_results(void *stream_v, const double *d_vals, uint64_t n, uint64_t expect, uint64_t *ranks_out)
+{
+    hipStream_t stream = (hipStream_t)stream_v;
+    if (n == 0 || expect == 0) return "";
+    DevMem mem;
+    uint64_t *d_key = nullptr, *d_kkey = nullptr, *d_kkey_s = nullptr, *d_idx_s = nullptr, *d_rank = nullptr, *d_cnt = nullptr;
+    uint8_t *d_keep = nullptr;
+    IG_HIP(mem.alloc(&d_key, n));
+    IG_HIP(mem.alloc(&d_keep, n));
+    IG_HIP(mem.alloc(&d_kkey, expect));
+    IG_HIP(mem.alloc(&d_kkey_s, expect));
+    IG_HIP(mem.alloc(&d_idx_s, expect));
+    IG_HIP(mem.alloc(&d_rank, expect));
+    IG_HIP(mem.alloc(&d_cnt, 1));
+    hipLaunchKernelGGL(rank_keys_kernel, dim3(grid_for(n)), dim3(256), 0, stream, d_vals, n, d_key, d_keep);
+    IG_HIP(hipGetLastError());
+    void *tmp = nullptr;
+    size_t bytes = 0, cap = 0;
+    auto need = [&](size_t b) -> hipError_t {
+        if (b <= cap) return hipSuccess;
+        char *p = nullptr;
+        hipError_t e = mem.alloc(&p, b);
+        tmp = p;
+        cap = b;
+        return e;
+    };
+    // kept keys in ascending-NodeID order; their result indices are 0..k-1 in that order
+    IG_HIP(rocprim::select(nullptr, bytes, d_key, d_keep, d_kkey, d_cnt, (size_t)n, stream));
+    IG_HIP(need(bytes));
+    IG_HIP(rocprim::select(tmp, bytes, d_key, d_keep, d_kkey, d_cnt, (size_t)n, stream));
+    uint64_t k = 0;
+    IG_HIP(hipMemcpyAsync(&k, d_cnt, sizeof(uint64_t), hipMemcpyDeviceToHost, stream));
+    IG_HIP(hipStreamSynchronize(stream));
+    if (k != expect) return "gpu rank: kept-result count mismatch";
+    auto iota = rocprim::make_counting_iterator<uint64_t>(0);
+    bytes = 0;
+    // stable: equal centralities keep ascending NodeID order
+    IG_HIP(rocprim::radix_sort_pairs(nullptr, bytes, d_kkey, d_kkey_s, iota, d_idx_s, (size_t)k, 0, 64, stream));
+    IG_HIP(need(bytes));
+    IG_HIP(rocprim::radix_sort_pairs(tmp, bytes, d_kkey, d_kkey_s, iota, d_idx_s, (size_t)k, 0, 64, stream));
+    hipLaunchKernelGGL(rank_scatter_kernel, dim3(grid_for(k)), dim3(256), 0, stream, (const uint64_t *)d_idx_s, k, d_rank);
+    IG_HIP(hipGetLastError());
+    IG_HIP(hipMemcpyAsync(ranks_out, d_rank, k * sizeof(uint64_t), hipMemcpyDeviceToHost, stream));
+    IG_HIP(hipStreamSynchronize(stream));
     return "";
 }
 

@@ -200,6 +200,25 @@ def test_salted_edge_records_match_faithful_oracle(gpu_ctx_factory):
     assert np.array_equal(ids2, fids) and np.array_equal(vals2.view(np.uint64), fvals.view(np.uint64))
 
 
+def test_result_ranks_match_store_harmonic_order(gpu_ctx_factory):
+    # centrality/mod.rs:92-103: harmonic_rank = position by (Reverse(total_cmp(centrality)), NodeID)
+    g = synth.RmatGraph(13, 60_000)
+    with gpu_ctx_factory() as ctx:
+        ctx.load_dense(g.ids, g.row_ptr, g.src)
+        ctx.run()
+        ids, vals = ctx.results()
+        ranks = ctx.ranks()
+    assert len(ranks) == len(vals) and sorted(ranks.tolist()) == list(range(len(vals)))
+    assert np.array_equal(ranks, hbo.rank_results(vals))
+    assert len(np.unique(vals)) < len(vals)  # ties exist: the NodeID tie-break is exercised
+    hc = HarmonicCentrality.calculate(graphs.fixture_graph())
+    with gpu_ctx_factory() as ctx:
+        ctx.load_edges(graphs.fixture_graph().host_edges())
+        ctx.run()
+        assert ctx.ranks().tolist() == [1, 2, 0]  # C > A > B (harmonic.rs:465-473)
+        assert hc.len() == 3
+
+
 def test_gpu_ingest_equals_host_ingest(gpu_ctx_factory):
     """hb_ingest.hip (rocPRIM sorts on the device) against hb_host.cpp and the plain-Python statement of
     store.rs:297-357 + harmonic.rs:131: node set, first-occurrence de-duplication, flag filter, CSR."""

@@ -195,6 +195,20 @@ def test_golden_vectors():
         assert got == case["centrality_hex"]
 
 
+def test_rank_results_order():
+    # centrality/mod.rs:92-103 + lib.rs:259-263: (Reverse(total_cmp(centrality)), NodeID ascending)
+    vals = np.array([0.5, 0.75, 0.5, 0.0, 1.0, 0.75, 5e-324], dtype=np.float64)
+    r = hbo.rank_results(vals)
+    assert r.tolist() == [3, 1, 4, 6, 0, 2, 5]
+    rng = np.random.default_rng(3)
+    v = rng.choice(rng.random(50), 2000)  # many ties
+    want = np.empty(len(v), dtype=np.uint64)
+    want[np.lexsort((np.arange(len(v)), -v))] = np.arange(len(v), dtype=np.uint64)
+    assert np.array_equal(hbo.rank_results(v), want)
+    assert len(hbo.rank_results(np.zeros(0))) == 0
+    # sorted_k's own test data (centrality/mod.rs:120-205 pins a top-k ordering by value only)
+
+
 def test_bloom_pieces():
     # bloom/src/lib.rs:36-41: bits = ceil(n ln(0.05) / (-8 ln^2 2)) ~= 0.78 n
     assert hbo.load().hbo_bloom_num_bits(1000, 0.05) == 780
