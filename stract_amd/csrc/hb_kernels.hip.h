@@ -324,7 +324,10 @@ __global__ __launch_bounds__(256) void pass_kernel(const PassParams p)
         uint4 selfv = make_uint4(0, 0, 0, 0);
         Acc acc;
         acc_zero(acc);
-        if (!FRONTIER && valid) { // dense mode: self is always needed, issue it first
+        // dense mode, node rows: self is always needed, issue it first.  Dense mode, hub chunks: the maximum
+        // over ALL current sources already dominates the stored partial (counters only grow), so the partial
+        // is overwritten without being read, and no changed bit is kept (nobody tests it in a dense pass).
+        if (!FRONTIER && REAL && valid) {
             selfv = *selfp;
             acc_merge(acc, selfv);
         }
@@ -410,7 +413,7 @@ __global__ __launch_bounds__(256) void pass_kernel(const PassParams p)
             }
         }
         const uint4 accv = acc_value(acc);
-        const bool lane_diff = need && u4_ne(accv, selfv);
+        const bool lane_diff = need && ((!REAL && !FRONTIER) || u4_ne(accv, selfv));
         const uint64_t bal = __ballot(lane_diff);
         const bool changed = ((bal >> qshift) & 0xFull) != 0;
         if (REAL) {
@@ -421,7 +424,7 @@ __global__ __launch_bounds__(256) void pass_kernel(const PassParams p)
             if (changed) p.part[(row - p.n_pad) * 4 + q] = accv;
         }
         const uint32_t ch16 = pack16(bal);
-        if (FUSED || !REAL) {
+        if (FUSED || (!REAL && FRONTIER)) {
             // changed bits: real rows -> next frontier; virtual rows -> this pass' bits
             uint16_t *dst = REAL ? (uint16_t *)p.bits_wr : (uint16_t *)p.bits_rd;
             if (lane == 0 && row16 < row_hi) dst[row16 >> 4] = (uint16_t)ch16;
