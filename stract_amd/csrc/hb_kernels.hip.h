@@ -309,28 +309,60 @@ __global__ __launch_bounds__(256) void pass_kernel(const PassParams p)
     const uint64_t ntiles = (row_hi - row_lo + 63) >> 6;
     unsigned long long cnt_changed = 0, cnt_active = 0, cnt_rows = 0, cnt_out = 0;
 
+    // Software pipeline over the tiles of this workgroup: the row pointers / out-degree / own counter of the
+    // NEXT tile are requested before the gathers of the current one, and the Kahan/size words of the current
+    // rows are requested at the top of the iteration - the per-tile chain of dependent memory round trips
+    // (row_ptr -> index -> gather -> self -> size/ksum/kerr) shrinks to (index -> gather); node rows have ~5
+    // sources each, so that chain, not bandwidth, bounded the node-row kernel.
+    constexpr bool kDenseReal = REAL && !FRONTIER;
+    uint64_t nbeg = 0, nend = 0;
+    uint32_t nod = 0;
+    uint4 nself = make_uint4(0, 0, 0, 0);
+    {
+        const uint64_t r0 = row_lo + (tile0 << 6) + ((uint64_t)wave << 4) + (uint64_t)g;
+        if (tile0 < ntiles && r0 < row_hi) {
+            nbeg = p.row_ptr[r0];
+            nend = p.row_ptr[r0 + 1];
+            if (REAL && FUSED) nod = p.outdeg[r0];
+            if (kDenseReal) nself = p.rd[r0 * 4 + q];
+        }
+    }
     for (uint64_t tile = tile0; tile < ntiles; tile += tstride) {
         const uint64_t row16 = row_lo + (tile << 6) + ((uint64_t)wave << 4); // first row of this wave
         const uint64_t row = row16 + (uint64_t)g;
         const bool valid = row < row_hi;
-        uint64_t beg = 0, end = 0;
-        uint32_t od = 0; // out-degree of the row's node: issued with the row pointers, used in the epilogue
-        if (valid) {
-            beg = p.row_ptr[row];
-            end = p.row_ptr[row + 1];
-            if (REAL && FUSED) od = p.outdeg[row];
+        const uint64_t beg = nbeg, end = nend;
+        const uint32_t od = nod; // out-degree of the row's node, used in the epilogue
+        uint4 selfv = nself;
+        {   // requests for the next tile of this workgroup
+            const uint64_t nrow = row + (tstride << 6);
+            nbeg = nend = 0;
+            nod = 0;
+            nself = make_uint4(0, 0, 0, 0);
+            if (tile + tstride < ntiles && nrow < row_hi) {
+                nbeg = p.row_ptr[nrow];
+                nend = p.row_ptr[nrow + 1];
+                if (REAL && FUSED) nod = p.outdeg[nrow];
+                if (kDenseReal) nself = p.rd[nrow * 4 + q];
+            }
+        }
+        // dense fused node rows: 4 of 5 rows change, so the estimator/Kahan words are requested now, unconditionally
+        uint64_t pre_sz = 0;
+        double pre_ks = 0.0, pre_ke = 0.0;
+        if (kDenseReal && FUSED && valid) {
+            pre_sz = p.size[row];
+            if (q == 0) {
+                pre_ks = p.ksum[row];
+                pre_ke = p.kerr[row];
+            }
         }
         const uint4 *selfp = REAL ? (p.rd + row * 4 + q) : (p.part + (row - p.n_pad) * 4 + q);
-        uint4 selfv = make_uint4(0, 0, 0, 0);
         Acc acc;
         acc_zero(acc);
-        // dense mode, node rows: self is always needed, issue it first.  Dense mode, hub chunks: the maximum
+        // dense mode, node rows: self (prefetched) is always merged.  Dense mode, hub chunks: the maximum
         // over ALL current sources already dominates the stored partial (counters only grow), so the partial
         // is overwritten without being read, and no changed bit is kept (nobody tests it in a dense pass).
-        if (!FRONTIER && REAL && valid) {
-            selfv = *selfp;
-            acc_merge(acc, selfv);
-        }
+        if (kDenseReal && valid) acc_merge(acc, selfv);
         bool lane_act = false;
         if (beg < end) {
             // all sources of one row are of one kind: real nodes (read rd) or virtual rows (read part)
@@ -437,10 +469,10 @@ __global__ __launch_bounds__(256) void pass_kernel(const PassParams p)
         if (REAL && FUSED) {
             bool err_nz = false;
             if (need && (changed || kd)) {
-                const uint64_t sz_old = p.size[row];
+                const uint64_t sz_old = kDenseReal ? pre_sz : p.size[row];
                 const uint64_t sz_new = changed ? hll_size_quad(accv, s_raw, s_bias, s_lc) : sz_old;
                 if (q == 0) {
-                    double ks = p.ksum[row], ke = p.kerr[row];
+                    double ks = kDenseReal ? pre_ks : p.ksum[row], ke = kDenseReal ? pre_ke : p.kerr[row];
                     err_nz = kahan_update(ks, ke, sz_new, sz_old, p.t_plus_1); // still moving -> visit again
                     if (err_nz) {
                         p.ksum[row] = ks;
