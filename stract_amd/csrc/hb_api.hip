@@ -792,11 +792,13 @@ int hb_begin(hb_ctx *c)
         hipError_t stale = hipGetLastError(); // an unchecked failure of an earlier call on this thread
         if (stale != hipSuccess) return fail(c, HB_ERR_HIP, std::string("stale HIP error before hb_begin: ") + hipGetErrorString(stale));
     }
-    HB_HIP(hipMemsetAsync(c->d_part, 0, std::max<size_t>(p.nv * 64, 256), c->stream));
+    // d_part needs no clearing: pass 0 is always dense, and a dense pass overwrites every partial without
+    // reading it (hb_kernels.hip.h)
     HB_HIP(hipMemsetAsync(c->d_bits[0], 0, c->bits_words * 4, c->stream));
     HB_HIP(hipMemsetAsync(c->d_bits[1], 0, c->bits_words * 4, c->stream));
     HB_HIP(hipMemsetAsync(c->d_counters, 0, ((size_t)c->max_passes + 1) * hbk::kCounterWords * sizeof(unsigned long long), c->stream));
-    HB_HIP(hipMemsetAsync(c->d_ksum, 0, c->ksum_len * sizeof(double), c->stream));
+    if (c->ksum_len > p.n_pad) // slice padding beyond the rows init_kernel writes (all-reduce mode)
+        HB_HIP(hipMemsetAsync(c->d_ksum + p.n_pad, 0, (c->ksum_len - p.n_pad) * sizeof(double), c->stream));
     if (p.n_pad) {
         unsigned blocks = (unsigned)((p.n_pad * 4 + 255) / 256);
         hipLaunchKernelGGL(hbk::init_kernel, dim3(blocks), dim3(256), 0, c->stream, c->d_idlow, (const uint32_t *)c->d_sid_of, p.n_pad,
