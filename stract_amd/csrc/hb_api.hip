@@ -181,7 +181,11 @@ PlanTune plan_tune(uint32_t chunk, const uint32_t *tune)
 bool multi_rank(const hb_ctx *c) { return c->opt.world_size > 1; }
 // destination partition: this rank owns the rows (nodes) with sid % world == rank and holds all their
 // in-edges; one all-gather of the owned counter slices per pass
-bool dest_mode(const hb_ctx *c) { return multi_rank(c) && (c->opt.flags & HB_FLAG_DEST_PARTITION); }
+// (also with a 1-rank communicator, HB_FLAG_RCCL_SELF: the grouped all-gathers run for real on one GPU)
+bool dest_mode(const hb_ctx *c)
+{
+    return (c->opt.flags & HB_FLAG_DEST_PARTITION) && (multi_rank(c) || (c->opt.flags & HB_FLAG_RCCL_SELF));
+}
 // edge partition: every rank holds some in-edges of every row; one all-reduce(max) of all counters per pass
 bool edge_partitioned(const hb_ctx *c) { return multi_rank(c) && !dest_mode(c); }
 bool unfused(const hb_ctx *c)
@@ -283,7 +287,7 @@ int plan_and_upload(hb_ctx *c)
     }
     PlanTune pt = plan_tune(c->opt.chunk, c->opt.tune);
     pt.xcd_map = !(c->opt.flags & HB_FLAG_NO_XCD_MAP);
-    if (dest_mode(c)) pt.world = (uint32_t)c->opt.world_size;
+    if (dest_mode(c)) pt.world = (uint32_t)std::max(c->opt.world_size, 1);
     std::string perr = build_plan(n, c->g.row_ptr.data(), c->g.src.data(), outdeg, reorder, pt, &c->plan);
     if (!perr.empty()) return fail(c, perr.find("memory") != std::string::npos ? HB_ERR_NOMEM : HB_ERR_LIMIT, perr);
     c->stats.ms_plan = now_ms() - t0;
@@ -309,7 +313,7 @@ int plan_and_upload(hb_ctx *c)
     // Kahan ownership: one contiguous slice of rows per rank (multiple of 64 rows)
     const uint64_t world = c->comm ? (uint64_t)c->opt.world_size : 1;
     c->slice_rows = dest_mode(c) ? p.slice : ((p.n_pad + world - 1) / world + 63) / 64 * 64;
-    c->ksum_len = std::max<uint64_t>(c->slice_rows * (dest_mode(c) ? (uint64_t)c->opt.world_size : world), p.n_pad);
+    c->ksum_len = std::max<uint64_t>(c->slice_rows * (dest_mode(c) ? (uint64_t)std::max(c->opt.world_size, 1) : world), p.n_pad);
     if ((rc = dev_alloc(c, &c->d_ksum, c->ksum_len))) return rc;
     if ((rc = dev_alloc(c, &c->d_kerr, p.n_pad))) return rc;
     if ((rc = dev_alloc(c, &c->d_size, p.n_pad))) return rc;
@@ -726,7 +730,7 @@ int hb_load_edges(hb_ctx *c, const hb_u128 *node_ids, uint64_t n, const hb_edge 
                                                         : gpu_ingest_edges((void *)c->stream, node_ids, n, edges, m, &c->g);
     if (!e.empty())
         return fail(c, e.find("memory") != std::string::npos ? HB_ERR_NOMEM : (e.find("hip") != std::string::npos ? HB_ERR_HIP : HB_ERR_LIMIT), e);
-    if (dest_mode(c)) keep_owned_rows(&c->g, (uint64_t)c->opt.world_size, (uint64_t)c->opt.rank);
+    if (dest_mode(c)) keep_owned_rows(&c->g, (uint64_t)std::max(c->opt.world_size, 1), (uint64_t)c->opt.rank);
     c->stats.ms_ingest = now_ms() - t0;
     double ing = c->stats.ms_ingest;
     rc = plan_and_upload(c);
@@ -773,7 +777,7 @@ int hb_load_dense(hb_ctx *c, const hb_u128 *sorted_ids, uint64_t n, const uint64
     }
     c->g.m_input = m_eff;
     c->g.m_unique = m_eff;
-    if (dest_mode(c)) keep_owned_rows(&c->g, (uint64_t)c->opt.world_size, (uint64_t)c->opt.rank);
+    if (dest_mode(c)) keep_owned_rows(&c->g, (uint64_t)std::max(c->opt.world_size, 1), (uint64_t)c->opt.rank);
     double ing = now_ms() - t0;
     rc = plan_and_upload(c);
     c->stats.ms_ingest = ing;

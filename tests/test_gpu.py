@@ -334,16 +334,21 @@ def test_dest_partition_ignores_foreign_records(gpu_ctx_factory):
             c.close()
 
 
-def test_rccl_call_path_single_rank(gpu_ctx_factory):
-    """A 1-rank RCCL communicator: ncclAllReduce(max, u8) / ncclAllGather run for real."""
+@pytest.mark.parametrize("dest", [False, True])
+def test_rccl_call_path_single_rank(gpu_ctx_factory, dest):
+    """A 1-rank RCCL communicator: the collectives of both decompositions run for real -
+    ncclAllReduce(max, u8) + epilogue (edge partition), grouped ncclAllGather of the counter / changed-bit
+    slices + ncclAllReduce(sum) of the counters (destination partition), ncclAllGather of the Kahan sums."""
     g = synth.RmatGraph(12, 40_000)
     o, T, vals, keep, k = _oracle_dense(g.ids, g.row_ptr, g.src)
     uid = _lib.rccl_unique_id()
-    with gpu_ctx_factory(flags=_lib.HB_FLAG_RCCL_SELF, rccl_id=uid) as ctx:
+    flags = _lib.HB_FLAG_RCCL_SELF | (_lib.HB_FLAG_DEST_PARTITION if dest else 0)
+    with gpu_ctx_factory(flags=flags, rccl_id=uid) as ctx:
         ctx.load_dense(g.ids, g.row_ptr, g.src)
         st = ctx.run()
         _check_final(ctx, g.ids, T, vals, keep, st)
         assert st["ms_collective"] > 0.0
+        assert np.array_equal(ctx.registers(), o.registers())
 
 
 # ---- larger sizes ---------------------------------------------------------------------------------
