@@ -91,7 +91,15 @@ typedef struct hb_options {
     int32_t  rank;          /* edge-partition mode: this process' rank ...                 */
     int32_t  world_size;    /* ... of world_size (<= 1: single GPU, no collective)         */
     uint8_t  rccl_id[128];  /* ncclUniqueId from hb_rccl_unique_id() of rank 0             */
-    uint32_t tune[8];       /* kernel tuning knobs, 0 = default            */
+    uint32_t tune[8];       /* tuning knobs, 0 = default:
+                             *  [0] workgroups per CU of the pass launches (8)
+                             *  [1] gather unroll 1|2|4 (hub chunks 4, node rows 2)
+                             *  [2] frontier mode when A_t < tune[2] % of the edges (50; > 100 = always)
+                             *  [3] log2 of the hotness slice width in counters (16 = 4 MiB; 1 = no slices)
+                             *  [4] min sources of a chunk at a slice cut (8)
+                             *  [5] largest row that is not split into chunks (chunk)
+                             *  [6] sparse worklist mode when A_t * tune[6] < edges (64; 1 = whenever frontier)
+                             *  [7] reserved (hb_host_plan: owner slices)                          */
 } hb_options;
 
 typedef struct hb_ctx hb_ctx;
@@ -121,7 +129,8 @@ typedef struct hb_stats {
 typedef struct hb_pass_stats {
     uint64_t pass;          /* t                                                            */
     uint64_t changed;       /* nodes whose counter changed in pass t                        */
-    uint64_t active_edges;  /* A_t (only with HB_FLAG_PASS_STATS, else 0)                   */
+    uint64_t active_edges;  /* A_t = edges whose source changed in pass t-1 (out-degree sum of those
+                               nodes; with HB_FLAG_PASS_STATS counted edge by edge in frontier passes) */
     uint64_t touched;       /* V_t (only with HB_FLAG_PASS_STATS, else 0)                   */
     uint32_t mode;          /* 0 = dense (no frontier test), 1 = frontier bitmap, 2 = sparse worklists */
     float    ms_gpu;        /* GPU time of the pass (all its launches + collective)         */
