@@ -84,4 +84,5 @@ CONFIGS = {
     "C2": dict(scale=21, m=20_000_000, label="1M-host / 20M-edge"),
     "C3": dict(scale=24, m=200_000_000, label="10M-host / 200M-edge"),
     "C4": dict(scale=28, m=2_000_000_000, label="100M-host / 2B-edge"),
+    "C5": dict(scale=30, m=5_000_000_000, label="~300M-host / ~5B-edge (CommonCrawl-scale host graph, synthetic)"),
 }
