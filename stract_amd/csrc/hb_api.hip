@@ -359,8 +359,8 @@ int plan_and_upload(hb_ctx *c)
     HB_HIP(hipStreamSynchronize(c->stream));
     if ((rc = build_sparse_support(c))) return rc;
     // the plan's big host arrays are no longer needed
-    std::vector<uint64_t>().swap(c->plan.row_ptr);
-    std::vector<uint32_t>().swap(c->plan.src);
+    decltype(c->plan.row_ptr)().swap(c->plan.row_ptr);
+    decltype(c->plan.src)().swap(c->plan.src);
     c->stats.ms_h2d = now_ms() - t0;
     c->loaded = true;
     return HB_OK;

@@ -293,7 +293,7 @@ std::string build_plan(uint64_t n, const uint64_t *row_ptr, const uint32_t *src,
             uint32_t s = p->order[d];
             rp[d + 1] = rp[d] + (s == kNone ? 0 : (row_ptr[s + 1] - row_ptr[s]));
         }
-        std::vector<uint32_t> rs(p->m_eff);
+        uvec<uint32_t> rs(p->m_eff);
         // small dynamic chunks: in device order the biggest hubs sit next to each other at the front
 #pragma omp parallel for schedule(dynamic, 32)
         for (int64_t d = 0; d < (int64_t)n_pad; d++) {
@@ -316,7 +316,7 @@ std::string build_plan(uint64_t n, const uint64_t *row_ptr, const uint32_t *src,
         // time gather from the same few MiB of the counter array (L2 hits instead of fabric
         // requests; measured ceilings: tools/gather_bench.hip).
         std::vector<uint64_t> vrow_ptr; // offsets of virtual rows' lists in vsrc
-        std::vector<uint32_t> vsrc;
+        uvec<uint32_t> vsrc;
         vrow_ptr.push_back(0);
         std::vector<uint8_t> is_split(n_pad, 0);
         uint64_t next_vid = p->n_pad;
@@ -339,11 +339,14 @@ std::string build_plan(uint64_t n, const uint64_t *row_ptr, const uint32_t *src,
         std::vector<uint64_t> hub_first;         // first chunk (creation order) of each split row, +1 sentinel
         const uint32_t minc = std::max<uint32_t>(1, std::min(tune.minc, chunk));
         for (uint64_t d = 0; d < n_pad; d++) {
-            const uint64_t b = rp[d], e = rp[d + 1];
-            if (e - b <= tune.direct_max) continue;
+            if (rp[d + 1] - rp[d] <= tune.direct_max) continue;
             is_split[d] = 1;
             hub_rows.push_back((uint32_t)d);
-            hub_first.push_back(chunks.size());
+        }
+        // the greedy cut of one row; emit(begin, length, key) per chunk.  Rows are independent: count in
+        // parallel, prefix, then fill in parallel.
+        auto cut_row = [&](uint64_t d, auto &&emit) {
+            const uint64_t b = rp[d], e = rp[d + 1];
             uint64_t i = b;
             while (i < e) {
                 const uint32_t b0 = band_of(rs[i]);
@@ -354,11 +357,24 @@ std::string build_plan(uint64_t n, const uint64_t *row_ptr, const uint32_t *src,
                 }
                 // do not leave a tiny remainder behind: absorb it when it fits
                 if (e - j < minc && e - i <= chunk) j = e;
-                chunks.push_back({i, (uint32_t)(j - i), b0});
+                emit(i, (uint32_t)(j - i), b0);
                 i = j;
             }
+        };
+        hub_first.assign(hub_rows.size() + 1, 0);
+#pragma omp parallel for schedule(dynamic, 64)
+        for (int64_t h = 0; h < (int64_t)hub_rows.size(); h++) {
+            uint64_t cnt = 0;
+            cut_row(hub_rows[h], [&](uint64_t, uint32_t, uint32_t) { cnt++; });
+            hub_first[h + 1] = cnt;
         }
-        hub_first.push_back(chunks.size());
+        for (size_t h = 0; h < hub_rows.size(); h++) hub_first[h + 1] += hub_first[h];
+        chunks.resize(hub_first[hub_rows.size()]);
+#pragma omp parallel for schedule(dynamic, 64)
+        for (int64_t h = 0; h < (int64_t)hub_rows.size(); h++) {
+            uint64_t w = hub_first[h];
+            cut_row(hub_rows[h], [&](uint64_t beg, uint32_t len, uint32_t key) { chunks[w++] = {beg, len, key}; });
+        }
         lap("cut chunks");
         // XCD groups: a warm-slice chunk belongs to XCD (slice mod 8); hot (slice 0) and cold chunks fill the
         // groups up to equal work.  Inside a group: slice ascending, longer chunks first (wave-uniform
@@ -421,6 +437,9 @@ std::string build_plan(uint64_t n, const uint64_t *row_ptr, const uint32_t *src,
             p->xcd_groups = groups;
             vrp.push_back(off);
             vrow_ptr.swap(vrp);
+            // capacity for the upper levels too (each holds at most 1/chunk of the rows below it, plus
+            // padding), so that appending them never reallocates - and copies - the level-1 lists
+            vsrc.reserve(off + row_chunk.size() + row_chunk.size() / 8 + 64ull * kRowAlign);
             vsrc.resize(off);
 #pragma omp parallel for schedule(static, 4096)
             for (int64_t r = 0; r < (int64_t)row_chunk.size(); r++) {
@@ -451,9 +470,11 @@ std::string build_plan(uint64_t n, const uint64_t *row_ptr, const uint32_t *src,
             pad_level();
             p->level_begin.push_back(next_vid);
             bool any = false;
+            for (size_t h = 0; h < hub_rows.size() && !any; h++) any = (lptr[h + 1] - lptr[h]) > chunk;
+            if (!any) break;
             std::vector<uint64_t> nptr(hub_rows.size() + 1, 0);
             std::vector<uint32_t> nids;
-            nids.reserve(lids.size() / 2 + 16);
+            nids.reserve(lids.size());
             for (size_t h = 0; h < hub_rows.size(); h++) {
                 nptr[h] = nids.size();
                 const uint64_t cnt = lptr[h + 1] - lptr[h];
@@ -461,7 +482,6 @@ std::string build_plan(uint64_t n, const uint64_t *row_ptr, const uint32_t *src,
                     nids.insert(nids.end(), lids.begin() + lptr[h], lids.begin() + lptr[h + 1]);
                     continue;
                 }
-                any = true;
                 const uint64_t parts = (cnt + chunk - 1) / chunk;
                 const uint64_t per = (cnt + parts - 1) / parts;
                 for (uint64_t k = 0; k < parts; k++) {
@@ -474,7 +494,6 @@ std::string build_plan(uint64_t n, const uint64_t *row_ptr, const uint32_t *src,
             nptr[hub_rows.size()] = nids.size();
             lptr.swap(nptr);
             lids.swap(nids);
-            if (!any) break;
         }
         if (p->level_begin.size() >= 2 && p->level_begin[p->level_begin.size() - 1] ==
                                               p->level_begin[p->level_begin.size() - 2])
@@ -488,7 +507,7 @@ std::string build_plan(uint64_t n, const uint64_t *row_ptr, const uint32_t *src,
         lap("upper levels");
         // ---- assemble: real rows [0, n_pad), then virtual rows
         const uint64_t rows_total = p->n_pad + p->nv;
-        p->row_ptr.assign(rows_total + 1, 0);
+        p->row_ptr.resize(rows_total + 1);
         uint64_t total = 0;
         for (uint64_t d = 0; d < n_pad; d++) {
             p->row_ptr[d] = total;
@@ -509,7 +528,14 @@ std::string build_plan(uint64_t n, const uint64_t *row_ptr, const uint32_t *src,
             }
         }
         lap("assemble");
-        if (!vsrc.empty()) std::memcpy(p->src.data() + real_total, vsrc.data(), vsrc.size() * sizeof(uint32_t));
+        {
+            const int64_t blocks = (int64_t)((vsrc.size() + (1u << 20) - 1) >> 20);
+#pragma omp parallel for schedule(static)
+            for (int64_t b = 0; b < blocks; b++) {
+                const uint64_t o = (uint64_t)b << 20, cnt = std::min<uint64_t>(1u << 20, vsrc.size() - o);
+                std::memcpy(p->src.data() + real_total + o, vsrc.data() + o, cnt * sizeof(uint32_t));
+            }
+        }
     } catch (const std::bad_alloc &) {
         return "out of host memory in the planner";
     }

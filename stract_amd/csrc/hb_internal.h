@@ -10,6 +10,31 @@
 
 namespace hb {
 
+// std::vector whose resize() leaves trivially-constructible elements uninitialised: the multi-GB index
+// arrays of the planner are filled by parallel loops right after being sized (first touch by the
+// threads that fill them instead of a serial zero fill)
+template <class T>
+struct NoInitAlloc {
+    using value_type = T;
+    NoInitAlloc() = default;
+    template <class U>
+    NoInitAlloc(const NoInitAlloc<U> &) {}
+    T *allocate(size_t n) { return static_cast<T *>(::operator new(n * sizeof(T))); }
+    void deallocate(T *p, size_t) { ::operator delete(p); }
+    template <class U, class... A>
+    void construct(U *p, A &&...a)
+    {
+        if constexpr (sizeof...(A) == 0) ::new ((void *)p) U;
+        else ::new ((void *)p) U(static_cast<A &&>(a)...);
+    }
+    template <class U>
+    bool operator==(const NoInitAlloc<U> &) const { return true; }
+    template <class U>
+    bool operator!=(const NoInitAlloc<U> &) const { return false; }
+};
+template <class T>
+using uvec = std::vector<T, NoInitAlloc<T>>;
+
 constexpr uint32_t kNone = 0xFFFFFFFFu;   // "no source" sentinel in the device src stream
 constexpr uint32_t kRowAlign = 64;        // row-id alignment of level boundaries (rows per block tile)
 constexpr uint32_t kDefaultChunk = 64;    // max sources per work row
@@ -39,8 +64,8 @@ struct Plan {
     uint32_t chunk = kDefaultChunk;
     std::vector<uint32_t> order;      // device index -> sid (n_pad entries, kNone = padding row)
     std::vector<uint32_t> dev_of;     // sid -> device index
-    std::vector<uint64_t> row_ptr;    // (n_pad + nv) + 1 offsets into src
-    std::vector<uint32_t> src;        // device indices (real < n_pad <= virtual ids)
+    uvec<uint64_t> row_ptr;           // (n_pad + nv) + 1 offsets into src
+    uvec<uint32_t> src;               // device indices (real < n_pad <= virtual ids)
     std::vector<uint64_t> level_begin; // virtual level l = rows [level_begin[l], level_begin[l+1])
     uint64_t xcd_begin[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}; // level-1 rows of XCD group x = [xcd_begin[x], xcd_begin[x+1])
     int xcd_groups = 1;
