@@ -74,3 +74,38 @@ def random_registers(rng, count, kind="mixed"):
         else:                  # extreme register values incl. > 47 (sequential f64 fold)
             regs[i] = rng.integers(0, 66, 64)
     return regs
+
+
+def random_graph(rng, kind=None):
+    """Small random graphs of several shapes (as unique (from, to) int tuples, ids 1..n)."""
+    kind = kind or ("uniform", "stars", "chains", "dense_core", "bipartite")[int(rng.integers(0, 5))]
+    n = int(rng.integers(2, 600))
+    edges = set()
+    if kind == "uniform":
+        for _ in range(int(rng.integers(0, 6 * n))):
+            edges.add((int(rng.integers(1, n + 1)), int(rng.integers(1, n + 1))))
+    elif kind == "stars":      # a few destinations with very many sources (deep chunk trees at small chunk sizes)
+        for h in range(1, int(rng.integers(1, 5)) + 1):
+            for s in rng.choice(np.arange(1, n + 1), size=int(rng.integers(1, n)), replace=False):
+                edges.add((int(s), h))
+        for _ in range(n):
+            edges.add((int(rng.integers(1, n + 1)), int(rng.integers(1, n + 1))))
+    elif kind == "chains":     # long diameter: many frontier / sparse passes
+        for i in range(1, n):
+            edges.add((i, i + 1))
+        for _ in range(n // 4):
+            edges.add((int(rng.integers(1, n + 1)), int(rng.integers(1, n + 1))))
+    elif kind == "dense_core":
+        core = max(2, n // 10)
+        for a in range(1, core + 1):
+            for b in range(1, core + 1):
+                if rng.random() < 0.5:
+                    edges.add((a, b))
+        for v in range(core + 1, n + 1):
+            edges.add((v, int(rng.integers(1, core + 1))))
+            edges.add((int(rng.integers(1, core + 1)), v))
+    else:                      # sources-only nodes -> destination-only nodes
+        half = max(1, n // 2)
+        for _ in range(4 * n):
+            edges.add((int(rng.integers(1, half + 1)), int(rng.integers(half + 1, n + 2))))
+    return kind, sorted(edges)

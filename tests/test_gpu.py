@@ -262,6 +262,32 @@ def test_hub_rows_and_isolated_nodes(gpu_ctx_factory):
         assert np.array_equal(ids, fids) and np.array_equal(vals.view(np.uint64), fvals.view(np.uint64)), kw
 
 
+def test_randomized_graphs_and_knobs(gpu_ctx_factory):
+    """Random small graphs of several shapes x random planner / mode knobs: final list, pass count and
+    registers against the oracle."""
+    rng = np.random.default_rng(977)
+    flag_pool = [0, 0, _lib.HB_FLAG_NO_REORDER, _lib.HB_FLAG_NO_XCD_MAP, _lib.HB_FLAG_UNFUSED, _lib.HB_FLAG_NO_SPARSE,
+                 _lib.HB_FLAG_NO_FRONTIER, _lib.HB_FLAG_PASS_STATS]
+    for case in range(40):
+        kind, edges = graphs.random_graph(rng)
+        ids, row_ptr, src = graphs.dense_from_tuples(edges) if edges else (np.zeros(0, _lib.U128), np.zeros(1, np.uint64), np.zeros(0, np.uint32))
+        o, T, vals, keep, k = _oracle_dense(ids, row_ptr, src)
+        chunk = int(rng.choice([4, 8, 16, 64]))
+        tune = (int(rng.choice([0, 1, 2])), int(rng.choice([0, 1, 2, 4])), int(rng.choice([0, 30, 101])), int(rng.integers(4, 9)),
+                int(rng.integers(1, 9)), int(rng.integers(0, chunk + 1)), int(rng.choice([0, 1, 4])))
+        flags = int(rng.choice(flag_pool)) | int(rng.choice(flag_pool))
+        with gpu_ctx_factory(flags=flags, chunk=chunk, tune=tune) as ctx:
+            ctx.load_dense(ids, row_ptr, src)
+            st = ctx.run()
+            what = (case, kind, len(ids), len(src), chunk, tune, flags)
+            assert st["passes"] == T, what
+            gids, gvals = ctx.results()
+            assert np.array_equal(gids, ids[keep]), what
+            assert np.array_equal(gvals.view(np.uint64), vals[keep].view(np.uint64)), what
+            if len(ids):
+                assert np.array_equal(ctx.registers(), o.registers()), what
+
+
 # ---- edge-partition mode ------------------------------------------------------------------------
 @pytest.mark.parametrize("world,mode", [(2, "edge"), (3, "edge"), (2, "dest"), (3, "dest"), (4, "dest")])
 def test_logical_ranks_on_one_device(gpu_ctx_factory, world, mode):

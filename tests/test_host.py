@@ -183,6 +183,35 @@ def test_planner_owner_slices(world):
         assert plan["row_ptr"][d] == plan["row_ptr"][d + 1]
 
 
+def test_planner_randomized_coverage():
+    """Random small graphs x random knobs: every row's tree covers exactly its in-edges, rows obey the chunk
+    limit, levels only read the level below."""
+    rng = np.random.default_rng(20240922)
+    for case in range(60):
+        kind, edges = graphs.random_graph(rng)
+        if not edges:
+            continue
+        ids, row_ptr, src = graphs.dense_from_tuples(edges)
+        n = len(ids)
+        chunk = int(rng.choice([4, 5, 8, 16, 64]))
+        tune = (0, 0, 0, int(rng.integers(4, 9)), int(rng.integers(1, 9)), int(rng.integers(0, chunk + 1)), 0,
+                int(rng.choice([0, 0, 2, 3])))
+        flags = int(rng.choice([0, _lib.HB_FLAG_NO_REORDER, _lib.HB_FLAG_NO_XCD_MAP]))
+        plan = _lib.host_plan(row_ptr, src, flags, chunk, tune)
+        n_pad = plan["n_pad"]
+        order = plan["order"].astype(np.int64)
+        real = np.nonzero(order != 0xFFFFFFFF)[0] if len(order) == n_pad else np.arange(n)
+        sids = order[real] if len(order) == n_pad else order
+        assert sorted(sids.tolist()) == list(range(n)), (case, kind)
+        dev_of = np.zeros(n, np.int64)
+        dev_of[sids] = real
+        lens = np.diff(plan["row_ptr"].astype(np.int64))
+        assert lens.max(initial=0) <= chunk, (case, kind, chunk)
+        for d, sid in zip(real.tolist(), sids.tolist()):
+            want = sorted(dev_of[src[int(row_ptr[sid]):int(row_ptr[sid + 1])]].tolist())
+            assert sorted(_expand(plan, d, n_pad)) == want, (case, kind, chunk, tune, flags)
+
+
 def test_planner_deep_hub():
     # one destination with 5000 in-edges and chunk 4 needs a 6-level tree
     n = 5001
