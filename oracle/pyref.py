@@ -1,0 +1,231 @@
+"""pyref.py - a SECOND, independent restatement of the reference arithmetic, in plain Python.
+
+TEST INFRASTRUCTURE ONLY.  Written directly from the Rust sources (not from hb_oracle.c) so that the two
+restatements can be checked against each other (tests/test_oracle.py): a transcription slip in one of them
+shows up as a disagreement.  Small inputs only (pure-Python loops).
+
+Follows, line by line:
+  crates/core/src/hyperloglog.rs:4311-4313  FastHasher::hash
+  crates/core/src/hyperloglog.rs:4366-4383  am(), b()
+  crates/core/src/hyperloglog.rs:4385-4400  add, add_u128
+  crates/core/src/hyperloglog.rs:4407-4470  estimate_bias
+  crates/core/src/hyperloglog.rs:4472-4480  linear_counting, threshold
+  crates/core/src/hyperloglog.rs:4484-4516  size
+  crates/core/src/hyperloglog.rs:4531-4535  merge
+  crates/core/src/kahan_sum.rs:35-54        KahanSum
+  crates/core/src/webgraph/centrality/harmonic.rs:53-287  the HyperBall loop (map-based, host-level)
+Parity status: unpinned against the reference binary (no Rust toolchain here), like hb_oracle.c.
+"""
+import math
+import os
+import re
+import struct
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+MASK64 = (1 << 64) - 1
+N = 64
+SKIPPED_REL = 0x6FED00  # harmonic.rs:36-49 with the bit values of webpage/html/links.rs:114-141
+
+
+def _load_tables():
+    """RAW_ESTIMATE_DATA_VEC[1] / BIAS_DATA_VEC[1] (the rows N = 64 indexes, hyperloglog.rs:4411,4467) as
+    extracted from the reference by oracle/gen_tables.py into hll64_tables.h."""
+    text = open(os.path.join(_HERE, "hll64_tables.h")).read()
+    out = []
+    for name in ("HLL64_RAW_ESTIMATE", "HLL64_BIAS"):
+        body = re.search(name + r"\[HLL64_TABLE_LEN\] = \{(.*?)\};", text, re.S).group(1)
+        out.append([float(x) for x in body.replace("\n", " ").split(",") if x.strip()])
+    assert len(out[0]) == 159 and len(out[1]) == 159
+    return out
+
+
+RAW, BIAS = _load_tables()
+THRESHOLD_B6 = 40  # THRESHOLD_DATA_VEC[6 - 4], hyperloglog.rs:27-45
+
+
+def fast_hash(item):
+    return (item * 11400714819323198549) & MASK64  # wrapping_mul
+
+
+def leading_zeros64(w):
+    return 64 - w.bit_length()
+
+
+def hll_new():
+    return [0] * N
+
+
+def hll_add(reg, item):
+    b = int(math.log2(N))  # (N as f64).log2() as usize == 6
+    h = fast_hash(item & MASK64)  # add_u128: `item as u64`
+    j = h >> (64 - b)
+    w = (h << b) & MASK64
+    p = leading_zeros64(w) + 1
+    reg[j] = max(reg[j], p & 0xFF)
+
+
+def hll_merge(dst, src):
+    for i in range(N):
+        dst[i] = max(dst[i], src[i])
+
+
+def total_cmp(a, b):
+    """f64::total_cmp as -1/0/1."""
+    def key(x):
+        (bits,) = struct.unpack("<q", struct.pack("<d", x))
+        return bits ^ ((bits >> 63) & 0x7FFFFFFFFFFFFFFF)
+    ka, kb = key(a), key(b)
+    return (ka > kb) - (ka < kb)
+
+
+def binary_search_by(arr, e):
+    """slice::binary_search_by(|v| v.total_cmp(&e)) of Rust >= 1.82 (library/core/src/slice/mod.rs):
+    returns ("Ok", i) or ("Err", i)."""
+    size = len(arr)
+    if size == 0:
+        return ("Err", 0)
+    base = 0
+    while size > 1:
+        half = size // 2
+        mid = base + half
+        cmp = total_cmp(arr[mid], e)
+        base = base if cmp > 0 else mid
+        size -= half
+    cmp = total_cmp(arr[base], e)
+    if cmp == 0:
+        return ("Ok", base)
+    return ("Err", base + (1 if cmp < 0 else 0))
+
+
+def estimate_bias(e):
+    K = 6
+    lookup = RAW  # RAW_ESTIMATE_DATA_VEC[b - 1 - 4] with b = 6
+    kind, i = binary_search_by(lookup, e)
+    if kind == "Err" and i == len(lookup):
+        idx_left = i - 1
+    else:
+        idx_left = i
+    idx_right = idx_left + 1 if idx_left < len(lookup) - 1 else None
+    neighbors = []
+    for _ in range(K):
+        if idx_left is not None and idx_right is not None:
+            delta_left = abs(lookup[idx_left] - e)
+            delta_right = abs(lookup[idx_right] - e)
+            if delta_right < delta_left:
+                right, idx = True, idx_right
+            else:
+                right, idx = False, idx_left
+        elif idx_left is not None:
+            right, idx = False, idx_left
+        elif idx_right is not None:
+            right, idx = True, idx_right
+        else:
+            raise AssertionError("neighborhood search failed")
+        neighbors.append(idx)
+        if right:
+            idx_right = idx + 1 if idx < len(lookup) - 1 else None
+        else:
+            idx_left = idx - 1 if idx > 0 else None
+    s = 0.0
+    for i in neighbors:  # Iterator::sum is a left fold
+        s = s + BIAS[i]
+    return s / float(K)
+
+
+def as_usize(x):
+    """Rust `f64 as usize`: truncation toward zero, saturating, NaN -> 0."""
+    if x != x or x <= 0.0:
+        return 0
+    if x >= 18446744073709551616.0:
+        return MASK64
+    return int(x)
+
+
+def hll_size(reg):
+    m = float(len(reg))
+    s = 0.0
+    for val in reg:  # ONE_OVER_POWER_OF_TWO[val] == 2^-val exactly (hyperloglog.rs:4043-4300)
+        s = s + math.ldexp(1.0, -val)
+    z = 1.0 / s
+    am = 0.709  # m == 64
+    e = am * (m * m) * z  # am() * m.powi(2) * z, left to right
+    if e <= 5.0 * m:
+        e_star = e - estimate_bias(e)
+    else:
+        e_star = e
+    v = sum(1 for r in reg if r == 0)
+    if v != 0:
+        h = m * math.log(m / float(v))
+    else:
+        h = e_star
+    if h <= float(THRESHOLD_B6):
+        return as_usize(h)
+    return as_usize(e_star)
+
+
+class Kahan:
+    __slots__ = ("sum", "err")
+
+    def __init__(self):
+        self.sum = 0.0
+        self.err = 0.0
+
+    def add(self, rhs):
+        y = rhs - self.err
+        t = self.sum + y
+        self.err = (t - self.sum) - y
+        self.sum = t
+
+
+def harmonic_centrality(edges):
+    """edges: stream of (from_id, to_id, rel_flags) with integer ids (u128).  Returns (dict id -> f64 in
+    ascending id order, passes).  Semantics of harmonic.rs:53-287 on host-level edges; the bloom filter /
+    exact-set switch is results-inert and replaced by the exact changed set."""
+    nodes = sorted({x for e in edges for x in (e[0], e[1])})  # store.rs:338-357: flagged records included
+    seen, kept = set(), []
+    for e in edges:  # store.rs:313 unique_by first, THEN the rel filter (harmonic.rs:131)
+        k = (e[0], e[1])
+        if k in seen:
+            continue
+        seen.add(k)
+        if (e[2] if len(e) > 2 else 0) & SKIPPED_REL:
+            continue
+        kept.append(k)
+    old = {}
+    for v in nodes:  # initialize, harmonic.rs:53-73
+        c = hll_new()
+        hll_add(c, v)
+        old[v] = c
+    new = {v: list(c) for v, c in old.items()}
+    cent = {v: Kahan() for v in nodes}
+    n = len(nodes)
+    changed_nodes = set(nodes)  # harmonic.rs:221-225
+    has_changes = True
+    t = 0
+    while has_changes:  # harmonic.rs:237-280
+        has_changes = False
+        new_changed = set()
+        for (f, to) in kept:  # update_all_counters / update_changed_counters
+            if f not in changed_nodes:
+                continue
+            fc, tc = old[f], new[to]
+            if any(a > b for a, b in zip(fc, tc)):
+                hll_merge(tc, fc)
+                new_changed.add(to)
+                has_changes = True
+        for v in nodes:  # update_centralities, harmonic.rs:159-176
+            sn, so = hll_size(new[v]), hll_size(old[v])
+            d = sn - so if sn >= so else 0  # checked_sub().unwrap_or_default()
+            cent[v].add(float(d) / float(t + 1))
+        old = {v: list(c) for v, c in new.items()}  # Counters::step
+        changed_nodes = new_changed
+        t += 1
+    out = {}
+    if n >= 2:
+        norm = float(n - 1)
+        for v in nodes:  # normalize_centralities, harmonic.rs:178-195
+            c = cent[v].sum
+            if c > 0.0:
+                c = c / norm
+                out[v] = c if math.isfinite(c) else 0.0
+    return out, t

@@ -1,5 +1,6 @@
 """CPU oracle (oracle/hb_oracle.c) against every known answer the reference's tests hold
 for this path, SURVEY.md Appendix B, and the committed golden fixtures."""
+import ctypes
 import json
 import math
 import os
@@ -207,6 +208,62 @@ def test_rank_results_order():
     assert np.array_equal(hbo.rank_results(v), want)
     assert len(hbo.rank_results(np.zeros(0))) == 0
     # sorted_k's own test data (centrality/mod.rs:120-205 pins a top-k ordering by value only)
+
+
+def test_second_restatement_agrees_estimator():
+    """oracle/pyref.py (plain Python, written from the Rust sources independently of hb_oracle.c) against the C
+    oracle: HyperLogLog add positions and size() on every branch."""
+    from oracle import pyref
+
+    r = pyref.hll_new()
+    pyref.hll_add(r, 1)
+    assert r[39] == 1 and sum(r) == 1
+    r = pyref.hll_new()
+    pyref.hll_add(r, (123 << 64) | 0)  # add_u128 truncates to the low 64 bits
+    assert r[0] == 65
+    gold = json.load(open(GOLD))
+    regs = np.array(gold["size_cases"]["registers"], dtype=np.uint8)
+    assert [pyref.hll_size(x.tolist()) for x in regs] == gold["size_cases"]["sizes"]
+    rng = np.random.default_rng(11)
+    more = graphs.random_registers(rng, 3000)
+    want = hbo.hll_sizes(more).tolist()
+    assert [pyref.hll_size(x.tolist()) for x in more] == want
+    # counters as they occur in a run
+    c = pyref.hll_new()
+    cc = np.zeros(64, np.uint8)
+    for i, x in enumerate(rng.integers(0, 1 << 63, size=4000, dtype=np.uint64)):
+        pyref.hll_add(c, int(x))
+        hbo.hll_add(cc, int(x))
+        if i % 97 == 0:
+            assert c == cc.tolist()
+            assert pyref.hll_size(c) == hbo.hll_size(cc)
+    # the unsorted spots of the raw-estimate table: both binary searches land on the same index
+    L = hbo.load()
+    for e in list(np.linspace(127.0, 133.0, 4001)) + pyref.RAW:
+        kind, i = pyref.binary_search_by(pyref.RAW, float(e))
+        first = len(pyref.RAW) - 1 if (kind == "Err" and i == len(pyref.RAW)) else i
+        assert first == L.hbo_hll_bias_first_index(ctypes.c_double(float(e)), 0)
+
+
+def test_second_restatement_agrees_hyperball():
+    """The map-based Python HyperBall against the C oracle (faithful form), bit for bit."""
+    from oracle import pyref
+
+    rng = np.random.default_rng(5)
+    cases = [[(f, t, 0) for f, t in graphs.FIXTURE],
+             [(f, t, 0) for f, t in graphs.lcg_graph(50, 120, 99)],
+             [(f, t, graphs.NOFOLLOW if i % 7 == 0 else 0) for i, (f, t) in enumerate(graphs.lcg_graph(80, 300, 5))],
+             [(1, 2, graphs.TAG), (1, 2, 0), (2, 3, 0), (3, 3, 0), (9, 1, graphs.SAME_ICANN_DOMAIN)]]
+    for _ in range(6):
+        kind, edges = graphs.random_graph(rng)
+        cases.append([(f, t, 0) for f, t in edges[:1500]])
+    for tuples in cases:
+        py, passes = pyref.harmonic_centrality(tuples)
+        ids, vals, st = hbo.faithful_run(graphs.EdgeListGraph.from_tuples(tuples).host_edges())
+        got = {(int(h) << 64) | int(l): float(v) for l, h, v in zip(ids["lo"], ids["hi"], vals)}
+        assert st["passes"] == passes
+        assert list(got.keys()) == list(py.keys())
+        assert [np.float64(v).view(np.uint64) for v in got.values()] == [np.float64(v).view(np.uint64) for v in py.values()]
 
 
 def test_bloom_pieces():
