@@ -193,6 +193,21 @@ struct hbo_dense {
     uint64_t last_active, last_touched;
 };
 
+/* OpenMP threads worth starting for `work` units (edges + 8 * nodes): small problems on a many-core box
+ * are slower with every hardware thread than with a few (fork/join and idle spinning dominate). */
+static int eff_threads(int requested, uint64_t work)
+{
+#ifdef _OPENMP
+    int nt = requested > 0 ? requested : omp_get_max_threads();
+    uint64_t cap = work / 32768 + 1;
+    if ((uint64_t)nt > cap) nt = (int)cap;
+    return nt < 1 ? 1 : nt;
+#else
+    (void)requested; (void)work;
+    return 1;
+#endif
+}
+
 hbo_dense *hbo_dense_create(uint64_t n, const uint64_t *id_low64, const uint64_t *row_ptr,
                             const uint32_t *src, int threads)
 {
@@ -227,7 +242,7 @@ hbo_dense *hbo_dense_create(uint64_t n, const uint64_t *id_low64, const uint64_t
         s->ksum[0] = s->kerr[0] = 0.0; s->size_old[0] = 0;
     }
 #ifdef _OPENMP
-    int nt0 = threads > 0 ? threads : omp_get_max_threads();
+    int nt0 = eff_threads(threads, 8 * n);
 #pragma omp parallel for schedule(static) num_threads(nt0)
 #endif
     for (int64_t vi = 0; vi < (int64_t)n; vi++) {
@@ -270,7 +285,7 @@ void hbo_dense_step_local(hbo_dense *s, int flags)
     const int frontier = (flags & HBO_FRONTIER) != 0;
     uint64_t active = 0, touched = 0;
 #ifdef _OPENMP
-    int nt = s->threads > 0 ? s->threads : omp_get_max_threads();
+    int nt = eff_threads(s->threads, (n ? s->row_ptr[n] : 0) + 8 * n);
 #pragma omp parallel for schedule(dynamic, 4096) num_threads(nt) reduction(+ : active, touched)
 #endif
     for (int64_t vi = 0; vi < (int64_t)n; vi++) {
@@ -309,7 +324,7 @@ int hbo_dense_step_finish(hbo_dense *s, int flags, hbo_pass_stats *st)
     const double denom = (double)(s->t + 1); /* (t + 1) as f64, harmonic.rs:174 */
     uint64_t changed = 0;
 #ifdef _OPENMP
-    int nt = s->threads > 0 ? s->threads : omp_get_max_threads();
+    int nt = eff_threads(s->threads, 8 * n);
 #pragma omp parallel for schedule(static) num_threads(nt) reduction(+ : changed)
 #endif
     for (int64_t vi = 0; vi < (int64_t)n; vi++) {

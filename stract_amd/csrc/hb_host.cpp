@@ -32,6 +32,23 @@
 
 namespace hb {
 
+// Caps the OpenMP team for the duration of a host stage by the amount of work: on a many-core box small
+// inputs are far slower with every hardware thread (fork/join, idle spinning) than with a few.
+struct ThreadScope {
+#ifdef _OPENMP
+    int old;
+    explicit ThreadScope(uint64_t work)
+    {
+        old = omp_get_max_threads();
+        const uint64_t cap = work / 65536 + 1;
+        omp_set_num_threads((uint64_t)old > cap ? (int)cap : old);
+    }
+    ~ThreadScope() { omp_set_num_threads(old); }
+#else
+    explicit ThreadScope(uint64_t) {}
+#endif
+};
+
 double now_ms()
 {
     using namespace std::chrono;
@@ -99,6 +116,7 @@ std::string ingest_edges(const hb_u128 *node_ids, uint64_t n_in, const hb_edge *
     out->m_input = m;
     out->m_unique = 0;
     if (m && !edges) return "edges == NULL with m > 0";
+    ThreadScope threads(m + n_in);
     // ---- node set
     std::vector<hb_u128> &ids = out->ids;
     try {
@@ -187,6 +205,7 @@ std::string check_dense(const hb_u128 *ids, uint64_t n, const uint64_t *row_ptr,
     if (m && !src) return "NULL src";
     if (n == 0) return m ? "edges without nodes" : "";
     if (row_ptr[0] != 0 || row_ptr[n] != m) return "row_ptr[0] != 0 or row_ptr[n] != m_eff";
+    ThreadScope threads(m + n);
     int bad = 0;
 #pragma omp parallel for schedule(static) reduction(| : bad)
     for (int64_t v = 0; v < (int64_t)n; v++) {
@@ -206,6 +225,7 @@ void count_out_degree(const uint64_t *row_ptr, const uint32_t *src, uint64_t n, 
 {
     deg->assign(n, 0);
     const uint64_t m = n ? row_ptr[n] : 0;
+    ThreadScope threads(m);
     uint32_t *d = deg->data();
 #pragma omp parallel for schedule(static)
     for (int64_t e = 0; e < (int64_t)m; e++) {
@@ -235,6 +255,7 @@ std::string build_plan(uint64_t n, const uint64_t *row_ptr, const uint32_t *src,
     if (tune.direct_max == 0 || tune.direct_max > chunk) tune.direct_max = chunk;
     if (tune.minc == 0) tune.minc = 8;
     const uint64_t world = tune.world > 1 ? tune.world : 1;
+    ThreadScope threads((n ? row_ptr[n] : 0) + 4 * n);
     const bool timing = std::getenv("HB_PLAN_TIMING") != nullptr;
     double tmark = now_ms();
     auto lap = [&](const char *what) {

@@ -97,7 +97,12 @@ hbs_graph *hbs_rmat(int scale, uint64_t m_target, uint64_t seed, int threads)
 {
     if (scale < 1 || scale > 31) return nullptr;
 #ifdef _OPENMP
-    if (threads > 0) omp_set_num_threads(threads);
+    {   // small graphs: a few threads beat every hardware thread of a many-core box
+        int nt = threads > 0 ? threads : omp_get_max_threads();
+        const uint64_t cap = m_target / 65536 + 1;
+        if ((uint64_t)nt > cap) nt = (int)cap;
+        omp_set_num_threads(nt < 1 ? 1 : nt);
+    }
 #else
     (void)threads;
 #endif
