@@ -16,6 +16,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <sched.h>
 #include <numeric>
 
 #ifdef _OPENMP
@@ -34,6 +35,51 @@ namespace hb {
 
 // Caps the OpenMP team for the duration of a host stage by the amount of work: on a many-core box small
 // inputs are far slower with every hardware thread (fork/join, idle spinning) than with a few.
+// CPUs this process may really use: min(OpenMP default, affinity mask, cgroup v2/v1 CPU quota).  Containers
+// often expose every hardware thread of the host while the quota is a fraction of it; an OpenMP team larger
+// than the quota is slower than a smaller one (measured on the GPU box: 64 of 256 threads is fastest).
+static int usable_cpus()
+{
+    static int cached = 0;
+    if (cached) return cached;
+    int n = 1;
+#ifdef _OPENMP
+    n = omp_get_max_threads();
+#endif
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof(set), &set) == 0) {
+        const int a = CPU_COUNT(&set);
+        if (a > 0 && a < n) n = a;
+    }
+    auto quota_from = [](const char *path, bool v2) -> double {
+        FILE *f = std::fopen(path, "r");
+        if (!f) return 0.0;
+        char buf[128] = {0};
+        const size_t got = std::fread(buf, 1, sizeof(buf) - 1, f);
+        std::fclose(f);
+        if (!got) return 0.0;
+        if (v2) { // "max 100000" or "<quota> <period>"
+            double q = 0, p = 0;
+            if (std::sscanf(buf, "%lf %lf", &q, &p) == 2 && q > 0 && p > 0) return q / p;
+            return 0.0;
+        }
+        return std::atof(buf);
+    };
+    double q = quota_from("/sys/fs/cgroup/cpu.max", true);
+    if (q <= 0.0) {
+        const double quota = quota_from("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", false);
+        const double period = quota_from("/sys/fs/cgroup/cpu/cpu.cfs_period_us", false);
+        if (quota > 0 && period > 0) q = quota / period;
+    }
+    if (q > 0.0) {
+        const int c = (int)(q + 0.999);
+        if (c > 0 && c < n) n = c;
+    }
+    if (n > 64) n = 64; // the host stages are memory-bound sorts/scatters: no gain beyond this
+    cached = n < 1 ? 1 : n;
+    return cached;
+}
+
 struct ThreadScope {
 #ifdef _OPENMP
     int old;
@@ -41,7 +87,8 @@ struct ThreadScope {
     {
         old = omp_get_max_threads();
         const uint64_t cap = work / 65536 + 1;
-        omp_set_num_threads((uint64_t)old > cap ? (int)cap : old);
+        const int cpus = usable_cpus();
+        omp_set_num_threads((uint64_t)cpus > cap ? (int)cap : cpus);
     }
     ~ThreadScope() { omp_set_num_threads(old); }
 #else
@@ -316,7 +363,7 @@ std::string build_plan(uint64_t n, const uint64_t *row_ptr, const uint32_t *src,
         }
         uvec<uint32_t> rs(p->m_eff);
         // small dynamic chunks: in device order the biggest hubs sit next to each other at the front
-#pragma omp parallel for schedule(dynamic, 32)
+#pragma omp parallel for schedule(dynamic, 256)
         for (int64_t d = 0; d < (int64_t)n_pad; d++) {
             uint32_t s = p->order[d];
             if (s == kNone) continue;
