@@ -226,18 +226,40 @@ def _pmc_traffic(config):
     return None
 
 
+def _cpu_quota():
+    """CPUs the cgroup lets this process use (cgroup v2 cpu.max or v1 cfs quota), or None."""
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            return max(1, int(round(float(q) / float(p))))
+    except Exception:
+        pass
+    try:
+        q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        p = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        if q > 0 and p > 0:
+            return max(1, int(round(q / p)))
+    except Exception:
+        pass
+    return None
+
+
 def cpu_baseline(g, seconds, gpu_passes, gpu_ids, gpu_vals, verify):
     """Oracle (dense OpenMP port of the reference arithmetic) on this box's host cores, on the
     same graph, for as many passes as fit in `seconds` (all of them with --verify)."""
     from oracle import hbo
 
     ncpu = os.cpu_count() or 1
+    quota = _cpu_quota()  # containers: the cgroup CPU quota can be far below the visible hardware threads
     # pick the OpenMP thread count that is fastest on THIS box (all hardware threads is not always best:
     # SMT, NUMA, container CPU quotas): two dense passes of a small calibration graph per candidate
     from stract_amd import synth
     cal = synth.RmatGraph(19, 4_000_000)
     best_t, cores = None, ncpu
-    for th in sorted({ncpu, max(ncpu // 2, 1), max(ncpu // 4, 1), min(ncpu, 64), min(ncpu, 32), min(ncpu, 16)}, reverse=True):
+    cands = {ncpu, max(ncpu // 2, 1), max(ncpu // 4, 1), min(ncpu, 64), min(ncpu, 32), min(ncpu, 16)}
+    if quota:
+        cands |= {min(ncpu, quota), min(ncpu, 2 * quota)}
+    for th in sorted(cands, reverse=True):
         oc = hbo.Dense(cal.id_low64(), cal.row_ptr, cal.src, threads=th)
         oc.step(0)
         t0 = time.perf_counter()
@@ -256,7 +278,10 @@ def cpu_baseline(g, seconds, gpu_passes, gpu_ids, gpu_vals, verify):
     dt = time.perf_counter() - t0
     res = {"value": round(g.m * done / dt / 1e9, 5), "unit": "GTEPS", "cores": cores, "kind": "port",
            "sample": "first %d of %d passes of the same graph, oracle dense OpenMP port (oracle/hb_oracle.c), %.1f s, "
-                     "%d of %d hardware threads (fastest of a calibration sweep)" % (done, gpu_passes, dt, cores, ncpu)}
+                     "%d OpenMP threads (fastest of a calibration sweep; %d hardware threads visible, cgroup CPU quota %s)"
+                     % (done, gpu_passes, dt, cores, ncpu, quota if quota else "none")}
+    if quota:
+        res["cpu_quota"] = quota
     if not has:  # converged inside the budget: a free end-to-end parity check
         vals, keep, k = o.finish()
         same = (done == gpu_passes and k == len(gpu_vals) and np.array_equal(gpu_ids, g.ids[keep]) and
