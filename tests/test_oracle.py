@@ -275,3 +275,51 @@ def test_bloom_pieces():
     assert L.hbo_bloom_estimate_card(1000, 600) == 0        # ln(0.4) = -0.91 -> 0
     assert L.hbo_bloom_estimate_card(1000, 700) == 1000     # ln(0.3) = -1.2  -> -1
     assert L.hbo_bloom_estimate_card(1000, 1000) == 0xFFFFFFFFFFFFFFFF
+
+
+def test_oracle_under_sanitizers(tmp_path):
+    """The C oracle rebuilt with AddressSanitizer + UBSan, exercised through the same Python wrapper on the
+    golden vectors and two HyperBall runs (sanitizer runs of the CPU oracle)."""
+    import shutil
+    import subprocess
+    import sys
+    import textwrap
+
+    if not shutil.which("gcc"):
+        pytest.skip("no gcc")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    work = tmp_path / "san"
+    shutil.copytree(os.path.join(root, "oracle"), work / "oracle", ignore=shutil.ignore_patterns("*.so", "__pycache__"))
+    shutil.copytree(os.path.join(root, "stract_amd"), work / "stract_amd", ignore=shutil.ignore_patterns("csrc", "__pycache__"))
+    shutil.copytree(os.path.join(root, "tests"), work / "tests", ignore=shutil.ignore_patterns("__pycache__"))
+    r = subprocess.run(["gcc", "-O1", "-g", "-fPIC", "-std=c11", "-fsanitize=address,undefined", "-fno-omit-frame-pointer",
+                        "-ffp-contract=off", "-fopenmp", "-D_POSIX_C_SOURCE=200809L", "-shared", "-o",
+                        str(work / "oracle" / "libhb_oracle.so"), str(work / "oracle" / "hb_oracle.c"), "-lm"],
+                       capture_output=True, text=True, timeout=600)
+    if r.returncode != 0 and "sanitize" in r.stderr:
+        pytest.skip("sanitizer runtime not available")
+    assert r.returncode == 0, r.stderr[-2000:]
+    pre = [subprocess.run(["gcc", "-print-file-name=" + lib], capture_output=True, text=True).stdout.strip()
+           for lib in ("libasan.so", "libubsan.so")]
+    if not all(os.path.isabs(p) and os.path.exists(p) for p in pre):
+        pytest.skip("sanitizer runtime libraries not found")
+    script = textwrap.dedent("""
+        import json, numpy as np
+        from oracle import hbo
+        from tests import graphs
+        from stract_amd import synth
+        gold = json.load(open("tests/golden/hyperball_golden.json"))
+        regs = np.array(gold["size_cases"]["registers"], dtype=np.uint8)
+        assert hbo.hll_sizes(regs).tolist() == gold["size_cases"]["sizes"]
+        ids, row_ptr, src = graphs.dense_from_tuples(graphs.lcg_graph())
+        o = hbo.Dense(np.ascontiguousarray(ids["lo"]), row_ptr, src, threads=2)
+        assert o.run() == 7
+        g = synth.RmatGraph(10, 6000, threads=2)
+        fids, fvals, st = hbo.faithful_run(g.edges(salt=1, salt_seed=3))
+        assert st["passes"] > 2 and len(fvals) > 0
+        assert hbo.rank_results(fvals).max() == len(fvals) - 1
+        print("sanitized oracle ok")
+    """)
+    env = dict(os.environ, LD_PRELOAD=" ".join(pre), ASAN_OPTIONS="detect_leaks=0", OMP_NUM_THREADS="2", PYTHONPATH=str(work))
+    r = subprocess.run([sys.executable, "-c", script], cwd=str(work), capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0 and "sanitized oracle ok" in r.stdout, (r.stdout[-1000:], r.stderr[-3000:])
