@@ -41,3 +41,28 @@ def test_smoke_entry_point():
     import __graft_entry__ as g
 
     g.smoke()
+
+
+@pytest.mark.gpu
+def test_offline_bridge_tool(tmp_path):
+    """tools/centrality_from_records.py on a dump of raw records = the operator mirror on the same records."""
+    import numpy as np
+
+    from oracle import hbo
+    from stract_amd import synth
+    from stract_amd.harmonic import EdgeListGraph, HarmonicCentrality
+
+    g = synth.RmatGraph(11, 12_000)
+    e = g.edges(salt=1, salt_seed=2)
+    rec = tmp_path / "records.bin"
+    e.tofile(str(rec))
+    out = tmp_path / "out.csv"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "centrality_from_records.py"), str(rec), str(out),
+                        "--chunk-records", "5000"], cwd=ROOT, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    rows = [line.strip().split(",") for line in open(out)][1:]
+    hc = HarmonicCentrality.calculate(EdgeListGraph(e))
+    ids, vals = hc.arrays()
+    assert [int(x[0], 16) for x in rows] == [(int(h) << 64) | int(l) for l, h in zip(ids["lo"], ids["hi"])]
+    assert [float(x[1]) for x in rows] == vals.tolist()
+    assert [int(x[2]) for x in rows] == hbo.rank_results(vals).tolist()
