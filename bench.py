@@ -11,16 +11,24 @@ torch.distributed.run, one rank per GPU).  Prints ONE JSON line on rank 0.
               (CSR by destination) already resident in HBM when the timed region starts.
   workload  = BASELINE.json configs[2] (10M-host / 200M-edge R-MAT, the roofline config) by
               default; --config C2 selects configs[1] (1M/20M: fits the 256 MiB Infinity Cache, so
-              it says little about HBM), C4 = configs[3].
+              it says little about HBM), C4 = configs[3], C5 = configs[4], LT = the long-tail graph.
   N > 1     = the same graph partitioned over the ranks (strong scaling), one RCCL collective of
               the counters per pass: --partition dest (default) = rows by owner,
               ncclAllGather of the owned slices; --partition edge = the north-star edge partition
               with ncclAllReduce(max, u8).
-  roofline  = dominant kernel (dense pull over the hub chunks): algorithmic bytes per launch / its
-              mean duration (HIP events on the library's stream) vs 8 TB/s; the whole dense pass
-              (68*m_eff + 192.25*n bytes) is reported next to it.
+  roofline  = SURVEY.md §8(d): HBM-bound.  Headline `achieved`/`frac` = the WHOLE dense pass
+              (pass 0: 68*m_eff + 192.25*n algorithmic bytes; later dense passes B_t with their own
+              A_t) over its measured GPU time (HIP events on the library's stream) vs 8 TB/s.
+              `dominant_kernel` = the level-1 hub-chunk launch alone: 68 B x the REAL edges it
+              gathers (no partial-row traffic booked), over its own event-timed duration.
+              `whole_loop` = sum_t B_t / t_loop with B_t = 68*A_t + 4*(m-A_t) + 184*V_t + 8n + n/4.
+  parity    = every line carries `parity_bit_exact`: final (NodeID, f64) list vs the oracle when the
+              CPU run converges inside its budget (always with --verify), else an order-independent
+              checksum of all registers + Kahan state after the last pass the CPU finished.
   cpu_baseline = the CPU oracle's dense OpenMP port of the reference arithmetic, timed on
-              this box's host cores on the same graph for a bounded number of passes.
+              this box's host cores on the same graph for a bounded number of passes; the GPU time
+              of the SAME passes is reported next to it (like for like); `cpu_faithful` = the
+              single-thread structure-faithful form on C1.
 """
 import argparse
 import json
@@ -35,6 +43,7 @@ if ROOT not in sys.path:
 import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+HBM_COPY_GBS = 6290.0
 
 
 def parse():
@@ -42,7 +51,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--config", default=os.environ.get("HB_BENCH_CONFIG", "C3"), help="C1|C2|C3|C4 or scale:m")
+    ap.add_argument("--config", default=os.environ.get("HB_BENCH_CONFIG", "C3"), help="C1|C2|C3|C4|C5|LT or scale:m")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="CPU-baseline time bound (0 = skip)")
     ap.add_argument("--partition", default="dest", choices=["dest", "edge"],
                     help="N > 1: destination partition + all-gather per pass (default) or the north-star "
@@ -50,9 +59,22 @@ def parse():
     ap.add_argument("--flags", type=int, default=0)
     ap.add_argument("--chunk", type=int, default=0)
     ap.add_argument("--tune", default="", help="comma separated hb_options.tune values")
-    ap.add_argument("--verify", action="store_true", help="compare the final result with the oracle (full CPU run)")
+    ap.add_argument("--verify", action="store_true", help="run the CPU oracle to convergence and compare the final result")
     ap.add_argument("--pass-log", default="", help="write per-pass stats JSON here")
     return ap.parse_args()
+
+
+def pass_bytes(ps, n, m_eff, rows_with_in):
+    """Algorithmic HBM bytes of one pass, SURVEY.md §8(d):
+    B_t = 68*A_t + 4*(m_eff - A_t) + 184*V_t + 8*n + n/4; pass 0 = 68*m_eff + 192.25*n."""
+    a = min(int(ps["active_edges"]), m_eff)
+    if ps["pass"] == 0:
+        a, v = m_eff, n
+    elif ps["mode"] == 0:
+        v = rows_with_in  # dense pass: every row with an in-edge has (almost surely) an active one
+    else:
+        v = int(ps["touched"])
+    return 68.0 * a + 4.0 * (m_eff - a) + 184.0 * v + 8.0 * n + n / 4.0
 
 
 def main():
@@ -78,14 +100,8 @@ def main():
     from stract_amd import _lib, dist, synth
 
     # ---- synthetic input (identical on every rank, deterministic seed)
-    if a.config in synth.CONFIGS:
-        cfg = synth.CONFIGS[a.config]
-        scale, m_target, label = cfg["scale"], cfg["m"], cfg["label"]
-    else:
-        scale, m_target = (int(x) for x in a.config.split(":"))
-        label = "R-MAT scale %d / %d edges" % (scale, m_target)
     t0 = time.perf_counter()
-    g = synth.RmatGraph(scale, m_target)
+    g, scale, label = synth.make_config(a.config)
     t_gen = time.perf_counter() - t0
     n, m_eff = int(g.n), int(g.m)
 
@@ -121,9 +137,9 @@ def main():
         one_step()
     barrier()
     t0 = time.perf_counter()
-    hub_ms, main_ms, dense_passes, loop_ms, gpu_ms, coll_ms, d2h_ms = 0.0, 0.0, 0, 0.0, 0.0, 0.0, 0.0
+    loop_ms, gpu_ms, coll_ms, d2h_ms = 0.0, 0.0, 0.0, 0.0
     passes = 0
-    last_pass_stats = []
+    all_pass_stats = []
     for _ in range(a.steps):
         st = one_step()
         passes = int(st["passes"])
@@ -131,12 +147,7 @@ def main():
         gpu_ms += st["ms_loop_gpu"]
         coll_ms += st["ms_collective"]
         d2h_ms += st["ms_d2h"]
-        last_pass_stats = ctx.pass_stats()
-        for ps in last_pass_stats:
-            if ps["mode"] == 0:  # dense pass: hub-level launches (ev0..ev1) + the real-row launch (ev1..ev2)
-                hub_ms += ps["ms_gpu"] - ps["ms_main"] - ps["ms_collective"]
-                main_ms += ps["ms_main"]
-                dense_passes += 1
+        all_pass_stats.append(ctx.pass_stats())
     barrier()
     dt = time.perf_counter() - t0
     if td is not None:
@@ -145,35 +156,72 @@ def main():
         dt = float(tt.item())
     ids, vals = ctx.results()
     stats = ctx.stats()
+    last_pass_stats = all_pass_stats[-1] if all_pass_stats else []
+
+    # ---- parity + CPU baseline (rank 0 computes; a checksum rerun, if needed, is collective)
+    cpu, parity = None, None
+    if a.cpu_seconds > 0 or a.verify:
+        cpu, parity = cpu_and_parity(a, g, ctx, td, rank, world, passes, ids, vals, last_pass_stats)
 
     if rank == 0:
         steps = max(a.steps, 1)
         teps = m_eff * passes * steps / dt
-        # Dominant kernel (rocprofv3 --stats, profiles/): the dense pull over the hub chunks,
-        # pass_kernel<REAL=false, FRONTIER=false, ...>, launched once per virtual level per dense pass.
-        # Algorithmic bytes of one dense pass over the virtual rows: per gathered source 64 B counter + 4 B
-        # index; per virtual row 64 B partial read + 64 B partial write + 8 B row pointer.  Per launch =
-        # that / levels (the same average rocprofv3 reports for the kernel symbol).
-        levels = max(int(stats["levels"]), 1)
-        v_edges, v_rows = int(stats["virtual_edges"]), int(stats["virtual_rows"])
+        rows_in = int(stats["rows_with_in_edges"])
+        # per-pass averages over the timed steps
+        T = len(last_pass_stats)
+        avg = []
+        for t in range(T):
+            rows = [s[t] for s in all_pass_stats if len(s) == T]
+            d = dict(rows[-1])
+            for k in ("ms_gpu", "ms_main", "ms_level1", "ms_collective"):
+                d[k] = float(np.mean([r[k] for r in rows]))
+            d["alg_bytes"] = pass_bytes(d, n, m_eff, rows_in)
+            avg.append(d)
+        dense = [d for d in avg if d["mode"] == 0]
         roof = None
-        if dense_passes and v_rows:
-            alg_bytes = (68.0 * v_edges + 136.0 * v_rows) / levels
-            avg_ms = hub_ms / dense_passes / levels
-            achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
-            traffic = _pmc_traffic(a.config)
+        if dense:
+            b_dense = sum(d["alg_bytes"] for d in dense)
+            ms_dense = sum(d["ms_gpu"] - d["ms_collective"] for d in dense)
+            achieved = b_dense / (ms_dense * 1e-3) / 1e9
+            b_loop = sum(d["alg_bytes"] for d in avg)
+            ms_loop_gpu = sum(d["ms_gpu"] for d in avg)
+            l1_edges = int(stats["level1_edges"])
+            l1_ms = float(np.mean([d["ms_level1"] for d in dense]))
+            dom = None
+            if l1_edges and l1_ms > 0:
+                dom_b = 68.0 * l1_edges
+                traffic, traffic_src = _pmc_traffic(a.config)
+                dom = {"kernel": "hbk::pass_kernel<false,false,false,false,4> level-1 launch (dense pull over hub chunks)",
+                       "alg_bytes_per_launch": dom_b, "alg_bytes_def": "68 B x real edges gathered by the launch (%d)" % l1_edges,
+                       "avg_launch_ms": round(l1_ms, 4), "launches": len(dense) * steps,
+                       "achieved": round(dom_b / (l1_ms * 1e-3) / 1e9, 1), "frac": round(dom_b / (l1_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                       "traffic": traffic, "traffic_source": traffic_src}
+            p0 = avg[0]
             roof = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                    "kernel": "hbk::pass_kernel<false,false,false,false,4> (dense pull over hub chunks)",
-                    "alg_bytes_per_launch": alg_bytes, "avg_launch_ms": round(avg_ms, 4),
-                    "launches": dense_passes * levels,
-                    "whole_dense_pass": {"alg_bytes": 68.0 * m_eff + 192.25 * n,
-                                         "avg_ms": round((hub_ms + main_ms) / dense_passes, 4),
-                                         "achieved_GBs": round((68.0 * m_eff + 192.25 * n) /
-                                                               ((hub_ms + main_ms) / dense_passes * 1e-3) / 1e9, 1)}}
-        cpu = None
-        if world == 1 and a.cpu_seconds > 0:
-            cpu = cpu_baseline(g, a.cpu_seconds, passes, ids, vals, a.verify)
+                    "frac": round(achieved / HBM_PEAK_GBS, 4),
+                    "traffic": dom["traffic"] if dom else None,
+                    "what": "whole dense pass (all launches of the pass), algorithmic bytes B_t of SURVEY.md 8(d) over "
+                            "event-timed GPU time, mean over the %d dense passes" % len(dense),
+                    "frac_of_measured_copy_6.29TBs": round(achieved / HBM_COPY_GBS, 4),
+                    "pass0": {"alg_bytes": p0["alg_bytes"], "ms": round(p0["ms_gpu"] - p0["ms_collective"], 4),
+                              "achieved": round(p0["alg_bytes"] / ((p0["ms_gpu"] - p0["ms_collective"]) * 1e-3) / 1e9, 1)},
+                    "dominant_kernel": dom,
+                    "whole_loop": {"alg_bytes": b_loop, "ms_gpu": round(ms_loop_gpu, 4),
+                                   "achieved": round(b_loop / (ms_loop_gpu * 1e-3) / 1e9, 1),
+                                   "frac": round(b_loop / (ms_loop_gpu * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
+                    "per_pass": [{"t": int(d["pass"]), "mode": int(d["mode"]), "A_t": int(d["active_edges"]),
+                                  "V_t": (n if d["pass"] == 0 else rows_in if d["mode"] == 0 else int(d["touched"])),
+                                  "ms": round(d["ms_gpu"], 4),
+                                  "frac": round(d["alg_bytes"] / (max(d["ms_gpu"], 1e-6) * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+                                 for d in avg]}
+        gathered = sum(min(int(d["active_edges"]), m_eff) if d["pass"] else m_eff for d in avg)
+        n_pad = (n + 63) // 64 * 64
+        wire = None
+        if world > 1:
+            wire = {"ran": a.partition,
+                    "edge_allreduce_bytes_per_gpu_per_pass": 2.0 * (world - 1) / world * n_pad * 64,
+                    "dest_allgather_bytes_per_gpu_per_pass": (world - 1) / world * (n_pad * 64 + n_pad / 8),
+                    "ms_collective_per_pass": round(coll_ms / steps / max(passes, 1), 4)}
         out = {
             "metric": "HyperBall traversed edges/sec (GTEPS)",
             "value": round(teps / 1e9, 4),
@@ -187,23 +235,29 @@ def main():
             "vs_baseline": None,
             "dtype": "u8",
             "data": "synthetic",
-            "config": {"workload": "%s %s (R-MAT scale %d, a,b,c,d=.57,.19,.19,.05, seed 0x5712AC7)" % (a.config, label, scale),
+            "config": {"workload": "%s %s" % (a.config, label),
                        "n_hosts": n, "m_eff": m_eff, "passes_T": passes,
                        "parallelism": ("1 GPU" if world == 1 else
                                        "destination-partition x%d + allgather(u8)/pass" % world if a.partition == "dest" else
                                        "edge-partition x%d + allreduce(max,u8)/pass" % world)},
+            "parity_bit_exact": None if parity is None else parity["bit_exact"],
+            "parity": parity,
             "roofline": roof,
             "cpu_baseline": cpu,
             "detail": {"ms_loop_per_step": round(loop_ms / steps, 3), "ms_gpu_passes_per_step": round(gpu_ms / steps, 3),
                        "ms_collective_per_step": round(coll_ms / steps, 3), "ms_finish_per_step": round(d2h_ms / steps, 3),
                        "loop_gteps": round(m_eff * passes / (loop_ms / steps * 1e-3) / 1e9, 4) if loop_ms else None,
+                       "gathered_edges_per_run": gathered,
+                       "gathered_gteps": round(gathered / (loop_ms / steps * 1e-3) / 1e9, 4) if loop_ms else None,
+                       "collective": wire,
                        "results": int(len(vals)), "s_generate": round(t_gen, 2), "s_load": round(t_load, 2),
                        "ms_plan": round(stats["ms_plan"], 1), "ms_h2d": round(stats["ms_h2d"], 1),
-                       "device_bytes": int(stats["device_bytes"]), "virtual_rows": int(stats["virtual_rows"])},
+                       "device_bytes": int(stats["device_bytes"]), "virtual_rows": int(stats["virtual_rows"]),
+                       "level1_edges": int(stats["level1_edges"]), "direct_edges": int(stats["direct_edges"])},
         }
         if a.pass_log:
             with open(a.pass_log, "w") as f:
-                json.dump({"config": out["config"], "passes": last_pass_stats}, f, indent=1)
+                json.dump({"config": out["config"], "passes": avg}, f, indent=1)
         print(json.dumps(out), flush=True)
     ctx.close()
     if td is not None:
@@ -212,18 +266,19 @@ def main():
 
 
 def _pmc_traffic(config):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC summary
-    (profiles/pmc_<config>.json, produced by tools/pmc_summary.py), or None."""
-    p = os.path.join(ROOT, "profiles", "current_%s_pmc.json" % config)
+    """HBM bytes per launch of the dominant kernel: NOT measured by this run - read from the newest
+    committed rocprofv3 PMC summary (profiles/current_<config>_pmc.json, tools/export_profile.py);
+    returns (bytes or None, source file or None)."""
+    rel = os.path.join("profiles", "current_%s_pmc.json" % config)
     try:
-        with open(p) as f:
+        with open(os.path.join(ROOT, rel)) as f:
             d = json.load(f)
         for k, v in d.items():
             if "pass_kernel<false, false, false, false, 4>" in k:
-                return v.get("hbm_bytes_per_dispatch")
+                return v.get("hbm_bytes_per_dispatch"), rel + " (committed rocprofv3 --pmc run of the same command)"
     except Exception:
         pass
-    return None
+    return None, None
 
 
 def _cpu_quota():
@@ -244,21 +299,14 @@ def _cpu_quota():
     return None
 
 
-def cpu_baseline(g, seconds, gpu_passes, gpu_ids, gpu_vals, verify):
-    """Oracle (dense OpenMP port of the reference arithmetic) on this box's host cores, on the
-    same graph, for as many passes as fit in `seconds` (all of them with --verify)."""
-    from oracle import hbo
-
-    ncpu = os.cpu_count() or 1
-    quota = _cpu_quota()  # containers: the cgroup CPU quota can be far below the visible hardware threads
-    # pick the OpenMP thread count that is fastest on THIS box (all hardware threads is not always best:
-    # SMT, NUMA, container CPU quotas): two dense passes of a small calibration graph per candidate
-    from stract_amd import synth
+def _pick_threads(hbo, synth, ncpu, quota):
+    """OpenMP thread count that is fastest on THIS box (SMT, NUMA, container CPU quotas): two dense passes
+    of a small calibration graph per candidate."""
     cal = synth.RmatGraph(19, 4_000_000)
     best_t, cores = None, ncpu
     cands = {ncpu, max(ncpu // 2, 1), max(ncpu // 4, 1), min(ncpu, 64), min(ncpu, 32), min(ncpu, 16)}
     if quota:
-        cands |= {min(ncpu, quota), min(ncpu, 2 * quota)}
+        cands |= {min(ncpu, quota), min(ncpu, 2 * quota), min(ncpu, 4 * quota)}
     for th in sorted(cands, reverse=True):
         oc = hbo.Dense(cal.id_low64(), cal.row_ptr, cal.src, threads=th)
         oc.step(0)
@@ -269,25 +317,86 @@ def cpu_baseline(g, seconds, gpu_passes, gpu_ids, gpu_vals, verify):
         oc.close()
         if best_t is None or dt < best_t:
             best_t, cores = dt, th
-    o = hbo.Dense(g.id_low64(), g.row_ptr, g.src, threads=cores)
-    t0 = time.perf_counter()
-    done, has = 0, True
-    while has and (verify or time.perf_counter() - t0 < seconds):
-        has, _ = o.step(hbo.FRONTIER)
-        done += 1
-    dt = time.perf_counter() - t0
-    res = {"value": round(g.m * done / dt / 1e9, 5), "unit": "GTEPS", "cores": cores, "kind": "port",
-           "sample": "first %d of %d passes of the same graph, oracle dense OpenMP port (oracle/hb_oracle.c), %.1f s, "
-                     "%d OpenMP threads (fastest of a calibration sweep; %d hardware threads visible, cgroup CPU quota %s)"
-                     % (done, gpu_passes, dt, cores, ncpu, quota if quota else "none")}
-    if quota:
-        res["cpu_quota"] = quota
-    if not has:  # converged inside the budget: a free end-to-end parity check
-        vals, keep, k = o.finish()
-        same = (done == gpu_passes and k == len(gpu_vals) and np.array_equal(gpu_ids, g.ids[keep]) and
-                np.array_equal(gpu_vals.view(np.uint64), vals[keep].view(np.uint64)))
-        res["parity_bit_exact"] = bool(same)
-    return res
+    return cores
+
+
+def cpu_and_parity(a, g, ctx, td, rank, world, gpu_passes, gpu_ids, gpu_vals, gpu_pass_stats):
+    """Rank 0: oracle (dense OpenMP port of the reference arithmetic) on this box's host cores, on the
+    same graph, for as many passes as fit in --cpu-seconds (all of them with --verify).  Parity: the final
+    (NodeID, f64) list when the oracle converged, else a checksum of registers (+ Kahan state on one GPU)
+    after the last pass the oracle finished - the GPU is re-run for that many passes (collectively for
+    N > 1).  Returns (cpu_baseline dict or None, parity dict)."""
+    import torch
+
+    cpu, parity, done, o = None, None, 0, None
+    if rank == 0:
+        from oracle import hbo
+        from stract_amd import synth
+
+        ncpu = os.cpu_count() or 1
+        quota = _cpu_quota()  # containers: the cgroup CPU quota can be far below the visible hardware threads
+        cores = _pick_threads(hbo, synth, ncpu, quota)
+        o = hbo.Dense(g.id_low64(), g.row_ptr, g.src, threads=cores)
+        t0 = time.perf_counter()
+        has = True
+        cpu_pass_s = []
+        while has and (a.verify or time.perf_counter() - t0 < a.cpu_seconds):
+            t1 = time.perf_counter()
+            has, _ = o.step(hbo.FRONTIER)
+            cpu_pass_s.append(time.perf_counter() - t1)
+            done += 1
+        dt = time.perf_counter() - t0
+        gpu_same_ms = sum(ps["ms_gpu"] for ps in gpu_pass_stats[:done])
+        cpu = {"value": round(g.m * done / dt / 1e9, 5), "unit": "GTEPS", "cores": cores, "kind": "port",
+               "sample": "first %d of %d passes of the same graph, oracle dense OpenMP port (oracle/hb_oracle.c), %.1f s, "
+                         "%d OpenMP threads (fastest of a calibration sweep; %d hardware threads visible, cgroup CPU quota %s)"
+                         % (done, gpu_passes, dt, cores, ncpu, quota if quota else "none"),
+               "converged": not has, "seconds": round(dt, 3),
+               "gpu_same_passes": {"passes": done, "ms": round(gpu_same_ms, 3),
+                                   "gteps": round(g.m * done / (gpu_same_ms * 1e-3) / 1e9, 3) if gpu_same_ms else None,
+                                   "speedup": round(dt * 1e3 / gpu_same_ms, 1) if gpu_same_ms else None}}
+        if quota:
+            cpu["cpu_quota"] = quota
+        if not has:
+            cpu["seconds_to_convergence"] = round(dt, 3)
+            ovals, keep, k = o.finish()
+            same = (done == gpu_passes and k == len(gpu_vals) and np.array_equal(gpu_ids, g.ids[keep]) and
+                    np.array_equal(gpu_vals.view(np.uint64), ovals[keep].view(np.uint64)))
+            parity = {"bit_exact": bool(same), "scope": "final (NodeID, f64) list after all %d passes, %d results" % (done, k),
+                      "oracle": "oracle/hb_oracle.c dense form (parity unpinned against the Rust reference, see DESIGN.md)"}
+        # the structure-faithful single-thread form (what `stract centrality harmonic` does), C1 only
+        try:
+            c1 = synth.RmatGraph(synth.CONFIGS["C1"]["scale"], synth.CONFIGS["C1"]["m"])
+            _, _, fst = hbo.faithful_run(c1.edges())
+            cpu["cpu_faithful"] = {"value": round(fst["m_eff"] * fst["passes"] / fst["seconds_loop"] / 1e9, 6), "unit": "GTEPS",
+                                   "cores": 1, "sample": "C1 (%d hosts / %d edges), all %d passes, %.2f s, single thread, "
+                                   "ordered map + per-pass clone + re-dedup + bloom (hbo.faithful_run)"
+                                   % (fst["n"], fst["m_eff"], fst["passes"], fst["seconds_loop"])}
+        except Exception as e:  # pragma: no cover
+            cpu["cpu_faithful"] = {"error": str(e)}
+    # did the oracle stop early?  then compare state checksums after `done` passes
+    need = torch.tensor([done if (rank == 0 and parity is None) else 0], dtype=torch.int64, device="cuda")
+    if td is not None:
+        td.broadcast(need, src=0)
+    k = int(need.item())
+    if k > 0:
+        ctx.begin()
+        for _ in range(k):
+            ctx.step()
+        hr, hk = ctx.state_hash()
+        if rank == 0:
+            ohr, ohk = o.state_hash()
+            same = (hr == ohr) and (world > 1 or hk == ohk)
+            parity = {"bit_exact": bool(same),
+                      "scope": "checksum of all %d x 64 registers%s after pass %d of %d (the CPU budget ended there)"
+                               % (g.n, "" if world > 1 else " and of every Kahan (sum, err)", k, gpu_passes),
+                      "oracle": "oracle/hb_oracle.c dense form (parity unpinned against the Rust reference, see DESIGN.md)"}
+        ctx.run()  # leave the context finished (results valid)
+    if rank == 0 and o is not None:
+        o.close()
+    if world > 1:
+        cpu = None  # the CPU baseline is reported at N = 1 only; parity is reported at every N
+    return cpu, parity
 
 
 if __name__ == "__main__":

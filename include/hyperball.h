@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define HB_ABI_VERSION 1
+#define HB_ABI_VERSION 2
 
 /* ---- error codes -------------------------------------------------------------- */
 #define HB_OK 0
@@ -79,6 +79,9 @@ typedef struct hb_edge {
                                         owned counter slices per pass instead of an all-reduce          */
 #define HB_FLAG_HOST_INGEST   0x400u /* hb_load_edges: reduce the records on the host (hb_host.cpp) instead of
                                         on the GPU (hb_ingest.hip); same result                      */
+#define HB_FLAG_BITMAP_FRONTIER 0x800u /* mid-tail passes: the bitmap frontier pass (every index read and bit-tested)
+                                         instead of the push mode (changed nodes set position bits in their readers'
+                                         64-bit row masks); multi-GPU contexts always use the bitmap pass; same results */
 #define HB_FLAG_RCCL_SELF     0x80u /* world_size == 1 but still create a 1-rank communicator and run
                                        the collectives (exercises the RCCL call path on one GPU)   */
 
@@ -124,6 +127,10 @@ typedef struct hb_stats {
     uint64_t device_bytes;  /* device memory held by the context                            */
     uint64_t virtual_edges; /* entries of the virtual rows' source lists, all levels        */
     uint64_t levels;        /* virtual levels = hub-kernel launches per pass                */
+    uint64_t level1_edges;  /* REAL edges gathered by the level-1 hub-chunk launch (the dominant kernel) */
+    uint64_t level1_rows;   /* hub-chunk rows of level 1 (padding rows excluded)            */
+    uint64_t direct_edges;  /* REAL edges gathered directly by the node-row launch          */
+    uint64_t rows_with_in_edges; /* nodes with >= 1 in-edge: V_t of a dense pass t >= 1      */
 } hb_stats;
 
 typedef struct hb_pass_stats {
@@ -131,11 +138,14 @@ typedef struct hb_pass_stats {
     uint64_t changed;       /* nodes whose counter changed in pass t                        */
     uint64_t active_edges;  /* A_t = edges whose source changed in pass t-1 (out-degree sum of those
                                nodes; with HB_FLAG_PASS_STATS counted edge by edge in frontier passes) */
-    uint64_t touched;       /* V_t (only with HB_FLAG_PASS_STATS, else 0)                   */
-    uint32_t mode;          /* 0 = dense (no frontier test), 1 = frontier bitmap, 2 = sparse worklists */
+    uint64_t touched;       /* frontier / sparse passes: node rows with >= 1 gathered source (<= V_t: a split
+                               row counts only when one of its partials changed); dense passes: 0   */
+    uint32_t mode;          /* 0 = dense (no frontier test), 1 = frontier bitmap, 2 = sparse worklists, 3 = push masks */
     float    ms_gpu;        /* GPU time of the pass (all its launches + collective)         */
     float    ms_main;       /* GPU time of the dominant launch (real rows)                  */
     float    ms_collective;
+    float    ms_level1;     /* GPU time of the level-1 hub-chunk launch (dense / frontier passes)   */
+    uint32_t reserved;
 } hb_pass_stats;
 
 /* ---- lifecycle --------------------------------------------------------------------- */
@@ -225,6 +235,12 @@ int hb_debug_copy_sizes(hb_ctx *ctx, uint64_t *out);
 /* Runs the device estimator (HyperLogLog::size, hyperloglog.rs:4484-4516) on `count`
  * arbitrary 64-byte register blocks. */
 int hb_debug_hll_size(hb_ctx *ctx, const uint8_t *regs, uint64_t count, uint64_t *out);
+/* Order-independent 64-bit checksums of the current state: out[0] over all counters, out[1] over the
+ * Kahan (sum, err) bit patterns; node v (v-th smallest NodeID) contributes a mix of (v, its words), summed
+ * mod 2^64 (definition: oracle/hb_oracle.c hbo_dense_state_hash computes the same function).  For per-pass
+ * parity at sizes where n*64 bytes are too many to ship.  Multi-rank contexts: out[1] = 0 (a rank holds the
+ * Kahan state of its own rows only); out[0] covers all counters (every rank holds them after the collective). */
+int hb_debug_state_hash(hb_ctx *ctx, uint64_t out[2]);
 /* Reduced graph as the library sees it after ingest (ascending-NodeID indexing):
  * any pointer may be NULL; row_ptr has n+1 entries, src has m_eff. */
 int hb_debug_copy_graph(hb_ctx *ctx, hb_u128 *ids, uint64_t *row_ptr, uint32_t *src);

@@ -395,6 +395,43 @@ uint64_t hbo_dense_finish(const hbo_dense *s, double *out, uint8_t *keep)
     return k;
 }
 
+
+/* Order-independent checksum of the state after the last executed pass (test infrastructure for
+ * per-pass parity at sizes where register arrays are too big to ship around): out[0] over the
+ * registers, out[1] over the Kahan (sum, err) bit patterns; node v contributes a 64-bit mix of
+ * (v, its words), contributions are added mod 2^64.  The GPU library computes the same function
+ * (hb_debug_state_hash). */
+static inline uint64_t hash_mix64(uint64_t x)
+{
+    x ^= x >> 33;
+    x *= 0xff51afd7ed558ccdull;
+    x ^= x >> 33;
+    x *= 0xc4ceb9fe1a85ec53ull;
+    x ^= x >> 33;
+    return x;
+}
+
+void hbo_dense_state_hash(const hbo_dense *s, uint64_t out[2])
+{
+    uint64_t hr = 0, hk = 0;
+#pragma omp parallel for schedule(static) reduction(+ : hr, hk) num_threads(eff_threads(s->threads, 8 * s->n))
+    for (int64_t v = 0; v < (int64_t)s->n; v++) {
+        uint64_t r = (uint64_t)v * 0x9E3779B97F4A7C15ull + 1ull;
+        for (int k = 0; k < 8; k++) {
+            uint64_t w;
+            memcpy(&w, s->old_regs + 64 * (uint64_t)v + 8 * k, 8);
+            r = hash_mix64(r ^ w);
+        }
+        hr += r;
+        uint64_t a, b;
+        memcpy(&a, &s->ksum[v], 8);
+        memcpy(&b, &s->kerr[v], 8);
+        hk += hash_mix64(hash_mix64(((uint64_t)v + 0x632BE59BD9B4E019ull) ^ a) ^ b);
+    }
+    out[0] = hr;
+    out[1] = hk;
+}
+
 /* ------------------------------------------------------------------------------- */
 /* structure-faithful path                                                           */
 /* ------------------------------------------------------------------------------- */

@@ -110,6 +110,9 @@ uint64_t hbo_dense_passes(const hbo_dense *);
  * (non-finite -> 0.0), keep[i] = sum_i > 0.  Returns number kept. */
 uint64_t hbo_dense_finish(const hbo_dense *, double *out, uint8_t *keep);
 void hbo_dense_set_bsearch(hbo_dense *, int variant);
+/* Order-independent 64-bit checksums of the state after the last executed pass: out[0] over the
+ * registers, out[1] over the Kahan (sum, err) bits (same function as hb_debug_state_hash). */
+void hbo_dense_state_hash(const hbo_dense *, uint64_t out[2]);
 
 /* ---- structure-faithful single-thread path ("what `stract centrality harmonic`
  *      does"): id-keyed ordered lookups, per-pass edge re-dedup, per-pass clone of the

@@ -71,6 +71,7 @@ def load():
     L.hbo_dense_finish.restype = U64
     L.hbo_dense_finish.argtypes = [P, P, P]
     L.hbo_dense_set_bsearch.argtypes = [P, ctypes.c_int]
+    L.hbo_dense_state_hash.argtypes = [P, P]
     L.hbo_faithful_run.restype = U64
     L.hbo_faithful_run.argtypes = [P, U64, P, P, U64, P]
     L.hbo_bloom_num_bits.restype = U64
@@ -174,6 +175,12 @@ class Dense:
 
     def passes(self):
         return self.L.hbo_dense_passes(self.h)
+
+    def state_hash(self):
+        """(registers checksum, Kahan checksum) of the state after the last executed pass."""
+        out = np.zeros(2, dtype=np.uint64)
+        self.L.hbo_dense_state_hash(self.h, out.ctypes.data)
+        return int(out[0]), int(out[1])
 
     def finish(self):
         """(values[n], keep[n]) - normalize_centralities on index space."""

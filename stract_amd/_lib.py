@@ -26,6 +26,7 @@ HB_FLAG_RCCL_SELF = 0x80
 HB_FLAG_NO_SPARSE = 0x100
 HB_FLAG_DEST_PARTITION = 0x200
 HB_FLAG_HOST_INGEST = 0x400
+HB_FLAG_BITMAP_FRONTIER = 0x800
 
 # numpy views of the plain-data structs
 U128 = np.dtype([("lo", "<u8"), ("hi", "<u8")])
@@ -67,6 +68,10 @@ class HbStats(ctypes.Structure):
         ("device_bytes", ctypes.c_uint64),
         ("virtual_edges", ctypes.c_uint64),
         ("levels", ctypes.c_uint64),
+        ("level1_edges", ctypes.c_uint64),
+        ("level1_rows", ctypes.c_uint64),
+        ("direct_edges", ctypes.c_uint64),
+        ("rows_with_in_edges", ctypes.c_uint64),
     ]
 
     def as_dict(self):
@@ -83,6 +88,8 @@ class HbPassStats(ctypes.Structure):
         ("ms_gpu", ctypes.c_float),
         ("ms_main", ctypes.c_float),
         ("ms_collective", ctypes.c_float),
+        ("ms_level1", ctypes.c_float),
+        ("reserved", ctypes.c_uint32),
     ]
 
     def as_dict(self):
@@ -120,6 +127,7 @@ _SIGNATURES = [
     ("hb_debug_copy_kahan", ctypes.c_int, [_P, _P, _P]),
     ("hb_debug_copy_sizes", ctypes.c_int, [_P, _P]),
     ("hb_debug_hll_size", ctypes.c_int, [_P, _P, _U64, _P]),
+    ("hb_debug_state_hash", ctypes.c_int, [_P, _P]),
     ("hb_debug_copy_graph", ctypes.c_int, [_P, _P, _P, _P]),
     ("hb_debug_exchange", ctypes.c_int, [_P, ctypes.c_int, ctypes.c_int]),
     ("hb_step_local", ctypes.c_int, [_P]),
@@ -332,6 +340,12 @@ class Context:
         out = np.zeros(self.n(), dtype=np.uint64)
         self._check(self.lib.hb_debug_copy_sizes(self.h, _ptr(out)))
         return out
+
+    def state_hash(self):
+        """(registers checksum, Kahan checksum) of the current state (hb_debug_state_hash)."""
+        out = np.zeros(2, dtype=np.uint64)
+        self._check(self.lib.hb_debug_state_hash(self.h, _ptr(out)))
+        return int(out[0]), int(out[1])
 
     def hll_size(self, regs):
         regs = np.ascontiguousarray(regs, dtype=np.uint8).reshape(-1, 64)

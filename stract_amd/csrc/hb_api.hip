@@ -66,6 +66,9 @@ struct hb_ctx {
     // sparse (data-driven) tail passes: transposed work-row graph + worklists
     uint64_t *d_out_ptr = nullptr;
     uint32_t *d_out_rows = nullptr;
+    uint8_t *d_out_pos = nullptr;             // position of the source in the reader row's list (push mode)
+    unsigned long long *d_mask = nullptr;     // push mode: active-source mask per work row
+    bool push_ok = false;
     uint32_t *d_touch = nullptr;
     uint32_t *d_list_real = nullptr, *d_list_virt = nullptr, *d_seeds = nullptr, *d_heavy = nullptr, *d_medium = nullptr;
     unsigned int *d_sparse_counts = nullptr;
@@ -84,7 +87,7 @@ struct hb_ctx {
     uint64_t last_changed = 0;
     uint32_t max_passes = 4096;
     std::vector<hb_pass_stats> pstats;
-    hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}; // [5] = after the level-1 hub launch
     uint32_t cur_mode = 0;
 
     hb_stats stats{};
@@ -155,6 +158,9 @@ void free_graph_buffers(hb_ctx *c)
     c->d_out = nullptr;
     c->d_out_ptr = nullptr;
     c->d_out_rows = nullptr;
+    c->d_out_pos = nullptr;
+    c->d_mask = nullptr;
+    c->push_ok = false;
     c->d_touch = nullptr;
     c->d_list_real = c->d_list_virt = c->d_seeds = c->d_heavy = c->d_medium = nullptr;
     c->d_sparse_counts = nullptr;
@@ -199,6 +205,7 @@ int build_sparse_support(hb_ctx *c)
 {
     const Plan &p = c->plan;
     c->sparse_ok = false;
+    c->push_ok = false;
     if (unfused(c) || multi_rank(c) || (c->opt.flags & HB_FLAG_NO_SPARSE) || p.n == 0) return HB_OK;
     if (p.level_begin.size() > (size_t)hbk::kMaxSparseLevels + 1) return HB_OK; // very deep trees: bitmap modes only
     const uint64_t rows_total = p.n_pad + p.nv;
@@ -216,6 +223,13 @@ int build_sparse_support(hb_ctx *c)
     if ((rc = dev_alloc(c, &c->d_medium, p.n_pad))) return rc;
     if ((rc = dev_alloc(c, &c->d_sparse_counts, 64))) return rc;
     if ((rc = dev_alloc(c, &d_count, rows_total))) return rc; // stays allocated (small next to out_rows)
+    // push mode (mid-tail passes): 64-bit masks, so every work row must have <= 64 sources
+    const bool want_push = p.chunk <= 64 && !(c->opt.flags & HB_FLAG_BITMAP_FRONTIER);
+    if (want_push) {
+        if ((rc = dev_alloc(c, &c->d_out_pos, entries))) return rc;
+        if ((rc = dev_alloc(c, &c->d_mask, rows_total))) return rc;
+        HB_HIP(hipMemsetAsync(c->d_mask, 0, rows_total * sizeof(unsigned long long), c->stream));
+    }
     HB_HIP(hipMemsetAsync(d_count, 0, rows_total * sizeof(uint32_t), c->stream));
     const unsigned blocks = (unsigned)std::min<uint64_t>((rows_total * 4 + 255) / 256, (uint64_t)c->num_cu * 16);
     hipLaunchKernelGGL(hbk::transpose_count_kernel, dim3(blocks), dim3(256), 0, c->stream, (const uint64_t *)c->d_row_ptr,
@@ -235,10 +249,12 @@ int build_sparse_support(hb_ctx *c)
     HB_HIP(hipMemcpyAsync(c->d_out_ptr, optr.data(), (rows_total + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
     HB_HIP(hipMemsetAsync(d_count, 0, rows_total * sizeof(uint32_t), c->stream));
     hipLaunchKernelGGL(hbk::transpose_fill_kernel, dim3(blocks), dim3(256), 0, c->stream, (const uint64_t *)c->d_row_ptr,
-                       (const uint32_t *)c->d_src, rows_total, (const uint64_t *)c->d_out_ptr, d_count, c->d_out_rows);
+                       (const uint32_t *)c->d_src, rows_total, (const uint64_t *)c->d_out_ptr, d_count, c->d_out_rows,
+                       c->d_out_pos);
     HB_HIP(hipGetLastError());
     HB_HIP(hipStreamSynchronize(c->stream));
     c->sparse_ok = true;
+    c->push_ok = want_push;
     return HB_OK;
 }
 
@@ -296,6 +312,10 @@ int plan_and_upload(hb_ctx *c)
     c->stats.virtual_rows = p.nv;
     c->stats.virtual_edges = p.row_ptr.empty() ? 0 : p.row_ptr[p.n_pad + p.nv] - p.row_ptr[p.n_pad];
     c->stats.levels = p.level_begin.size() > 1 ? p.level_begin.size() - 1 : 0;
+    c->stats.level1_edges = p.level1_edges;
+    c->stats.level1_rows = p.level1_rows;
+    c->stats.direct_edges = p.direct_edges;
+    c->stats.rows_with_in_edges = p.rows_with_in_edges;
 
     // ---- device memory
     t0 = now_ms();
@@ -461,15 +481,18 @@ int step_local(hb_ctx *c)
                           (c->last_active * 100ull < (uint64_t)thr * c->m_global || thr > 100);
     const uint64_t sparse_div = c->opt.tune[6] ? c->opt.tune[6] : 64; // sparse when A_t * div < edges
     const bool sparse = frontier && c->sparse_ok && (c->last_active * sparse_div < c->m_global || c->opt.tune[6] == 1);
-    c->cur_mode = sparse ? 2 : (frontier ? 1 : 0);
+    const bool push = frontier && !sparse && c->push_ok;
+    c->cur_mode = sparse ? 2 : (push ? 3 : (frontier ? 1 : 0));
     const bool fused = !unfused(c);
     hbk::PassParams pp = make_params(c);
     HB_HIP(hipEventRecord(c->ev[0], c->stream));
-    if (sparse) {
+    if (sparse || push) {
         hbk::SparseParams sp{};
         sp.p = pp;
         sp.out_ptr = c->d_out_ptr;
         sp.out_rows = c->d_out_rows;
+        sp.out_pos = c->d_out_pos;
+        sp.mask = c->d_mask;
         sp.touch = c->d_touch;
         sp.list_real = c->d_list_real;
         sp.list_virt = c->d_list_virt;
@@ -482,16 +505,42 @@ int step_local(hb_ctx *c)
         for (size_t l = 0; l < p.level_begin.size(); l++) sp.level_begin[l] = p.level_begin[l];
         const uint64_t real_words = p.n_pad / 32;
         HB_HIP(hipMemsetAsync(c->d_sparse_counts, 0, 64 * sizeof(unsigned int), c->stream));
+        const unsigned sblocks = (unsigned)std::min<uint64_t>(std::max<uint64_t>(real_words / 256, 1), (uint64_t)c->num_cu * 4);
+        const unsigned wblocks = (unsigned)c->num_cu * 4;
+        if (push) {
+            // changed nodes -> bits in their readers' masks; then the levels, then the node rows
+            hipLaunchKernelGGL(hbk::sparse_collect_kernel<false>, dim3(sblocks), dim3(256), 0, c->stream, sp);
+            hipLaunchKernelGGL(hbk::sparse_expand_kernel<true>, dim3(wblocks), dim3(256), 0, c->stream, sp);
+            hipLaunchKernelGGL(hbk::sparse_expand_medium_kernel<true>, dim3(wblocks), dim3(256), 0, c->stream, sp);
+            hipLaunchKernelGGL(hbk::sparse_expand_heavy_kernel<true>, dim3(wblocks), dim3(256), 0, c->stream, sp);
+            const uint32_t bpc = c->opt.tune[0] ? c->opt.tune[0] : 8;
+            for (size_t l = 0; l + 1 < p.level_begin.size(); l++) {
+                sp.p.row_lo = p.level_begin[l];
+                sp.p.row_hi = p.level_begin[l + 1];
+                const uint64_t nt = (sp.p.row_hi - sp.p.row_lo + 63) / 64;
+                if (nt) {
+                    const unsigned blocks = (unsigned)std::min<uint64_t>(nt, (uint64_t)c->num_cu * bpc);
+                    hipLaunchKernelGGL(hbk::push_rows_kernel<false>, dim3(blocks), dim3(256), 0, c->stream, sp);
+                }
+                if (l == 0) HB_HIP(hipEventRecord(c->ev[5], c->stream));
+            }
+            HB_HIP(hipEventRecord(c->ev[1], c->stream));
+            sp.p.row_lo = 0;
+            sp.p.row_hi = p.n_pad;
+            if (p.n_pad) {
+                const unsigned blocks = (unsigned)std::min<uint64_t>(p.n_pad / 64, (uint64_t)c->num_cu * bpc);
+                hipLaunchKernelGGL(hbk::push_rows_kernel<true>, dim3(blocks), dim3(256), 0, c->stream, sp);
+            }
+            HB_HIP(hipEventRecord(c->ev[2], c->stream));
+        } else {
         HB_HIP(hipMemsetAsync(c->d_touch, 0, c->bits_words * 4, c->stream));
         HB_HIP(hipMemsetAsync(c->d_bits[c->cur ^ 1], 0, c->bits_words * 4, c->stream));           // this pass' changed bits
         if (c->bits_words > real_words)                                                             // this pass' virtual bits
             HB_HIP(hipMemsetAsync(c->d_bits[c->cur] + real_words, 0, (c->bits_words - real_words) * 4, c->stream));
-        const unsigned sblocks = (unsigned)std::min<uint64_t>(std::max<uint64_t>(real_words / 256, 1), (uint64_t)c->num_cu * 4);
-        hipLaunchKernelGGL(hbk::sparse_collect_kernel, dim3(sblocks), dim3(256), 0, c->stream, sp);
-        const unsigned wblocks = (unsigned)c->num_cu * 4;
-        hipLaunchKernelGGL(hbk::sparse_expand_kernel, dim3(wblocks), dim3(256), 0, c->stream, sp);
-        hipLaunchKernelGGL(hbk::sparse_expand_medium_kernel, dim3(wblocks), dim3(256), 0, c->stream, sp);
-        hipLaunchKernelGGL(hbk::sparse_expand_heavy_kernel, dim3(wblocks), dim3(256), 0, c->stream, sp);
+        hipLaunchKernelGGL(hbk::sparse_collect_kernel<true>, dim3(sblocks), dim3(256), 0, c->stream, sp);
+        hipLaunchKernelGGL(hbk::sparse_expand_kernel<false>, dim3(wblocks), dim3(256), 0, c->stream, sp);
+        hipLaunchKernelGGL(hbk::sparse_expand_medium_kernel<false>, dim3(wblocks), dim3(256), 0, c->stream, sp);
+        hipLaunchKernelGGL(hbk::sparse_expand_heavy_kernel<false>, dim3(wblocks), dim3(256), 0, c->stream, sp);
         for (int l = 0; l < sp.levels; l++) {
             sp.level = l;
             hipLaunchKernelGGL(hbk::sparse_rows_kernel<false>, dim3(wblocks), dim3(256), 0, c->stream, sp);
@@ -499,6 +548,7 @@ int step_local(hb_ctx *c)
         HB_HIP(hipEventRecord(c->ev[1], c->stream));
         hipLaunchKernelGGL(hbk::sparse_rows_kernel<true>, dim3(wblocks), dim3(256), 0, c->stream, sp);
         HB_HIP(hipEventRecord(c->ev[2], c->stream));
+        }
     } else {
         for (size_t l = 0; l + 1 < p.level_begin.size(); l++) {
             pp.row_lo = p.level_begin[l];
@@ -509,6 +559,7 @@ int step_local(hb_ctx *c)
                 pp.xcd_hi[x] = p.xcd_begin[x + 1];
             }
             launch_pass(c, pp, false, frontier, false);
+            if (l == 0) HB_HIP(hipEventRecord(c->ev[5], c->stream));
         }
         pp.xcd_map = 0;
         HB_HIP(hipEventRecord(c->ev[1], c->stream));
@@ -572,7 +623,9 @@ int step_finish(hb_ctx *c, int *has_changes)
     hb_pass_stats ps{};
     ps.pass = c->t;
     ps.changed = c->h_counters[0];
-    ps.active_edges = (c->opt.flags & HB_FLAG_PASS_STATS) ? c->h_counters[1] : c->last_active; // A_t
+    // A_t: the out-degree sum of the nodes changed in the previous pass; counted pair by pair in push mode
+    // (set mask bits of rows with node sources) and, with HB_FLAG_PASS_STATS, edge by edge in the bitmap mode
+    ps.active_edges = (c->cur_mode == 3 || (c->opt.flags & HB_FLAG_PASS_STATS)) ? c->h_counters[1] : c->last_active;
     ps.touched = c->h_counters[2];
     ps.mode = c->cur_mode;
     float ms_all = 0.f, ms_main = 0.f;
@@ -581,6 +634,11 @@ int step_finish(hb_ctx *c, int *has_changes)
     ps.ms_gpu = ms_all;
     ps.ms_main = ms_main;
     ps.ms_collective = c->comm ? ms_coll : 0.f;
+    if (c->cur_mode != 2 && p.level_begin.size() > 1) {
+        float ms_l1 = 0.f;
+        HB_HIP(hipEventElapsedTime(&ms_l1, c->ev[0], c->ev[5]));
+        ps.ms_level1 = ms_l1;
+    }
     c->pstats.push_back(ps);
     // counters.step(); changed_nodes = new_changed_nodes; t += 1 (harmonic.rs:273-275)
     c->last_changed = ps.changed;
@@ -591,6 +649,21 @@ int step_finish(hb_ctx *c, int *has_changes)
     c->pending_local = false;
     if (has_changes) *has_changes = c->has_changes ? 1 : 0;
     return HB_OK;
+}
+
+// The C ABI never unwinds (include/hyperball.h): every entry point that can allocate runs under this guard.
+template <class F>
+int guarded(hb_ctx *c, F &&f)
+{
+    try {
+        return f();
+    } catch (const std::bad_alloc &) {
+        try { return fail(c, HB_ERR_NOMEM, "out of host memory"); } catch (...) { return HB_ERR_NOMEM; }
+    } catch (const std::exception &e) {
+        try { return fail(c, HB_ERR_INVALID, std::string("C++ exception: ") + e.what()); } catch (...) { return HB_ERR_INVALID; }
+    } catch (...) {
+        try { return fail(c, HB_ERR_INVALID, "unknown C++ exception"); } catch (...) { return HB_ERR_INVALID; }
+    }
 }
 
 int set_device(hb_ctx *c)
@@ -619,72 +692,76 @@ int hb_device_count(int *count)
 
 int hb_rccl_unique_id(uint8_t out[128])
 {
-    hb_ctx *c = nullptr;
-    if (!out) return fail(c, HB_ERR_INVALID, "out == NULL");
-    static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId size");
-    ncclUniqueId id;
-    HB_NCCL(ncclGetUniqueId(&id));
-    std::memcpy(out, &id, 128);
-    return HB_OK;
+    return guarded(nullptr, [&]() -> int {
+        hb_ctx *c = nullptr;
+        if (!out) return fail(c, HB_ERR_INVALID, "out == NULL");
+        static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId size");
+        ncclUniqueId id;
+        HB_NCCL(ncclGetUniqueId(&id));
+        std::memcpy(out, &id, 128);
+        return HB_OK;
+    });
 }
 
 int hb_create(const hb_options *opt, hb_ctx **out)
 {
-    hb_ctx *c = nullptr; // errors before the ctx exists go to the thread-local slot
-    if (!out) return fail(c, HB_ERR_INVALID, "out == NULL");
-    *out = nullptr;
-    hb_options o{};
-    if (opt) {
-        size_t sz = opt->struct_size ? std::min<size_t>(opt->struct_size, sizeof(hb_options)) : sizeof(hb_options);
-        std::memcpy(&o, opt, sz);
-    } else {
-        o.device = -1;
-    }
-    int ndev = 0;
-    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
-        return fail(c, HB_ERR_NO_DEVICE, "no HIP device visible: this library has no CPU fallback");
-    int dev = o.device;
-    if (dev < 0) {
-        if (hipGetDevice(&dev) != hipSuccess) dev = 0;
-    }
-    if (dev >= ndev) return fail(c, HB_ERR_INVALID, "device ordinal out of range");
-    hipDeviceProp_t prop;
-    HB_HIP(hipGetDeviceProperties(&prop, dev));
-    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
-        return fail(c, HB_ERR_NO_DEVICE, std::string("device is ") + prop.gcnArchName + ", kernels are built for gfx950 only");
-    if (o.world_size > 1 && (o.rank < 0 || o.rank >= o.world_size)) return fail(c, HB_ERR_INVALID, "rank out of range");
-    hb_ctx *ctx = new (std::nothrow) hb_ctx();
-    if (!ctx) return fail(c, HB_ERR_NOMEM, "out of host memory");
-    ctx->opt = o;
-    ctx->device = dev;
-    ctx->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    ctx->arch = prop.gcnArchName;
-    ctx->max_passes = o.max_passes ? o.max_passes : 4096;
-    c = ctx;
-    auto bail = [&](int code) {
-        std::string m = ctx->err;
-        hb_destroy(ctx);
-        g_create_error = m;
-        return code;
-    };
-    if (hipSetDevice(dev) != hipSuccess) { ctx->err = "hipSetDevice failed"; return bail(HB_ERR_HIP); }
-    if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { ctx->err = "hipStreamCreate failed"; return bail(HB_ERR_HIP); }
-    for (int i = 0; i < 5; i++)
-        if (hipEventCreate(&ctx->ev[i]) != hipSuccess) { ctx->err = "hipEventCreate failed"; return bail(HB_ERR_HIP); }
-    if (hipHostMalloc((void **)&ctx->h_counters, hbk::kCounterWords * sizeof(unsigned long long)) != hipSuccess) { ctx->err = "hipHostMalloc failed"; return bail(HB_ERR_NOMEM); }
-    if (o.world_size > 1 && !(o.flags & HB_FLAG_NO_RCCL)) {
-        ncclUniqueId id;
-        std::memcpy(&id, o.rccl_id, 128);
-        ncclResult_t r = ncclCommInitRank(&ctx->comm, o.world_size, id, o.rank);
-        if (r != ncclSuccess) { ctx->err = std::string("ncclCommInitRank: ") + ncclGetErrorString(r); ctx->comm = nullptr; return bail(HB_ERR_RCCL); }
-    } else if (o.world_size == 1 && (o.flags & HB_FLAG_RCCL_SELF)) {
-        ncclUniqueId id;
-        std::memcpy(&id, o.rccl_id, 128);
-        ncclResult_t r = ncclCommInitRank(&ctx->comm, 1, id, 0);
-        if (r != ncclSuccess) { ctx->err = std::string("ncclCommInitRank: ") + ncclGetErrorString(r); ctx->comm = nullptr; return bail(HB_ERR_RCCL); }
-    }
-    *out = ctx;
-    return HB_OK;
+    return guarded(nullptr, [&]() -> int {
+        hb_ctx *c = nullptr; // errors before the ctx exists go to the thread-local slot
+        if (!out) return fail(c, HB_ERR_INVALID, "out == NULL");
+        *out = nullptr;
+        hb_options o{};
+        if (opt) {
+            size_t sz = opt->struct_size ? std::min<size_t>(opt->struct_size, sizeof(hb_options)) : sizeof(hb_options);
+            std::memcpy(&o, opt, sz);
+        } else {
+            o.device = -1;
+        }
+        int ndev = 0;
+        if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+            return fail(c, HB_ERR_NO_DEVICE, "no HIP device visible: this library has no CPU fallback");
+        int dev = o.device;
+        if (dev < 0) {
+            if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+        }
+        if (dev >= ndev) return fail(c, HB_ERR_INVALID, "device ordinal out of range");
+        hipDeviceProp_t prop;
+        HB_HIP(hipGetDeviceProperties(&prop, dev));
+        if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+            return fail(c, HB_ERR_NO_DEVICE, std::string("device is ") + prop.gcnArchName + ", kernels are built for gfx950 only");
+        if (o.world_size > 1 && (o.rank < 0 || o.rank >= o.world_size)) return fail(c, HB_ERR_INVALID, "rank out of range");
+        hb_ctx *ctx = new (std::nothrow) hb_ctx();
+        if (!ctx) return fail(c, HB_ERR_NOMEM, "out of host memory");
+        ctx->opt = o;
+        ctx->device = dev;
+        ctx->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+        ctx->arch = prop.gcnArchName;
+        ctx->max_passes = o.max_passes ? o.max_passes : 4096;
+        c = ctx;
+        auto bail = [&](int code) {
+            std::string m = ctx->err;
+            hb_destroy(ctx);
+            g_create_error = m;
+            return code;
+        };
+        if (hipSetDevice(dev) != hipSuccess) { ctx->err = "hipSetDevice failed"; return bail(HB_ERR_HIP); }
+        if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { ctx->err = "hipStreamCreate failed"; return bail(HB_ERR_HIP); }
+        for (int i = 0; i < 6; i++)
+            if (hipEventCreate(&ctx->ev[i]) != hipSuccess) { ctx->err = "hipEventCreate failed"; return bail(HB_ERR_HIP); }
+        if (hipHostMalloc((void **)&ctx->h_counters, hbk::kCounterWords * sizeof(unsigned long long)) != hipSuccess) { ctx->err = "hipHostMalloc failed"; return bail(HB_ERR_NOMEM); }
+        if (o.world_size > 1 && !(o.flags & HB_FLAG_NO_RCCL)) {
+            ncclUniqueId id;
+            std::memcpy(&id, o.rccl_id, 128);
+            ncclResult_t r = ncclCommInitRank(&ctx->comm, o.world_size, id, o.rank);
+            if (r != ncclSuccess) { ctx->err = std::string("ncclCommInitRank: ") + ncclGetErrorString(r); ctx->comm = nullptr; return bail(HB_ERR_RCCL); }
+        } else if (o.world_size == 1 && (o.flags & HB_FLAG_RCCL_SELF)) {
+            ncclUniqueId id;
+            std::memcpy(&id, o.rccl_id, 128);
+            ncclResult_t r = ncclCommInitRank(&ctx->comm, 1, id, 0);
+            if (r != ncclSuccess) { ctx->err = std::string("ncclCommInitRank: ") + ncclGetErrorString(r); ctx->comm = nullptr; return bail(HB_ERR_RCCL); }
+        }
+        *out = ctx;
+        return HB_OK;
+    });
 }
 
 void hb_destroy(hb_ctx *ctx)
@@ -695,7 +772,7 @@ void hb_destroy(hb_ctx *ctx)
     if (ctx->comm) (void)ncclCommDestroy(ctx->comm);
     free_graph_buffers(ctx);
     if (ctx->h_counters) (void)hipHostFree(ctx->h_counters);
-    for (int i = 0; i < 5; i++)
+    for (int i = 0; i < 6; i++)
         if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -710,32 +787,48 @@ int hb_device_name(const hb_ctx *ctx, char *name, uint64_t cap)
 
 int hb_device_synchronize(hb_ctx *c)
 {
-    if (!c) return HB_ERR_INVALID;
-    int rc = set_device(c);
-    if (rc) return rc;
-    HB_HIP(hipStreamSynchronize(c->stream));
-    return HB_OK;
+    return guarded(c, [&]() -> int {
+        if (!c) return HB_ERR_INVALID;
+        int rc = set_device(c);
+        if (rc) return rc;
+        HB_HIP(hipStreamSynchronize(c->stream));
+        return HB_OK;
+    });
 }
 
 // ---- input --------------------------------------------------------------------------------
 int hb_load_edges(hb_ctx *c, const hb_u128 *node_ids, uint64_t n, const hb_edge *edges, uint64_t m)
 {
-    if (!c) return HB_ERR_INVALID;
-    int rc = set_device(c);
-    if (rc) return rc;
-    c->stats = hb_stats{};
-    double t0 = now_ms();
-    // node/edge-set reduction: on the GPU (hb_ingest.hip) unless the host path is forced; identical output
-    std::string e = (c->opt.flags & HB_FLAG_HOST_INGEST) ? ingest_edges(node_ids, n, edges, m, &c->g)
-                                                        : gpu_ingest_edges((void *)c->stream, node_ids, n, edges, m, &c->g);
-    if (!e.empty())
-        return fail(c, e.find("memory") != std::string::npos ? HB_ERR_NOMEM : (e.find("hip") != std::string::npos ? HB_ERR_HIP : HB_ERR_LIMIT), e);
-    if (dest_mode(c)) keep_owned_rows(&c->g, (uint64_t)std::max(c->opt.world_size, 1), (uint64_t)c->opt.rank);
-    c->stats.ms_ingest = now_ms() - t0;
-    double ing = c->stats.ms_ingest;
-    rc = plan_and_upload(c);
-    c->stats.ms_ingest = ing;
-    return rc;
+    return guarded(c, [&]() -> int {
+        if (!c) return HB_ERR_INVALID;
+        int rc = set_device(c);
+        if (rc) return rc;
+        c->stats = hb_stats{};
+        double t0 = now_ms();
+        // node/edge-set reduction: on the GPU (hb_ingest.hip) unless the host path is forced; identical output
+        // The device pipeline keeps ~100 B per record resident at its peak (endpoint keys, sort double buffers):
+        // when that cannot fit, or an allocation fails anyway, the host path produces the same graph.
+        bool on_host = (c->opt.flags & HB_FLAG_HOST_INGEST) != 0;
+        if (!on_host) {
+            size_t free_b = 0, total_b = 0;
+            const double need = 100.0 * (double)m + 48.0 * (double)((node_ids && n) ? n : 0) + 512e6;
+            if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && need > (double)free_b) on_host = true;
+        }
+        std::string e = on_host ? ingest_edges(node_ids, n, edges, m, &c->g)
+                                : gpu_ingest_edges((void *)c->stream, node_ids, n, edges, m, &c->g);
+        if (!on_host && !e.empty() && (e.find("out of memory") != std::string::npos || e.find("OutOfMemory") != std::string::npos)) {
+            (void)hipGetLastError(); // clear the sticky allocation error
+            e = ingest_edges(node_ids, n, edges, m, &c->g);
+        }
+        if (!e.empty())
+            return fail(c, e.find("memory") != std::string::npos ? HB_ERR_NOMEM : (e.find("hip") != std::string::npos ? HB_ERR_HIP : HB_ERR_LIMIT), e);
+        if (dest_mode(c)) keep_owned_rows(&c->g, (uint64_t)std::max(c->opt.world_size, 1), (uint64_t)c->opt.rank);
+        c->stats.ms_ingest = now_ms() - t0;
+        double ing = c->stats.ms_ingest;
+        rc = plan_and_upload(c);
+        c->stats.ms_ingest = ing;
+        return rc;
+    });
 }
 
 int hb_append_edges(hb_ctx *c, const hb_edge *edges, uint64_t m)
@@ -751,159 +844,175 @@ int hb_append_edges(hb_ctx *c, const hb_edge *edges, uint64_t m)
 
 int hb_finalize(hb_ctx *c, const hb_u128 *node_ids, uint64_t n)
 {
-    if (!c) return HB_ERR_INVALID;
-    int rc = hb_load_edges(c, node_ids, n, c->pending.data(), c->pending.size());
-    std::vector<hb_edge>().swap(c->pending);
-    return rc;
+    return guarded(c, [&]() -> int {
+        if (!c) return HB_ERR_INVALID;
+        int rc = hb_load_edges(c, node_ids, n, c->pending.data(), c->pending.size());
+        std::vector<hb_edge>().swap(c->pending);
+        return rc;
+    });
 }
 
 int hb_load_dense(hb_ctx *c, const hb_u128 *sorted_ids, uint64_t n, const uint64_t *row_ptr, const uint32_t *src,
                   uint64_t m_eff)
 {
-    if (!c) return HB_ERR_INVALID;
-    int rc = set_device(c);
-    if (rc) return rc;
-    c->stats = hb_stats{};
-    double t0 = now_ms();
-    std::string e = check_dense(sorted_ids, n, row_ptr, src, m_eff);
-    if (!e.empty()) return fail(c, e.find("too many") != std::string::npos ? HB_ERR_LIMIT : HB_ERR_INVALID, e);
-    try {
-        c->g.ids.assign(sorted_ids, sorted_ids + n);
-        c->g.row_ptr.assign(row_ptr, row_ptr + n + 1);
-        if (n == 0) c->g.row_ptr.assign(1, 0);
-        c->g.src.assign(src, src + m_eff);
-    } catch (const std::bad_alloc &) {
-        return fail(c, HB_ERR_NOMEM, "out of host memory copying the graph");
-    }
-    c->g.m_input = m_eff;
-    c->g.m_unique = m_eff;
-    if (dest_mode(c)) keep_owned_rows(&c->g, (uint64_t)std::max(c->opt.world_size, 1), (uint64_t)c->opt.rank);
-    double ing = now_ms() - t0;
-    rc = plan_and_upload(c);
-    c->stats.ms_ingest = ing;
-    return rc;
+    return guarded(c, [&]() -> int {
+        if (!c) return HB_ERR_INVALID;
+        int rc = set_device(c);
+        if (rc) return rc;
+        c->stats = hb_stats{};
+        double t0 = now_ms();
+        std::string e = check_dense(sorted_ids, n, row_ptr, src, m_eff);
+        if (!e.empty()) return fail(c, e.find("too many") != std::string::npos ? HB_ERR_LIMIT : HB_ERR_INVALID, e);
+        try {
+            c->g.ids.assign(sorted_ids, sorted_ids + n);
+            c->g.row_ptr.assign(row_ptr, row_ptr + n + 1);
+            if (n == 0) c->g.row_ptr.assign(1, 0);
+            c->g.src.assign(src, src + m_eff);
+        } catch (const std::bad_alloc &) {
+            return fail(c, HB_ERR_NOMEM, "out of host memory copying the graph");
+        }
+        c->g.m_input = m_eff;
+        c->g.m_unique = m_eff;
+        if (dest_mode(c)) keep_owned_rows(&c->g, (uint64_t)std::max(c->opt.world_size, 1), (uint64_t)c->opt.rank);
+        double ing = now_ms() - t0;
+        rc = plan_and_upload(c);
+        c->stats.ms_ingest = ing;
+        return rc;
+    });
 }
 
 // ---- compute ------------------------------------------------------------------------------
 int hb_begin(hb_ctx *c)
 {
-    if (!c) return HB_ERR_INVALID;
-    if (!c->loaded) return fail(c, HB_ERR_INVALID, "hb_begin: no graph loaded");
-    int rc = set_device(c);
-    if (rc) return rc;
-    const Plan &p = c->plan;
-    {
-        hipError_t stale = hipGetLastError(); // an unchecked failure of an earlier call on this thread
-        if (stale != hipSuccess) return fail(c, HB_ERR_HIP, std::string("stale HIP error before hb_begin: ") + hipGetErrorString(stale));
-    }
-    // d_part needs no clearing: pass 0 is always dense, and a dense pass overwrites every partial without
-    // reading it (hb_kernels.hip.h)
-    HB_HIP(hipMemsetAsync(c->d_bits[0], 0, c->bits_words * 4, c->stream));
-    HB_HIP(hipMemsetAsync(c->d_bits[1], 0, c->bits_words * 4, c->stream));
-    HB_HIP(hipMemsetAsync(c->d_counters, 0, ((size_t)c->max_passes + 1) * hbk::kCounterWords * sizeof(unsigned long long), c->stream));
-    if (c->ksum_len > p.n_pad) // slice padding beyond the rows init_kernel writes (all-reduce mode)
-        HB_HIP(hipMemsetAsync(c->d_ksum + p.n_pad, 0, (c->ksum_len - p.n_pad) * sizeof(double), c->stream));
-    if (p.n_pad) {
-        unsigned blocks = (unsigned)((p.n_pad * 4 + 255) / 256);
-        hipLaunchKernelGGL(hbk::init_kernel, dim3(blocks), dim3(256), 0, c->stream, c->d_idlow, (const uint32_t *)c->d_sid_of, p.n_pad,
-                           c->d_regs[0], c->d_regs[1], c->d_ksum, c->d_kerr, c->d_size, c->d_bits[0], c->d_kdirty,
-                           c->d_raw, c->d_bias, c->d_lc);
-        HB_HIP(hipGetLastError());
-    }
-    HB_HIP(hipStreamSynchronize(c->stream));
-    c->t = 0;
-    c->cur = 0;
-    c->has_changes = true; // harmonic.rs:232
-    c->last_changed = p.n;
-    c->last_active = c->m_global;
-    c->pending_local = false;
-    c->pstats.clear();
-    c->begun = true;
-    c->finished = false;
-    c->res_count = 0;
-    return HB_OK;
+    return guarded(c, [&]() -> int {
+        if (!c) return HB_ERR_INVALID;
+        if (!c->loaded) return fail(c, HB_ERR_INVALID, "hb_begin: no graph loaded");
+        int rc = set_device(c);
+        if (rc) return rc;
+        const Plan &p = c->plan;
+        {
+            hipError_t stale = hipGetLastError(); // an unchecked failure of an earlier call on this thread
+            if (stale != hipSuccess) return fail(c, HB_ERR_HIP, std::string("stale HIP error before hb_begin: ") + hipGetErrorString(stale));
+        }
+        // d_part needs no clearing: pass 0 is always dense, and a dense pass overwrites every partial without
+        // reading it (hb_kernels.hip.h)
+        HB_HIP(hipMemsetAsync(c->d_bits[0], 0, c->bits_words * 4, c->stream));
+        HB_HIP(hipMemsetAsync(c->d_bits[1], 0, c->bits_words * 4, c->stream));
+        HB_HIP(hipMemsetAsync(c->d_counters, 0, ((size_t)c->max_passes + 1) * hbk::kCounterWords * sizeof(unsigned long long), c->stream));
+        if (c->ksum_len > p.n_pad) // slice padding beyond the rows init_kernel writes (all-reduce mode)
+            HB_HIP(hipMemsetAsync(c->d_ksum + p.n_pad, 0, (c->ksum_len - p.n_pad) * sizeof(double), c->stream));
+        if (p.n_pad) {
+            unsigned blocks = (unsigned)((p.n_pad * 4 + 255) / 256);
+            hipLaunchKernelGGL(hbk::init_kernel, dim3(blocks), dim3(256), 0, c->stream, c->d_idlow, (const uint32_t *)c->d_sid_of, p.n_pad,
+                               c->d_regs[0], c->d_regs[1], c->d_ksum, c->d_kerr, c->d_size, c->d_bits[0], c->d_kdirty,
+                               c->d_raw, c->d_bias, c->d_lc);
+            HB_HIP(hipGetLastError());
+        }
+        HB_HIP(hipStreamSynchronize(c->stream));
+        c->t = 0;
+        c->cur = 0;
+        c->has_changes = true; // harmonic.rs:232
+        c->last_changed = p.n;
+        c->last_active = c->m_global;
+        c->pending_local = false;
+        c->pstats.clear();
+        c->begun = true;
+        c->finished = false;
+        c->res_count = 0;
+        return HB_OK;
+    });
 }
 
 int hb_step_local(hb_ctx *c)
 {
-    if (!c) return HB_ERR_INVALID;
-    int rc = set_device(c);
-    if (rc) return rc;
-    return step_local(c);
+    return guarded(c, [&]() -> int {
+        if (!c) return HB_ERR_INVALID;
+        int rc = set_device(c);
+        if (rc) return rc;
+        return step_local(c);
+    });
 }
 
 int hb_step_finish(hb_ctx *c, int *has_changes)
 {
-    if (!c) return HB_ERR_INVALID;
-    int rc = set_device(c);
-    if (rc) return rc;
-    return step_finish(c, has_changes);
+    return guarded(c, [&]() -> int {
+        if (!c) return HB_ERR_INVALID;
+        int rc = set_device(c);
+        if (rc) return rc;
+        return step_finish(c, has_changes);
+    });
 }
 
 int hb_step(hb_ctx *c, int *has_changes)
 {
-    if (!c) return HB_ERR_INVALID;
-    int rc = set_device(c);
-    if (rc) return rc;
-    if ((rc = step_local(c))) return rc;
-    return step_finish(c, has_changes);
+    return guarded(c, [&]() -> int {
+        if (!c) return HB_ERR_INVALID;
+        int rc = set_device(c);
+        if (rc) return rc;
+        if ((rc = step_local(c))) return rc;
+        return step_finish(c, has_changes);
+    });
 }
 
 int hb_finish(hb_ctx *c)
 {
-    if (!c) return HB_ERR_INVALID;
-    if (!c->begun) return fail(c, HB_ERR_INVALID, "hb_finish: call hb_begin first");
-    int rc = set_device(c);
-    if (rc) return rc;
-    const Plan &p = c->plan;
-    double t0 = now_ms();
-    if (c->comm && p.n_pad) {
-        // every rank ends with all Kahan sums: in-place all-gather of the owned slices
-        HB_NCCL(ncclAllGather(c->d_ksum + (uint64_t)c->opt.rank * c->slice_rows, c->d_ksum, c->slice_rows, ncclDouble,
-                              c->comm, c->stream));
-    }
-    // normalize_centralities (harmonic.rs:178-195) on the device, in ascending-NodeID order;
-    // norm_factor = (num_nodes - 1) as f64 (:229)
-    const double norm = (double)(p.n ? p.n - 1 : 0);
-    unsigned long long *cnt = c->d_counters + (size_t)c->max_passes * hbk::kCounterWords; // the spare slot
-    HB_HIP(hipMemsetAsync(cnt, 0, hbk::kCounterWords * sizeof(unsigned long long), c->stream));
-    if (p.n) {
-        unsigned blocks = (unsigned)std::min<uint64_t>((p.n + 255) / 256, (uint64_t)c->num_cu * 8);
-        hipLaunchKernelGGL(hbk::finish_kernel, dim3(blocks), dim3(256), 0, c->stream, (const double *)c->d_ksum,
-                           (const uint32_t *)c->d_dev_of, p.n, norm, c->d_out, cnt);
-        HB_HIP(hipGetLastError());
-        HB_HIP(hipMemcpyAsync(c->h_out, c->d_out, p.n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    }
-    HB_HIP(hipMemcpyAsync(c->h_counters, cnt, hbk::kCounterWords * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
-    HB_HIP(hipStreamSynchronize(c->stream));
-    c->res_count = 0;
-    for (int s = 0; s < hbk::kStripes; s++) c->res_count += c->h_counters[4 * s];
-    c->stats.ms_d2h = now_ms() - t0;
-    c->stats.results = c->res_count;
-    c->stats.passes = c->t;
-    double g = 0, coll = 0;
-    for (auto &ps : c->pstats) { g += ps.ms_gpu; coll += ps.ms_collective; }
-    c->stats.ms_loop_gpu = g;
-    c->stats.ms_collective = coll;
-    c->finished = true;
-    return HB_OK;
+    return guarded(c, [&]() -> int {
+        if (!c) return HB_ERR_INVALID;
+        if (!c->begun) return fail(c, HB_ERR_INVALID, "hb_finish: call hb_begin first");
+        int rc = set_device(c);
+        if (rc) return rc;
+        const Plan &p = c->plan;
+        double t0 = now_ms();
+        if (c->comm && p.n_pad) {
+            // every rank ends with all Kahan sums: in-place all-gather of the owned slices
+            HB_NCCL(ncclAllGather(c->d_ksum + (uint64_t)c->opt.rank * c->slice_rows, c->d_ksum, c->slice_rows, ncclDouble,
+                                  c->comm, c->stream));
+        }
+        // normalize_centralities (harmonic.rs:178-195) on the device, in ascending-NodeID order;
+        // norm_factor = (num_nodes - 1) as f64 (:229)
+        const double norm = (double)(p.n ? p.n - 1 : 0);
+        unsigned long long *cnt = c->d_counters + (size_t)c->max_passes * hbk::kCounterWords; // the spare slot
+        HB_HIP(hipMemsetAsync(cnt, 0, hbk::kCounterWords * sizeof(unsigned long long), c->stream));
+        if (p.n) {
+            unsigned blocks = (unsigned)std::min<uint64_t>((p.n + 255) / 256, (uint64_t)c->num_cu * 8);
+            hipLaunchKernelGGL(hbk::finish_kernel, dim3(blocks), dim3(256), 0, c->stream, (const double *)c->d_ksum,
+                               (const uint32_t *)c->d_dev_of, p.n, norm, c->d_out, cnt);
+            HB_HIP(hipGetLastError());
+            HB_HIP(hipMemcpyAsync(c->h_out, c->d_out, p.n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        }
+        HB_HIP(hipMemcpyAsync(c->h_counters, cnt, hbk::kCounterWords * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+        HB_HIP(hipStreamSynchronize(c->stream));
+        c->res_count = 0;
+        for (int s = 0; s < hbk::kStripes; s++) c->res_count += c->h_counters[4 * s];
+        c->stats.ms_d2h = now_ms() - t0;
+        c->stats.results = c->res_count;
+        c->stats.passes = c->t;
+        double g = 0, coll = 0;
+        for (auto &ps : c->pstats) { g += ps.ms_gpu; coll += ps.ms_collective; }
+        c->stats.ms_loop_gpu = g;
+        c->stats.ms_collective = coll;
+        c->finished = true;
+        return HB_OK;
+    });
 }
 
 int hb_run(hb_ctx *c, hb_stats *stats)
 {
-    if (!c) return HB_ERR_INVALID;
-    int rc = hb_begin(c);
-    if (rc) return rc;
-    double t0 = now_ms();
-    int has = 1;
-    // harmonic.rs:237-240: loop { if !has_changes { break } ... }
-    while (has) {
-        if ((rc = hb_step(c, &has))) return rc;
-    }
-    c->stats.ms_loop = now_ms() - t0;
-    if ((rc = hb_finish(c))) return rc;
-    if (stats) *stats = c->stats;
-    return HB_OK;
+    return guarded(c, [&]() -> int {
+        if (!c) return HB_ERR_INVALID;
+        int rc = hb_begin(c);
+        if (rc) return rc;
+        double t0 = now_ms();
+        int has = 1;
+        // harmonic.rs:237-240: loop { if !has_changes { break } ... }
+        while (has) {
+            if ((rc = hb_step(c, &has))) return rc;
+        }
+        c->stats.ms_loop = now_ms() - t0;
+        if ((rc = hb_finish(c))) return rc;
+        if (stats) *stats = c->stats;
+        return HB_OK;
+    });
 }
 
 int hb_get_stats(const hb_ctx *c, hb_stats *out)
@@ -924,252 +1033,302 @@ int hb_get_pass_stats(const hb_ctx *c, uint64_t t, hb_pass_stats *out)
 // ---- results ------------------------------------------------------------------------------
 int hb_result_count(hb_ctx *c, uint64_t *count)
 {
-    if (!c || !count) return HB_ERR_INVALID;
-    if (!c->finished) return fail(c, HB_ERR_INVALID, "no results: hb_run / hb_finish not called");
-    *count = c->res_count;
-    return HB_OK;
+    return guarded(c, [&]() -> int {
+        if (!c || !count) return HB_ERR_INVALID;
+        if (!c->finished) return fail(c, HB_ERR_INVALID, "no results: hb_run / hb_finish not called");
+        *count = c->res_count;
+        return HB_OK;
+    });
 }
 
 int hb_result_copy(hb_ctx *c, hb_u128 *ids, double *vals, uint64_t cap)
 {
-    if (!c) return HB_ERR_INVALID;
-    if (!c->finished) return fail(c, HB_ERR_INVALID, "no results: hb_run / hb_finish not called");
-    // compaction of the per-node array (absent = negative) into the caller's buffers
-    const uint64_t n = c->plan.n;
-    uint64_t k = 0;
-    for (uint64_t sid = 0; sid < n && k < cap; sid++) {
-        const double v = c->h_out[sid];
-        if (v < 0.0) continue;
-        if (ids) ids[k] = c->g.ids[sid];
-        if (vals) vals[k] = v;
-        k++;
-    }
-    return HB_OK;
+    return guarded(c, [&]() -> int {
+        if (!c) return HB_ERR_INVALID;
+        if (!c->finished) return fail(c, HB_ERR_INVALID, "no results: hb_run / hb_finish not called");
+        // compaction of the per-node array (absent = negative) into the caller's buffers
+        const uint64_t n = c->plan.n;
+        uint64_t k = 0;
+        for (uint64_t sid = 0; sid < n && k < cap; sid++) {
+            const double v = c->h_out[sid];
+            if (v < 0.0) continue;
+            if (ids) ids[k] = c->g.ids[sid];
+            if (vals) vals[k] = v;
+            k++;
+        }
+        return HB_OK;
+    });
 }
 
 int hb_result_ranks(hb_ctx *c, uint64_t *ranks, uint64_t cap)
 {
-    if (!c || (cap && !ranks)) return HB_ERR_INVALID;
-    if (!c->finished) return fail(c, HB_ERR_INVALID, "no results: hb_run / hb_finish not called");
-    if (cap < c->res_count) return fail(c, HB_ERR_INVALID, "hb_result_ranks: cap < hb_result_count");
-    int rc = set_device(c);
-    if (rc) return rc;
-    std::string e = gpu_rank_results((void *)c->stream, c->d_out, c->plan.n, c->res_count, ranks);
-    if (!e.empty()) return fail(c, HB_ERR_HIP, e);
-    return HB_OK;
+    return guarded(c, [&]() -> int {
+        if (!c || (cap && !ranks)) return HB_ERR_INVALID;
+        if (!c->finished) return fail(c, HB_ERR_INVALID, "no results: hb_run / hb_finish not called");
+        if (cap < c->res_count) return fail(c, HB_ERR_INVALID, "hb_result_ranks: cap < hb_result_count");
+        int rc = set_device(c);
+        if (rc) return rc;
+        std::string e = gpu_rank_results((void *)c->stream, c->d_out, c->plan.n, c->res_count, ranks);
+        if (!e.empty()) return fail(c, HB_ERR_HIP, e);
+        return HB_OK;
+    });
 }
 
 // ---- debug exports ------------------------------------------------------------------------
 int hb_debug_copy_registers(hb_ctx *c, uint8_t *out)
 {
-    if (!c || !out) return HB_ERR_INVALID;
-    if (!c->begun) return fail(c, HB_ERR_INVALID, "call hb_begin first");
-    int rc = set_device(c);
-    if (rc) return rc;
-    const uint64_t n = c->plan.n;
-    if (!n) return HB_OK;
-    uint4 *tmp = nullptr;
-    HB_HIP(hipMalloc((void **)&tmp, n * 64));
-    unsigned blocks = (unsigned)((n * 4 + 255) / 256);
-    hipLaunchKernelGGL(hbk::gather_rows_kernel, dim3(blocks), dim3(256), 0, c->stream, (const uint4 *)c->d_regs[c->cur],
-                       (const uint32_t *)c->d_dev_of, n, tmp);
-    hipError_t e = hipMemcpyAsync(out, tmp, n * 64, hipMemcpyDeviceToHost, c->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-    (void)hipFree(tmp);
-    if (e != hipSuccess) return fail(c, HB_ERR_HIP, hipGetErrorString(e));
-    return HB_OK;
+    return guarded(c, [&]() -> int {
+        if (!c || !out) return HB_ERR_INVALID;
+        if (!c->begun) return fail(c, HB_ERR_INVALID, "call hb_begin first");
+        int rc = set_device(c);
+        if (rc) return rc;
+        const uint64_t n = c->plan.n;
+        if (!n) return HB_OK;
+        uint4 *tmp = nullptr;
+        HB_HIP(hipMalloc((void **)&tmp, n * 64));
+        unsigned blocks = (unsigned)((n * 4 + 255) / 256);
+        hipLaunchKernelGGL(hbk::gather_rows_kernel, dim3(blocks), dim3(256), 0, c->stream, (const uint4 *)c->d_regs[c->cur],
+                           (const uint32_t *)c->d_dev_of, n, tmp);
+        hipError_t e = hipMemcpyAsync(out, tmp, n * 64, hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        (void)hipFree(tmp);
+        if (e != hipSuccess) return fail(c, HB_ERR_HIP, hipGetErrorString(e));
+        return HB_OK;
+    });
 }
 
 int hb_debug_copy_kahan(hb_ctx *c, double *sum, double *err)
 {
-    if (!c) return HB_ERR_INVALID;
-    if (!c->begun) return fail(c, HB_ERR_INVALID, "call hb_begin first");
-    int rc = set_device(c);
-    if (rc) return rc;
-    const Plan &p = c->plan;
-    std::vector<double> tmp(p.n_pad ? p.n_pad : 1);
-    for (int k = 0; k < 2; k++) {
-        double *dst = k ? err : sum;
-        if (!dst || !p.n_pad) continue;
-        HB_HIP(hipMemcpyAsync(tmp.data(), k ? c->d_kerr : c->d_ksum, p.n_pad * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-        HB_HIP(hipStreamSynchronize(c->stream));
-        for (uint64_t sid = 0; sid < p.n; sid++) dst[sid] = tmp[p.dev_of[sid]];
-    }
-    return HB_OK;
+    return guarded(c, [&]() -> int {
+        if (!c) return HB_ERR_INVALID;
+        if (!c->begun) return fail(c, HB_ERR_INVALID, "call hb_begin first");
+        int rc = set_device(c);
+        if (rc) return rc;
+        const Plan &p = c->plan;
+        std::vector<double> tmp(p.n_pad ? p.n_pad : 1);
+        for (int k = 0; k < 2; k++) {
+            double *dst = k ? err : sum;
+            if (!dst || !p.n_pad) continue;
+            HB_HIP(hipMemcpyAsync(tmp.data(), k ? c->d_kerr : c->d_ksum, p.n_pad * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+            HB_HIP(hipStreamSynchronize(c->stream));
+            for (uint64_t sid = 0; sid < p.n; sid++) dst[sid] = tmp[p.dev_of[sid]];
+        }
+        return HB_OK;
+    });
 }
 
 int hb_debug_copy_sizes(hb_ctx *c, uint64_t *out)
 {
-    if (!c || !out) return HB_ERR_INVALID;
-    if (!c->begun) return fail(c, HB_ERR_INVALID, "call hb_begin first");
-    int rc = set_device(c);
-    if (rc) return rc;
-    const Plan &p = c->plan;
-    if (!p.n_pad) return HB_OK;
-    std::vector<uint64_t> tmp(p.n_pad);
-    HB_HIP(hipMemcpyAsync(tmp.data(), c->d_size, p.n_pad * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
-    HB_HIP(hipStreamSynchronize(c->stream));
-    for (uint64_t sid = 0; sid < p.n; sid++) out[sid] = tmp[p.dev_of[sid]];
-    return HB_OK;
+    return guarded(c, [&]() -> int {
+        if (!c || !out) return HB_ERR_INVALID;
+        if (!c->begun) return fail(c, HB_ERR_INVALID, "call hb_begin first");
+        int rc = set_device(c);
+        if (rc) return rc;
+        const Plan &p = c->plan;
+        if (!p.n_pad) return HB_OK;
+        std::vector<uint64_t> tmp(p.n_pad);
+        HB_HIP(hipMemcpyAsync(tmp.data(), c->d_size, p.n_pad * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+        HB_HIP(hipStreamSynchronize(c->stream));
+        for (uint64_t sid = 0; sid < p.n; sid++) out[sid] = tmp[p.dev_of[sid]];
+        return HB_OK;
+    });
 }
 
 int hb_debug_hll_size(hb_ctx *c, const uint8_t *regs, uint64_t count, uint64_t *out)
 {
-    if (!c || (count && (!regs || !out))) return HB_ERR_INVALID;
-    int rc = set_device(c);
-    if (rc) return rc;
-    if (!count) return HB_OK;
-    // tables may not be on the device yet (no graph loaded): stage private copies
-    double *d_raw = nullptr, *d_bias = nullptr;
-    uint8_t *d_lc = nullptr, *d_regs = nullptr;
-    uint64_t *d_out = nullptr;
-    uint8_t lc[68];
-    if (!build_lc_table(lc)) return fail(c, HB_ERR_INVALID, "linear-counting table not robust on this libm");
-    const uint64_t rows_pad = (count + 15) & ~15ull;
-    hipError_t e = hipMalloc((void **)&d_raw, sizeof(HLL64_RAW_ESTIMATE));
-    if (e == hipSuccess) e = hipMalloc((void **)&d_bias, sizeof(HLL64_BIAS));
-    if (e == hipSuccess) e = hipMalloc((void **)&d_lc, 256);
-    if (e == hipSuccess) e = hipMalloc((void **)&d_regs, rows_pad * 64);
-    if (e == hipSuccess) e = hipMalloc((void **)&d_out, rows_pad * 8);
-    if (e == hipSuccess) e = hipMemcpyAsync(d_raw, HLL64_RAW_ESTIMATE, sizeof(HLL64_RAW_ESTIMATE), hipMemcpyHostToDevice, c->stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(d_bias, HLL64_BIAS, sizeof(HLL64_BIAS), hipMemcpyHostToDevice, c->stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(d_lc, lc, 68, hipMemcpyHostToDevice, c->stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(d_regs, regs, count * 64, hipMemcpyHostToDevice, c->stream);
-    if (e == hipSuccess) {
-        unsigned blocks = (unsigned)((rows_pad * 4 + 255) / 256);
-        hipLaunchKernelGGL(hbk::hll_size_kernel, dim3(blocks), dim3(256), 0, c->stream, (const uint4 *)d_regs, count, d_out,
-                           (const double *)d_raw, (const double *)d_bias, (const uint8_t *)d_lc);
-        e = hipGetLastError();
-    }
-    if (e == hipSuccess) e = hipMemcpyAsync(out, d_out, count * 8, hipMemcpyDeviceToHost, c->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-    (void)hipFree(d_raw); (void)hipFree(d_bias); (void)hipFree(d_lc); (void)hipFree(d_regs); (void)hipFree(d_out);
-    if (e != hipSuccess) return fail(c, HB_ERR_HIP, hipGetErrorString(e));
-    return HB_OK;
+    return guarded(c, [&]() -> int {
+        if (!c || (count && (!regs || !out))) return HB_ERR_INVALID;
+        int rc = set_device(c);
+        if (rc) return rc;
+        if (!count) return HB_OK;
+        // tables may not be on the device yet (no graph loaded): stage private copies
+        double *d_raw = nullptr, *d_bias = nullptr;
+        uint8_t *d_lc = nullptr, *d_regs = nullptr;
+        uint64_t *d_out = nullptr;
+        uint8_t lc[68];
+        if (!build_lc_table(lc)) return fail(c, HB_ERR_INVALID, "linear-counting table not robust on this libm");
+        const uint64_t rows_pad = (count + 15) & ~15ull;
+        hipError_t e = hipMalloc((void **)&d_raw, sizeof(HLL64_RAW_ESTIMATE));
+        if (e == hipSuccess) e = hipMalloc((void **)&d_bias, sizeof(HLL64_BIAS));
+        if (e == hipSuccess) e = hipMalloc((void **)&d_lc, 256);
+        if (e == hipSuccess) e = hipMalloc((void **)&d_regs, rows_pad * 64);
+        if (e == hipSuccess) e = hipMalloc((void **)&d_out, rows_pad * 8);
+        if (e == hipSuccess) e = hipMemcpyAsync(d_raw, HLL64_RAW_ESTIMATE, sizeof(HLL64_RAW_ESTIMATE), hipMemcpyHostToDevice, c->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(d_bias, HLL64_BIAS, sizeof(HLL64_BIAS), hipMemcpyHostToDevice, c->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(d_lc, lc, 68, hipMemcpyHostToDevice, c->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(d_regs, regs, count * 64, hipMemcpyHostToDevice, c->stream);
+        if (e == hipSuccess) {
+            unsigned blocks = (unsigned)((rows_pad * 4 + 255) / 256);
+            hipLaunchKernelGGL(hbk::hll_size_kernel, dim3(blocks), dim3(256), 0, c->stream, (const uint4 *)d_regs, count, d_out,
+                               (const double *)d_raw, (const double *)d_bias, (const uint8_t *)d_lc);
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess) e = hipMemcpyAsync(out, d_out, count * 8, hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        (void)hipFree(d_raw); (void)hipFree(d_bias); (void)hipFree(d_lc); (void)hipFree(d_regs); (void)hipFree(d_out);
+        if (e != hipSuccess) return fail(c, HB_ERR_HIP, hipGetErrorString(e));
+        return HB_OK;
+    });
+}
+
+int hb_debug_state_hash(hb_ctx *c, uint64_t out[2])
+{
+    return guarded(c, [&]() -> int {
+        if (!c || !out) return HB_ERR_INVALID;
+        if (!c->begun) return fail(c, HB_ERR_INVALID, "call hb_begin first");
+        int rc = set_device(c);
+        if (rc) return rc;
+        out[0] = out[1] = 0;
+        const uint64_t n = c->plan.n;
+        if (!n) return HB_OK;
+        unsigned long long *cnt = c->d_counters + (size_t)c->max_passes * hbk::kCounterWords; // the spare slot
+        HB_HIP(hipMemsetAsync(cnt, 0, hbk::kCounterWords * sizeof(unsigned long long), c->stream));
+        const unsigned blocks = (unsigned)std::min<uint64_t>((n + 255) / 256, (uint64_t)c->num_cu * 8);
+        hipLaunchKernelGGL(hbk::state_hash_kernel, dim3(blocks), dim3(256), 0, c->stream, (const uint4 *)c->d_regs[c->cur],
+                           (const double *)c->d_ksum, (const double *)c->d_kerr, (const uint32_t *)c->d_dev_of, n, cnt);
+        HB_HIP(hipGetLastError());
+        std::vector<unsigned long long> h(hbk::kCounterWords);
+        HB_HIP(hipMemcpyAsync(h.data(), cnt, hbk::kCounterWords * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+        HB_HIP(hipStreamSynchronize(c->stream));
+        for (int s = 0; s < hbk::kStripes; s++) {
+            out[0] += h[4 * s];
+            out[1] += h[4 * s + 1];
+        }
+        if (multi_rank(c)) out[1] = 0; // a rank holds the Kahan state of its own rows only
+        return HB_OK;
+    });
 }
 
 int hb_debug_copy_graph(hb_ctx *c, hb_u128 *ids, uint64_t *row_ptr, uint32_t *src)
 {
-    if (!c) return HB_ERR_INVALID;
-    if (!c->loaded) return fail(c, HB_ERR_INVALID, "no graph loaded");
-    const uint64_t n = c->g.ids.size();
-    if (ids && n) std::memcpy(ids, c->g.ids.data(), n * sizeof(hb_u128));
-    if (row_ptr) std::memcpy(row_ptr, c->g.row_ptr.data(), (n + 1) * sizeof(uint64_t));
-    if (src && !c->g.src.empty()) std::memcpy(src, c->g.src.data(), c->g.src.size() * sizeof(uint32_t));
-    return HB_OK;
+    return guarded(c, [&]() -> int {
+        if (!c) return HB_ERR_INVALID;
+        if (!c->loaded) return fail(c, HB_ERR_INVALID, "no graph loaded");
+        const uint64_t n = c->g.ids.size();
+        if (ids && n) std::memcpy(ids, c->g.ids.data(), n * sizeof(hb_u128));
+        if (row_ptr) std::memcpy(row_ptr, c->g.row_ptr.data(), (n + 1) * sizeof(uint64_t));
+        if (src && !c->g.src.empty()) std::memcpy(src, c->g.src.data(), c->g.src.size() * sizeof(uint32_t));
+        return HB_OK;
+    });
 }
 
 int hb_host_ingest(const hb_u128 *node_ids, uint64_t n, const hb_edge *edges, uint64_t m, uint64_t *n_out,
                    uint64_t *m_unique, uint64_t *m_eff, hb_u128 *ids, uint64_t *row_ptr, uint32_t *src)
 {
-    hb_ctx *c = nullptr;
-    DenseGraph g;
-    std::string e = ingest_edges(node_ids, n, edges, m, &g);
-    if (!e.empty()) return fail(c, HB_ERR_INVALID, e);
-    const uint64_t nn = g.ids.size();
-    if (n_out) *n_out = nn;
-    if (m_unique) *m_unique = g.m_unique;
-    if (m_eff) *m_eff = g.src.size();
-    if (ids && nn) std::memcpy(ids, g.ids.data(), nn * sizeof(hb_u128));
-    if (row_ptr) std::memcpy(row_ptr, g.row_ptr.data(), (nn + 1) * sizeof(uint64_t));
-    if (src && !g.src.empty()) std::memcpy(src, g.src.data(), g.src.size() * sizeof(uint32_t));
-    return HB_OK;
+    return guarded(nullptr, [&]() -> int {
+        hb_ctx *c = nullptr;
+        DenseGraph g;
+        std::string e = ingest_edges(node_ids, n, edges, m, &g);
+        if (!e.empty()) return fail(c, HB_ERR_INVALID, e);
+        const uint64_t nn = g.ids.size();
+        if (n_out) *n_out = nn;
+        if (m_unique) *m_unique = g.m_unique;
+        if (m_eff) *m_eff = g.src.size();
+        if (ids && nn) std::memcpy(ids, g.ids.data(), nn * sizeof(hb_u128));
+        if (row_ptr) std::memcpy(row_ptr, g.row_ptr.data(), (nn + 1) * sizeof(uint64_t));
+        if (src && !g.src.empty()) std::memcpy(src, g.src.data(), g.src.size() * sizeof(uint32_t));
+        return HB_OK;
+    });
 }
 
 int hb_host_plan(uint64_t n, const uint64_t *row_ptr, const uint32_t *src, uint32_t flags, uint32_t chunk,
                  const uint32_t *tune, uint64_t sizes[4], uint32_t *order, uint64_t *plan_row_ptr, uint32_t *plan_src,
                  uint64_t *level_begin)
 {
-    hb_ctx *c = nullptr;
-    if (!sizes || (n && !row_ptr)) return fail(c, HB_ERR_INVALID, "NULL argument");
-    std::vector<uint32_t> outdeg;
-    const bool reorder = !(flags & HB_FLAG_NO_REORDER);
-    static const uint64_t zero = 0;
-    if (n == 0) row_ptr = &zero;
-    if (reorder) count_out_degree(row_ptr, src, n, &outdeg);
-    Plan p;
-    PlanTune pt = plan_tune(chunk, tune);
-    if (tune && tune[7] > 1) pt.world = tune[7]; // destination-partition layout (test hook)
-    pt.xcd_map = !(flags & HB_FLAG_NO_XCD_MAP);
-    std::string e = build_plan(n, row_ptr, src, outdeg, reorder, pt, &p);
-    if (!e.empty()) return fail(c, HB_ERR_LIMIT, e);
-    sizes[0] = p.n_pad;
-    sizes[1] = p.nv;
-    sizes[2] = p.src.size();
-    sizes[3] = p.level_begin.size() ? p.level_begin.size() - 1 : 0;
-    if (order && p.n_pad) std::memcpy(order, p.order.data(), p.n_pad * sizeof(uint32_t));
-    if (plan_row_ptr) std::memcpy(plan_row_ptr, p.row_ptr.data(), p.row_ptr.size() * sizeof(uint64_t));
-    if (plan_src && !p.src.empty()) std::memcpy(plan_src, p.src.data(), p.src.size() * sizeof(uint32_t));
-    if (level_begin) std::memcpy(level_begin, p.level_begin.data(), p.level_begin.size() * sizeof(uint64_t));
-    return HB_OK;
+    return guarded(nullptr, [&]() -> int {
+        hb_ctx *c = nullptr;
+        if (!sizes || (n && !row_ptr)) return fail(c, HB_ERR_INVALID, "NULL argument");
+        std::vector<uint32_t> outdeg;
+        const bool reorder = !(flags & HB_FLAG_NO_REORDER);
+        static const uint64_t zero = 0;
+        if (n == 0) row_ptr = &zero;
+        if (reorder) count_out_degree(row_ptr, src, n, &outdeg);
+        Plan p;
+        PlanTune pt = plan_tune(chunk, tune);
+        if (tune && tune[7] > 1) pt.world = tune[7]; // destination-partition layout (test hook)
+        pt.xcd_map = !(flags & HB_FLAG_NO_XCD_MAP);
+        std::string e = build_plan(n, row_ptr, src, outdeg, reorder, pt, &p);
+        if (!e.empty()) return fail(c, HB_ERR_LIMIT, e);
+        sizes[0] = p.n_pad;
+        sizes[1] = p.nv;
+        sizes[2] = p.src.size();
+        sizes[3] = p.level_begin.size() ? p.level_begin.size() - 1 : 0;
+        if (order && p.n_pad) std::memcpy(order, p.order.data(), p.n_pad * sizeof(uint32_t));
+        if (plan_row_ptr) std::memcpy(plan_row_ptr, p.row_ptr.data(), p.row_ptr.size() * sizeof(uint64_t));
+        if (plan_src && !p.src.empty()) std::memcpy(plan_src, p.src.data(), p.src.size() * sizeof(uint32_t));
+        if (level_begin) std::memcpy(level_begin, p.level_begin.data(), p.level_begin.size() * sizeof(uint64_t));
+        return HB_OK;
+    });
 }
 
 int hb_debug_exchange(hb_ctx **ctxs, int count, int phase)
 {
-    if (!ctxs || count < 1 || !ctxs[0]) return HB_ERR_INVALID;
-    hb_ctx *c = ctxs[0];
-    for (int i = 0; i < count; i++) {
-        hb_ctx *o = ctxs[i];
-        if (!o) return fail(c, HB_ERR_INVALID, "NULL context");
-        if (o->plan.n_pad != c->plan.n_pad || o->device != c->device || dest_mode(o) != dest_mode(c))
-            return fail(c, HB_ERR_INVALID, "contexts differ in size, device or partition mode");
-        if (phase == 0 && !o->pending_local)
-            return fail(c, HB_ERR_INVALID, "every context must be between hb_step_local and hb_step_finish");
-        if (dest_mode(c) && (o->opt.rank != i || o->opt.world_size != count))
-            return fail(c, HB_ERR_INVALID, "destination partition: ctxs[i] must be rank i of `count`");
-    }
-    int rc = set_device(c);
-    if (rc) return rc;
-    for (int i = 0; i < count; i++) HB_HIP(hipStreamSynchronize(ctxs[i]->stream));
-    const Plan &p = c->plan;
-    const uint64_t S = c->slice_rows;
-    if (phase == 1) {
-        // what hb_finish's ncclAllGather of the Kahan-sum slices does (edge partition without a
-        // communicator: every logical rank already holds all sums)
-        if (!dest_mode(c)) return HB_OK;
-        for (int i = 0; i < count; i++)
-            for (int j = 0; j < count; j++)
-                if (i != j && S)
-                    HB_HIP(hipMemcpyAsync(ctxs[i]->d_ksum + (uint64_t)j * S, ctxs[j]->d_ksum + (uint64_t)j * S, S * sizeof(double),
+    return guarded(nullptr, [&]() -> int {
+        if (!ctxs || count < 1 || !ctxs[0]) return HB_ERR_INVALID;
+        hb_ctx *c = ctxs[0];
+        for (int i = 0; i < count; i++) {
+            hb_ctx *o = ctxs[i];
+            if (!o) return fail(c, HB_ERR_INVALID, "NULL context");
+            if (o->plan.n_pad != c->plan.n_pad || o->device != c->device || dest_mode(o) != dest_mode(c))
+                return fail(c, HB_ERR_INVALID, "contexts differ in size, device or partition mode");
+            if (phase == 0 && !o->pending_local)
+                return fail(c, HB_ERR_INVALID, "every context must be between hb_step_local and hb_step_finish");
+            if (dest_mode(c) && (o->opt.rank != i || o->opt.world_size != count))
+                return fail(c, HB_ERR_INVALID, "destination partition: ctxs[i] must be rank i of `count`");
+        }
+        int rc = set_device(c);
+        if (rc) return rc;
+        for (int i = 0; i < count; i++) HB_HIP(hipStreamSynchronize(ctxs[i]->stream));
+        const Plan &p = c->plan;
+        const uint64_t S = c->slice_rows;
+        if (phase == 1) {
+            // what hb_finish's ncclAllGather of the Kahan-sum slices does (edge partition without a
+            // communicator: every logical rank already holds all sums)
+            if (!dest_mode(c)) return HB_OK;
+            for (int i = 0; i < count; i++)
+                for (int j = 0; j < count; j++)
+                    if (i != j && S)
+                        HB_HIP(hipMemcpyAsync(ctxs[i]->d_ksum + (uint64_t)j * S, ctxs[j]->d_ksum + (uint64_t)j * S, S * sizeof(double),
+                                              hipMemcpyDeviceToDevice, c->stream));
+            HB_HIP(hipStreamSynchronize(c->stream));
+            return HB_OK;
+        }
+        if (!dest_mode(c)) {
+            // all-reduce(max) of the pending counters: fold everything into ctxs[0], then copy out
+            const uint64_t count4 = p.n_pad * 4;
+            for (int i = 1; i < count && count4; i++) {
+                hipLaunchKernelGGL(hbk::merge_max_kernel, dim3(2048), dim3(256), 0, c->stream, c->d_regs[c->cur ^ 1],
+                                   (const uint4 *)ctxs[i]->d_regs[ctxs[i]->cur ^ 1], count4);
+                HB_HIP(hipGetLastError());
+            }
+            for (int i = 1; i < count && count4; i++)
+                HB_HIP(hipMemcpyAsync(ctxs[i]->d_regs[ctxs[i]->cur ^ 1], c->d_regs[c->cur ^ 1], count4 * 16, hipMemcpyDeviceToDevice, c->stream));
+        } else {
+            // all-gather of the owned slices (counters, changed bits) + sum of the changed counts
+            const size_t W = hbk::kCounterWords;
+            std::vector<unsigned long long> total(W, 0), cnt((size_t)count * W, 0);
+            for (int i = 0; i < count; i++) {
+                HB_HIP(hipMemcpyAsync(&cnt[(size_t)i * W], ctxs[i]->d_counters + W * ctxs[i]->t, W * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+            }
+            HB_HIP(hipStreamSynchronize(c->stream));
+            for (int i = 0; i < count; i++)
+                for (size_t k = 0; k < W; k++) total[k] += cnt[(size_t)i * W + k];
+            for (int i = 0; i < count; i++) {
+                hb_ctx *d = ctxs[i];
+                for (int j = 0; j < count; j++) {
+                    if (i == j || !S) continue;
+                    hb_ctx *o = ctxs[j];
+                    HB_HIP(hipMemcpyAsync(d->d_regs[d->cur ^ 1] + (uint64_t)j * S * 4, o->d_regs[o->cur ^ 1] + (uint64_t)j * S * 4, S * 64,
                                           hipMemcpyDeviceToDevice, c->stream));
+                    HB_HIP(hipMemcpyAsync(d->d_bits[d->cur ^ 1] + (uint64_t)j * (S / 32), o->d_bits[o->cur ^ 1] + (uint64_t)j * (S / 32), S / 8,
+                                          hipMemcpyDeviceToDevice, c->stream));
+                }
+                HB_HIP(hipMemcpyAsync(d->d_counters + W * d->t, total.data(), W * sizeof(unsigned long long), hipMemcpyHostToDevice, c->stream));
+            }
+        }
         HB_HIP(hipStreamSynchronize(c->stream));
         return HB_OK;
-    }
-    if (!dest_mode(c)) {
-        // all-reduce(max) of the pending counters: fold everything into ctxs[0], then copy out
-        const uint64_t count4 = p.n_pad * 4;
-        for (int i = 1; i < count && count4; i++) {
-            hipLaunchKernelGGL(hbk::merge_max_kernel, dim3(2048), dim3(256), 0, c->stream, c->d_regs[c->cur ^ 1],
-                               (const uint4 *)ctxs[i]->d_regs[ctxs[i]->cur ^ 1], count4);
-            HB_HIP(hipGetLastError());
-        }
-        for (int i = 1; i < count && count4; i++)
-            HB_HIP(hipMemcpyAsync(ctxs[i]->d_regs[ctxs[i]->cur ^ 1], c->d_regs[c->cur ^ 1], count4 * 16, hipMemcpyDeviceToDevice, c->stream));
-    } else {
-        // all-gather of the owned slices (counters, changed bits) + sum of the changed counts
-        const size_t W = hbk::kCounterWords;
-        std::vector<unsigned long long> total(W, 0), cnt((size_t)count * W, 0);
-        for (int i = 0; i < count; i++) {
-            HB_HIP(hipMemcpyAsync(&cnt[(size_t)i * W], ctxs[i]->d_counters + W * ctxs[i]->t, W * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
-        }
-        HB_HIP(hipStreamSynchronize(c->stream));
-        for (int i = 0; i < count; i++)
-            for (size_t k = 0; k < W; k++) total[k] += cnt[(size_t)i * W + k];
-        for (int i = 0; i < count; i++) {
-            hb_ctx *d = ctxs[i];
-            for (int j = 0; j < count; j++) {
-                if (i == j || !S) continue;
-                hb_ctx *o = ctxs[j];
-                HB_HIP(hipMemcpyAsync(d->d_regs[d->cur ^ 1] + (uint64_t)j * S * 4, o->d_regs[o->cur ^ 1] + (uint64_t)j * S * 4, S * 64,
-                                      hipMemcpyDeviceToDevice, c->stream));
-                HB_HIP(hipMemcpyAsync(d->d_bits[d->cur ^ 1] + (uint64_t)j * (S / 32), o->d_bits[o->cur ^ 1] + (uint64_t)j * (S / 32), S / 8,
-                                      hipMemcpyDeviceToDevice, c->stream));
-            }
-            HB_HIP(hipMemcpyAsync(d->d_counters + W * d->t, total.data(), W * sizeof(unsigned long long), hipMemcpyHostToDevice, c->stream));
-        }
-    }
-    HB_HIP(hipStreamSynchronize(c->stream));
-    return HB_OK;
+    });
 }
 
 } // extern "C"

@@ -509,6 +509,8 @@ std::string build_plan(uint64_t n, const uint64_t *row_ptr, const uint32_t *src,
             // padding), so that appending them never reallocates - and copies - the level-1 lists
             vsrc.reserve(off + row_chunk.size() + row_chunk.size() / 8 + 64ull * kRowAlign);
             vsrc.resize(off);
+            p->level1_edges = off;
+            p->level1_rows = chunks.size();
 #pragma omp parallel for schedule(static, 4096)
             for (int64_t r = 0; r < (int64_t)row_chunk.size(); r++) {
                 if (row_chunk[r] < 0) continue;
@@ -576,11 +578,15 @@ std::string build_plan(uint64_t n, const uint64_t *row_ptr, const uint32_t *src,
         // ---- assemble: real rows [0, n_pad), then virtual rows
         const uint64_t rows_total = p->n_pad + p->nv;
         p->row_ptr.resize(rows_total + 1);
-        uint64_t total = 0;
+        uint64_t total = 0, direct = 0, with_in = 0;
         for (uint64_t d = 0; d < n_pad; d++) {
             p->row_ptr[d] = total;
             total += is_split[d] ? (lptr[hub_index[d] + 1] - lptr[hub_index[d]]) : (rp[d + 1] - rp[d]);
+            if (!is_split[d]) direct += rp[d + 1] - rp[d];
+            with_in += rp[d + 1] > rp[d];
         }
+        p->direct_edges = direct;
+        p->rows_with_in_edges = with_in;
         p->row_ptr[n_pad] = total;
         const uint64_t real_total = total;
         for (uint64_t k = 0; k < p->nv; k++) p->row_ptr[p->n_pad + k + 1] = real_total + vrow_ptr[k + 1];

@@ -198,7 +198,15 @@ std::string gpu_ingest_edges(void *stream_v, const hb_u128 *node_ids, uint64_t n
         hb_edge *d_slab[2] = {nullptr, nullptr};
         IG_HIP(mem.alloc(&d_slab[0], std::min<uint64_t>(slab, std::max<uint64_t>(m, 1))));
         IG_HIP(mem.alloc(&d_slab[1], std::min<uint64_t>(slab, std::max<uint64_t>(m, 1))));
-        hipEvent_t done[2];
+        struct Events { // destroyed on every exit path
+            hipEvent_t e[2] = {nullptr, nullptr};
+            ~Events()
+            {
+                for (hipEvent_t x : e)
+                    if (x) (void)hipEventDestroy(x);
+            }
+        } evs;
+        hipEvent_t *done = evs.e;
         IG_HIP(hipEventCreateWithFlags(&done[0], hipEventDisableTiming));
         IG_HIP(hipEventCreateWithFlags(&done[1], hipEventDisableTiming));
         int b = 0;
@@ -211,8 +219,6 @@ std::string gpu_ingest_edges(void *stream_v, const hb_u128 *node_ids, uint64_t n
             IG_HIP(hipEventRecord(done[b], stream));
         }
         IG_HIP(hipStreamSynchronize(stream));
-        (void)hipEventDestroy(done[0]);
-        (void)hipEventDestroy(done[1]);
         mem.release(d_slab[0]);
         mem.release(d_slab[1]);
     }

@@ -69,6 +69,11 @@ struct Plan {
     std::vector<uint64_t> level_begin; // virtual level l = rows [level_begin[l], level_begin[l+1])
     uint64_t xcd_begin[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}; // level-1 rows of XCD group x = [xcd_begin[x], xcd_begin[x+1])
     int xcd_groups = 1;
+    // layout statistics (hb_stats)
+    uint64_t level1_edges = 0;       // real edges gathered by level-1 chunk rows
+    uint64_t level1_rows = 0;        // level-1 chunk rows (without padding rows)
+    uint64_t direct_edges = 0;       // real edges gathered directly by node rows
+    uint64_t rows_with_in_edges = 0; // nodes with in-degree > 0
 };
 
 // Planner knobs (hb_options.chunk / tune[3..5]).

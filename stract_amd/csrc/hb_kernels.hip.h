@@ -438,6 +438,7 @@ __global__ __launch_bounds__(256) void pass_kernel(const PassParams p)
         bool need = valid;
         if (FRONTIER) {
             const bool touched = ((__ballot(lane_act) >> qshift) & 0xFull) != 0;
+            if (REAL) cnt_rows += (valid && touched && q == 0); // V_t (hb_pass_stats.touched)
             need = valid && (touched || (REAL && (self_prev || kd)));
             if (need) {
                 selfv = *selfp;
@@ -465,7 +466,6 @@ __global__ __launch_bounds__(256) void pass_kernel(const PassParams p)
             cnt_changed += __popc(ch16);
             if (changed && q == 0) cnt_out += od;
         }
-        if (STATS) cnt_rows += (need && q == 0);
         if (REAL && FUSED) {
             bool err_nz = false;
             if (need && (changed || kd)) {
@@ -490,14 +490,12 @@ __global__ __launch_bounds__(256) void pass_kernel(const PassParams p)
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) {
             cnt_out += __shfl_down(cnt_out, off);
-            if (STATS) {
-                cnt_active += __shfl_down(cnt_active, off);
-                cnt_rows += __shfl_down(cnt_rows, off);
-            }
+            if (STATS) cnt_active += __shfl_down(cnt_active, off);
+            if (REAL && FRONTIER) cnt_rows += __shfl_down(cnt_rows, off);
         }
         // cnt_changed is identical in all lanes of the wave (derived from a ballot)
         const unsigned long long v[4] = {cnt_changed, cnt_active, cnt_rows, cnt_out};
-        block_add_counters(p.counters, v, (REAL ? 0x9u : 0u) | (STATS ? 0x6u : 0u));
+        block_add_counters(p.counters, v, (REAL ? 0x9u : 0u) | (STATS ? 0x2u : 0u) | ((REAL && FRONTIER) ? 0x4u : 0u));
     }
 }
 
@@ -519,6 +517,9 @@ struct SparseParams {
     PassParams p;
     const uint64_t *out_ptr;   // rows_total + 1
     const uint32_t *out_rows;  // work rows reading each source
+    const uint8_t *out_pos;    // ... and the position of the source inside that row's list (< 64)
+    unsigned long long *mask;  // push mode: per work row, bit k = the k-th source of the row is active in this pass;
+                               // all-zero between passes (the row kernels clear what they consume)
     uint32_t *touch;           // 1 bit per work row: already on a worklist
     uint32_t *list_real;       // worklist of node rows (capacity n_pad)
     uint32_t *list_virt;       // worklists of virtual rows, level l at offset level_begin[l] - n_pad
@@ -571,6 +572,8 @@ __device__ __forceinline__ void sparse_push(const SparseParams &sp, bool has, ui
 
 // one thread per 32 node rows: changed-in-the-previous-pass nodes become seeds (their readers are
 // expanded by sparse_expand_kernel) and, like Kahan-dirty nodes, are visited themselves.
+// LISTS = false (push mode): only the seed list is built
+template <bool LISTS>
 __global__ __launch_bounds__(256) void sparse_collect_kernel(const SparseParams sp)
 {
     const uint64_t words = sp.p.n_pad >> 5;
@@ -581,8 +584,8 @@ __global__ __launch_bounds__(256) void sparse_collect_kernel(const SparseParams 
         uint32_t ch = 0, both = 0;
         if (w < words) {
             ch = sp.p.bits_rd[w];
-            both = ch | sp.p.kdirty[w];
-            if (both) sp.touch[w] = both; // first writer of these words (the buffer was just cleared)
+            both = LISTS ? (ch | sp.p.kdirty[w]) : ch;
+            if (LISTS && both) sp.touch[w] = both; // first writer of these words (the buffer was just cleared)
         }
         // wave-aggregated reservation in the seed list and in the node-row worklist
         uint32_t nch = __popc(ch), nb = __popc(both);
@@ -599,7 +602,7 @@ __global__ __launch_bounds__(256) void sparse_collect_kernel(const SparseParams 
         uint32_t base_ch = 0, base_b = 0;
         if (lane == 0) {
             if (tot_ch) base_ch = atomicAdd(&sp.counts[0], tot_ch);
-            if (tot_b) base_b = atomicAdd(&sp.counts[1], tot_b);
+            if (LISTS && tot_b) base_b = atomicAdd(&sp.counts[1], tot_b);
         }
         base_ch = __shfl(base_ch, 0) + pch - nch;
         base_b = __shfl(base_b, 0) + pb - nb;
@@ -608,14 +611,27 @@ __global__ __launch_bounds__(256) void sparse_collect_kernel(const SparseParams 
             both &= both - 1;
             const uint32_t row = (uint32_t)(w << 5) + (uint32_t)b;
             if ((ch >> b) & 1u) sp.seeds[base_ch++] = row;
-            sp.list_real[base_b++] = row;
+            if (LISTS) sp.list_real[base_b++] = row;
         }
+    }
+}
+
+// what an expansion step does with reader entry k of a seed: worklist append (sparse mode) or, in push
+// mode, one fire-and-forget atomic OR of the source's position bit into the reader row's mask
+template <bool MASK>
+__device__ __forceinline__ void expand_emit(const SparseParams &sp, bool has, uint64_t k)
+{
+    if (MASK) {
+        if (has) atomicOr(&sp.mask[sp.out_rows[k]], 1ull << sp.out_pos[k]);
+    } else {
+        sparse_push(sp, has, has ? sp.out_rows[k] : 0u);
     }
 }
 
 // Seeds -> worklists in three tiers by reader count: <= kLightReaders inline, one LANE per seed
 // (most late changers are read by one or two rows); up to kHeavyReaders one WAVE per seed
 // (sparse_expand_medium_kernel); beyond that the whole grid (hubs stay in the changed set longest).
+template <bool MASK>
 __global__ __launch_bounds__(256) void sparse_expand_kernel(const SparseParams sp)
 {
     const int lane = threadIdx.x & 63;
@@ -643,13 +659,13 @@ __global__ __launch_bounds__(256) void sparse_expand_kernel(const SparseParams s
             }
         }
         while (__ballot(b < e)) {
-            const bool has = b < e;
-            sparse_push(sp, has, has ? sp.out_rows[b] : 0u);
+            expand_emit<MASK>(sp, b < e, b);
             b++;
         }
     }
 }
 
+template <bool MASK>
 __global__ __launch_bounds__(256) void sparse_expand_medium_kernel(const SparseParams sp)
 {
     const int lane = threadIdx.x & 63;
@@ -664,12 +680,12 @@ __global__ __launch_bounds__(256) void sparse_expand_medium_kernel(const SparseP
         }
         for (uint64_t k0 = b; k0 < e; k0 += 64) {
             const uint64_t k = k0 + lane;
-            const bool has = k < e;
-            sparse_push(sp, has, has ? sp.out_rows[k] : 0u);
+            expand_emit<MASK>(sp, k < e, k);
         }
     }
 }
 
+template <bool MASK>
 __global__ __launch_bounds__(256) void sparse_expand_heavy_kernel(const SparseParams sp)
 {
     const uint32_t nheavy = sp.counts[kHeavySlot];
@@ -680,8 +696,7 @@ __global__ __launch_bounds__(256) void sparse_expand_heavy_kernel(const SparsePa
         const uint64_t b = sp.out_ptr[u], e = sp.out_ptr[u + 1];
         for (uint64_t k0 = b + wbase; k0 < e; k0 += nthreads) { // wave-uniform trip count
             const uint64_t k = k0 + lane;
-            const bool has = k < e;
-            sparse_push(sp, has, has ? sp.out_rows[k] : 0u);
+            expand_emit<MASK>(sp, k < e, k);
         }
     }
 }
@@ -708,7 +723,7 @@ __global__ __launch_bounds__(256) void sparse_rows_kernel(const SparseParams sp)
     const uint32_t count = REAL ? sp.counts[1] : sp.counts[2 + sp.level];
     const uint32_t *list = REAL ? sp.list_real : sp.list_virt + (sp.level_begin[sp.level] - p.n_pad);
     const uint32_t nwaves = gridDim.x * 4;
-    unsigned long long cnt_changed = 0, cnt_out = 0;
+    unsigned long long cnt_changed = 0, cnt_out = 0, cnt_rows = 0;
     for (uint32_t base = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 16; base < count; base += nwaves * 16) {
         const uint32_t li = base + (uint32_t)g;
         const bool valid = li < count;
@@ -721,6 +736,7 @@ __global__ __launch_bounds__(256) void sparse_rows_kernel(const SparseParams sp)
         const uint4 *selfp = REAL ? (p.rd + row * 4 + q) : (p.part + (row - p.n_pad) * 4 + q);
         Acc acc;
         acc_zero(acc);
+        bool lane_act = false;
         if (beg < end) {
             const uint32_t first = p.src[beg];
             const uint4 *srcbase = (first >= p.n_pad) ? (const uint4 *)(p.part - p.n_pad * 4) : p.rd;
@@ -728,6 +744,7 @@ __global__ __launch_bounds__(256) void sparse_rows_kernel(const SparseParams sp)
                 const uint64_t ee = e + q;
                 uint32_t idx = (ee < end) ? p.src[ee] : kNone;
                 if (idx != kNone && !((p.bits_rd[idx >> 5] >> (idx & 31u)) & 1u)) idx = kNone;
+                lane_act |= (idx != kNone);
                 const uint32_t s0 = quad_bcast<0>(idx), s1 = quad_bcast<1>(idx);
                 const uint32_t s2 = quad_bcast<2>(idx), s3 = quad_bcast<3>(idx);
                 uint4 r0 = make_uint4(0, 0, 0, 0), r1 = r0, r2 = r0, r3 = r0;
@@ -751,6 +768,8 @@ __global__ __launch_bounds__(256) void sparse_rows_kernel(const SparseParams sp)
         const bool changed = ((bal >> qshift) & 0xFull) != 0;
         const uint32_t bit = 1u << (row & 31u);
         if (REAL) {
+            const bool touched = ((__ballot(lane_act) >> qshift) & 0xFull) != 0;
+            cnt_rows += (valid && touched && q == 0);
             const bool self_prev = valid && ((p.bits_rd[row >> 5] >> (row & 31u)) & 1u);
             const bool kd = valid && ((p.kdirty[row >> 5] >> (row & 31u)) & 1u);
             if (valid && (changed || self_prev)) p.wr[row * 4 + q] = accv; // lazy double buffer
@@ -795,9 +814,139 @@ __global__ __launch_bounds__(256) void sparse_rows_kernel(const SparseParams sp)
     }
     if (REAL) {
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) cnt_out += __shfl_down(cnt_out, off);
-        const unsigned long long v[4] = {cnt_changed, 0, 0, cnt_out};
-        block_add_counters(p.counters, v, 0x9u);
+        for (int off = 32; off > 0; off >>= 1) {
+            cnt_out += __shfl_down(cnt_out, off);
+            cnt_rows += __shfl_down(cnt_rows, off);
+        }
+        const unsigned long long v[4] = {cnt_changed, 0, cnt_rows, cnt_out};
+        block_add_counters(p.counters, v, 0xDu);
+    }
+}
+
+// ---- push mode: the mid-tail passes ---------------------------------------------------------
+// Between "most sources changed" (dense pull) and "almost none did" (worklists) the bitmap frontier
+// pass read and bit-tested EVERY index to gather a few per cent of them.  Here the changed nodes push
+// instead: the transposed graph gives, for every changed node, the rows that read it and its position in
+// their lists; one atomic OR per (changed source, reader) pair sets that bit in the row's 64-bit mask
+// (rows have <= 64 sources).  The row sweep then reads 8 bytes per row, skips rows with an empty mask
+// and otherwise loads exactly the indices whose bits are set - no index streaming, no bit tests.  A
+// virtual row that changed ORs its bit into its parent's mask, so changes climb the chunk trees inside
+// the pass (levels are swept in order).  Row semantics (lazy double buffer, Kahan fixed points,
+// changed bits) are those of the frontier pass, so registers / Kahan state stay bit-identical.
+template <bool REAL>
+__global__ __launch_bounds__(256) void push_rows_kernel(const SparseParams sp)
+{
+    __shared__ double s_raw[REAL ? kTableLen : 1];
+    __shared__ double s_bias[REAL ? kTableLen : 1];
+    __shared__ uint8_t s_lc[68];
+    const PassParams &p = sp.p;
+    if (REAL) {
+        for (int i = threadIdx.x; i < kTableLen; i += 256) {
+            s_raw[i] = p.raw[i];
+            s_bias[i] = p.bias[i];
+        }
+        if (threadIdx.x < 65) s_lc[threadIdx.x] = p.lc[threadIdx.x];
+        __syncthreads();
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int g = lane >> 2, q = lane & 3, qshift = lane & ~3;
+    const uint64_t ntiles = (p.row_hi - p.row_lo + 63) >> 6;
+    unsigned long long cnt_changed = 0, cnt_active = 0, cnt_rows = 0, cnt_out = 0;
+    for (uint64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const uint64_t row16 = p.row_lo + (tile << 6) + ((uint64_t)wave << 4);
+        const uint64_t row = row16 + (uint64_t)g;
+        const bool valid = row < p.row_hi;
+        unsigned long long mk = valid ? sp.mask[row] : 0ull;
+        const uint32_t prev16 = REAL ? (uint32_t)((const uint16_t *)p.bits_rd)[row16 >> 4] : 0u;
+        const uint32_t kd16 = REAL ? (uint32_t)((const uint16_t *)p.kdirty)[row16 >> 4] : 0u;
+        const bool self_prev = (prev16 >> g) & 1u;
+        const bool kd = (kd16 >> g) & 1u;
+        const bool need = valid && (mk != 0 || (REAL && (self_prev || kd)));
+        const bool touched = mk != 0;
+        Acc acc;
+        acc_zero(acc);
+        uint4 selfv = make_uint4(0, 0, 0, 0);
+        const uint4 *selfp = REAL ? (p.rd + row * 4 + q) : (p.part + (row - p.n_pad) * 4 + q);
+        if (need) {
+            selfv = *selfp;
+            acc_merge(acc, selfv);
+        }
+        if (mk) {
+            if (q == 0) sp.mask[row] = 0; // consumed
+            const uint64_t beg = p.row_ptr[row];
+            const uint32_t first = p.src[beg];
+            const uint4 *base = (first >= p.n_pad) ? (const uint4 *)(p.part - p.n_pad * 4) : p.rd;
+            if (first < p.n_pad && q == 0) cnt_active += __popcll(mk);
+            while (mk) { // quad-uniform: up to four active positions per round, one index load per lane
+                int pos = -1;
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const int b = mk ? __ffsll((long long)mk) - 1 : -1;
+                    mk &= mk - 1; // 0 stays 0
+                    if (j == q) pos = b;
+                }
+                const uint32_t idx = (pos >= 0) ? p.src[beg + (uint64_t)pos] : kNone;
+                const uint32_t s0 = quad_bcast<0>(idx), s1 = quad_bcast<1>(idx);
+                const uint32_t s2 = quad_bcast<2>(idx), s3 = quad_bcast<3>(idx);
+                uint4 r0 = make_uint4(0, 0, 0, 0), r1 = r0, r2 = r0, r3 = r0;
+                if (s0 != kNone) r0 = base[(uint64_t)s0 * 4 + q];
+                if (s1 != kNone) r1 = base[(uint64_t)s1 * 4 + q];
+                if (s2 != kNone) r2 = base[(uint64_t)s2 * 4 + q];
+                if (s3 != kNone) r3 = base[(uint64_t)s3 * 4 + q];
+                acc_merge(acc, r0);
+                acc_merge(acc, r1);
+                acc_merge(acc, r2);
+                acc_merge(acc, r3);
+            }
+        }
+        const uint4 accv = acc_value(acc);
+        const uint64_t bal = __ballot(need && u4_ne(accv, selfv));
+        const bool changed = ((bal >> qshift) & 0xFull) != 0;
+        const uint32_t ch16 = pack16(bal);
+        if (REAL) {
+            cnt_rows += (touched && q == 0);
+            if (need && (changed || self_prev)) p.wr[row * 4 + q] = accv; // lazy double buffer
+            if (lane == 0 && row16 < p.row_hi) ((uint16_t *)p.bits_wr)[row16 >> 4] = (uint16_t)ch16;
+            cnt_changed += __popc(ch16);
+            if (changed && q == 0) cnt_out += p.outdeg[row];
+            bool err_nz = false;
+            if (need && (changed || kd)) {
+                const uint64_t sz_old = p.size[row];
+                const uint64_t sz_new = changed ? hll_size_quad(accv, s_raw, s_bias, s_lc) : sz_old;
+                if (q == 0) {
+                    double ks = p.ksum[row], ke = p.kerr[row];
+                    err_nz = kahan_update(ks, ke, sz_new, sz_old, p.t_plus_1);
+                    if (err_nz) {
+                        p.ksum[row] = ks;
+                        p.kerr[row] = ke;
+                    }
+                    if (changed) p.size[row] = sz_new;
+                }
+            }
+            const uint32_t nk16 = pack16(__ballot(err_nz));
+            if (lane == 0 && row16 < p.row_hi && (nk16 | kd16)) ((uint16_t *)p.kdirty)[row16 >> 4] = (uint16_t)nk16;
+        } else if (changed) {
+            p.part[(row - p.n_pad) * 4 + q] = accv;
+            if (q == 0) { // the reader(s) of this partial (one parent) see it as an active source
+                for (uint64_t k = sp.out_ptr[row]; k < sp.out_ptr[row + 1]; k++)
+                    atomicOr(&sp.mask[sp.out_rows[k]], 1ull << sp.out_pos[k]);
+            }
+        }
+    }
+    if (REAL) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            cnt_out += __shfl_down(cnt_out, off);
+            cnt_active += __shfl_down(cnt_active, off);
+            cnt_rows += __shfl_down(cnt_rows, off);
+        }
+        const unsigned long long v[4] = {cnt_changed, cnt_active, cnt_rows, cnt_out};
+        block_add_counters(p.counters, v, 0xFu);
+    } else {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) cnt_active += __shfl_down(cnt_active, off);
+        const unsigned long long v[4] = {0, cnt_active, 0, 0};
+        block_add_counters(p.counters, v, 0x2u);
     }
 }
 
@@ -821,7 +970,8 @@ __global__ __launch_bounds__(256) void transpose_count_kernel(const uint64_t *ro
     }
 }
 __global__ __launch_bounds__(256) void transpose_fill_kernel(const uint64_t *row_ptr, const uint32_t *src, uint64_t rows,
-                                                             const uint64_t *out_ptr, uint32_t *cursor, uint32_t *out_rows)
+                                                             const uint64_t *out_ptr, uint32_t *cursor, uint32_t *out_rows,
+                                                             uint8_t *out_pos)
 {
     const uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     const uint64_t nq = (uint64_t)gridDim.x * 64;
@@ -830,7 +980,9 @@ __global__ __launch_bounds__(256) void transpose_fill_kernel(const uint64_t *row
         const uint64_t b = row_ptr[row], e = row_ptr[row + 1];
         for (uint64_t k = b + q; k < e; k += 4) {
             const uint32_t s = src[k];
-            out_rows[out_ptr[s] + atomicAdd(&cursor[s], 1u)] = (uint32_t)row;
+            const uint64_t o = out_ptr[s] + atomicAdd(&cursor[s], 1u);
+            out_rows[o] = (uint32_t)row;
+            if (out_pos) out_pos[o] = (uint8_t)(k - b); // rows longer than 256 entries: push mode is off (hb_api.hip)
         }
     }
 }
@@ -993,6 +1145,44 @@ __global__ __launch_bounds__(256) void finish_kernel(const double *ksum, const u
     for (int off = 32; off > 0; off >>= 1) kept += __shfl_down(kept, off);
     const unsigned long long v[4] = {kept, 0, 0, 0};
     block_add_counters(count, v, 0x1u); // striped: the host sums word 0 of every stripe
+}
+
+// Order-independent checksums of the state (hb_debug_state_hash; same function as
+// oracle/hb_oracle.c hbo_dense_state_hash): node sid contributes mixes of (sid, its 8 register
+// words) and of (sid, sum bits, err bits); contributions are added mod 2^64.
+__device__ __forceinline__ uint64_t hash_mix64(uint64_t x)
+{
+    x ^= x >> 33;
+    x *= 0xff51afd7ed558ccdull;
+    x ^= x >> 33;
+    x *= 0xc4ceb9fe1a85ec53ull;
+    x ^= x >> 33;
+    return x;
+}
+__global__ __launch_bounds__(256) void state_hash_kernel(const uint4 *regs, const double *ksum, const double *kerr,
+                                                         const uint32_t *dev_of, uint64_t n, unsigned long long *out)
+{
+    unsigned long long hr = 0, hk = 0;
+    for (uint64_t sid = (uint64_t)blockIdx.x * 256 + threadIdx.x; sid < n; sid += (uint64_t)gridDim.x * 256) {
+        const uint64_t row = dev_of[sid];
+        uint64_t r = sid * 0x9E3779B97F4A7C15ull + 1ull;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const uint4 v = regs[row * 4 + k];
+            r = hash_mix64(r ^ (((uint64_t)v.y << 32) | v.x));
+            r = hash_mix64(r ^ (((uint64_t)v.w << 32) | v.z));
+        }
+        hr += r;
+        const uint64_t a = (uint64_t)__double_as_longlong(ksum[row]), b = (uint64_t)__double_as_longlong(kerr[row]);
+        hk += hash_mix64(hash_mix64((sid + 0x632BE59BD9B4E019ull) ^ a) ^ b);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        hr += __shfl_down(hr, off);
+        hk += __shfl_down(hk, off);
+    }
+    const unsigned long long v[4] = {hr, hk, 0, 0};
+    block_add_counters(out, v, 0x3u);
 }
 
 // scatter/gather between device order and ascending-NodeID order (debug exports)

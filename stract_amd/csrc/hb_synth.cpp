@@ -93,7 +93,32 @@ void hbs_free(hbs_graph *g) { delete g; }
 // Draw raw R-MAT edges until at least m_target unique non-self edges exist, then keep
 // exactly the m_target smallest (in (to,from) vertex-key order is NOT stream order, so
 // instead we keep all uniques of the drawn prefix; the measured m is reported).
+// Long-tail variant (bench input for the convergence tail): the R-MAT core plus a levelled DAG hanging off it.
+// tail_permille * n_core / 1000 extra hosts are laid out in levels of geometrically shrinking size
+// (level d has ratio_permille/1000 of the hosts of level d-1); every host of level d gets `fanin` in-links from
+// random hosts of level d-1 (level 0 = random core hosts).  Information only flows core -> tail, so the core
+// converges as before and the tail keeps changing for one more pass per level: T grows by the tail depth
+// (tens of passes, like real host graphs) while the changed set shrinks geometrically - first bitmap/frontier
+// passes (A_t a few % of the edges), then many worklist passes.  tail_permille = 0: plain R-MAT.
+static hbs_graph *build_graph(int scale, uint64_t m_target, uint64_t seed, int threads, uint32_t tail_permille,
+                              uint32_t ratio_permille, uint32_t fanin);
+
 hbs_graph *hbs_rmat(int scale, uint64_t m_target, uint64_t seed, int threads)
+{
+    return build_graph(scale, m_target, seed, threads, 0, 0, 0);
+}
+
+hbs_graph *hbs_rmat_tail(int scale, uint64_t m_target, uint64_t seed, int threads, uint32_t tail_permille,
+                         uint32_t ratio_permille, uint32_t fanin)
+{
+    if (scale > 30 || ratio_permille >= 1000 || (tail_permille && !fanin)) return nullptr;
+    return build_graph(scale, m_target, seed, threads, tail_permille, ratio_permille, fanin);
+}
+
+} // extern "C"
+
+static hbs_graph *build_graph(int scale, uint64_t m_target, uint64_t seed, int threads, uint32_t tail_permille,
+                              uint32_t ratio_permille, uint32_t fanin)
 {
     if (scale < 1 || scale > 31) return nullptr;
 #ifdef _OPENMP
@@ -132,14 +157,58 @@ hbs_graph *hbs_rmat(int scale, uint64_t m_target, uint64_t seed, int threads)
         want = missing + missing / 4 + 64;
     }
     g->raw_drawn = drawn;
-    const uint64_t m = keys.size();
+    uint64_t m = keys.size();
     // touched vertices
-    const uint64_t space = 1ull << scale;
+    uint64_t space = 1ull << scale;
     std::vector<uint8_t> touched(space, 0);
 #pragma omp parallel for schedule(static)
     for (int64_t i = 0; i < (int64_t)m; i++) {
         touched[(uint32_t)keys[i]] = 1;
         touched[(uint32_t)(keys[i] >> 32)] = 1;
+    }
+    if (tail_permille) {
+        std::vector<uint32_t> core;
+        for (uint64_t v = 0; v < space; v++)
+            if (touched[v]) core.push_back((uint32_t)v);
+        const uint64_t n_core = core.size();
+        const uint64_t n_tail = n_core * tail_permille / 1000;
+        if (n_core && n_tail && space + n_tail < 0xFFFFFFF0ull) {
+            // level sizes: L_1 = n_tail * (1 - r), L_d = L_{d-1} * r
+            std::vector<uint64_t> level_begin; // tail vertex index (0-based) where each level starts
+            uint64_t sz = std::max<uint64_t>(1, n_tail * (1000 - ratio_permille) / 1000), used = 0;
+            while (sz && used < n_tail) {
+                level_begin.push_back(used);
+                used += std::min(sz, n_tail - used);
+                sz = sz * ratio_permille / 1000;
+            }
+            level_begin.push_back(used);
+            const uint64_t tail_nodes = used;
+            const size_t base = keys.size();
+            keys.resize(base + tail_nodes * fanin);
+            for (size_t d = 0; d + 1 < level_begin.size(); d++) {
+                const uint64_t lb = level_begin[d], le = level_begin[d + 1];
+                const uint64_t pb = d ? level_begin[d - 1] : 0, pcount = d ? lb - pb : n_core;
+#pragma omp parallel for schedule(static)
+                for (int64_t j = (int64_t)lb; j < (int64_t)le; j++) {
+                    for (uint32_t e = 0; e < fanin; e++) {
+                        const uint64_t h = splitmix64(seed ^ 0x7A11ull ^ ((uint64_t)j * 64 + e) * 0x9E3779B97F4A7C15ull);
+                        const uint64_t pick = h % pcount;
+                        const uint32_t from = d ? (uint32_t)(space + pb + pick) : core[pick];
+                        keys[base + (uint64_t)j * fanin + e] = ((uint64_t)(uint32_t)(space + (uint64_t)j) << 32) | from;
+                    }
+                }
+            }
+            HBS_SORT(keys.begin(), keys.end());
+            keys.erase(std::unique(keys.begin(), keys.end()), keys.end());
+            m = keys.size();
+            space += tail_nodes;
+            touched.assign(space, 0);
+#pragma omp parallel for schedule(static)
+            for (int64_t i = 0; i < (int64_t)m; i++) {
+                touched[(uint32_t)keys[i]] = 1;
+                touched[(uint32_t)(keys[i] >> 32)] = 1;
+            }
+        }
     }
     struct IdV {
         hbs_u128 id;
@@ -176,6 +245,8 @@ hbs_graph *hbs_rmat(int scale, uint64_t m_target, uint64_t seed, int threads)
     g->edges.swap(keys);
     return g;
 }
+
+extern "C" {
 
 uint64_t hbs_num_nodes(const hbs_graph *g) { return g->ids.size(); }
 uint64_t hbs_num_edges(const hbs_graph *g) { return g->src.size(); }

@@ -19,6 +19,9 @@ def _load():
         L = ctypes.CDLL(LIB_PATH)
         L.hbs_rmat.restype = ctypes.c_void_p
         L.hbs_rmat.argtypes = [ctypes.c_int, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_int]
+        L.hbs_rmat_tail.restype = ctypes.c_void_p
+        L.hbs_rmat_tail.argtypes = [ctypes.c_int, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_int, ctypes.c_uint32,
+                                    ctypes.c_uint32, ctypes.c_uint32]
         L.hbs_free.argtypes = [ctypes.c_void_p]
         for f in ("hbs_num_nodes", "hbs_num_edges", "hbs_raw_drawn"):
             getattr(L, f).restype = ctypes.c_uint64
@@ -35,11 +38,16 @@ def _load():
 class RmatGraph:
     """n touched hosts, m unique non-self edges; ids ascending; CSR by destination."""
 
-    def __init__(self, scale, m_target, seed=SEED, threads=0):
+    def __init__(self, scale, m_target, seed=SEED, threads=0, tail=None):
+        """tail = (tail_permille, ratio_permille, fanin): the long-tail variant (hb_synth.cpp: a levelled DAG of
+        tail_permille/1000 * n_core extra hosts hanging off the core, T grows by the tail depth)."""
         L = _load()
-        self._g = L.hbs_rmat(scale, m_target, seed, threads)
+        if tail:
+            self._g = L.hbs_rmat_tail(scale, m_target, seed, threads, int(tail[0]), int(tail[1]), int(tail[2]))
+        else:
+            self._g = L.hbs_rmat(scale, m_target, seed, threads)
         if not self._g:
-            raise ValueError("hbs_rmat failed (scale must be 1..31)")
+            raise ValueError("hbs_rmat failed (scale must be 1..31; 1..30 with a tail)")
         self.scale = scale
         self.n = L.hbs_num_nodes(self._g)
         self.m = L.hbs_num_edges(self._g)
@@ -85,4 +93,22 @@ CONFIGS = {
     "C3": dict(scale=24, m=200_000_000, label="10M-host / 200M-edge"),
     "C4": dict(scale=28, m=2_000_000_000, label="100M-host / 2B-edge"),
     "C5": dict(scale=30, m=5_000_000_000, label="~300M-host / ~5B-edge (CommonCrawl-scale host graph, synthetic)"),
+    # long convergence tail (real host graphs take tens of passes; plain R-MAT converges in 9-10): the C3 core plus
+    # a levelled DAG of 30 % extra hosts, level sizes shrinking by 0.8, 10 in-links per tail host
+    "LT": dict(scale=24, m=200_000_000, tail=(300, 800, 10), label="long-tail: C3 core + 30% levelled-DAG tail (r=0.8, fan-in 10)"),
+    "LT2": dict(scale=21, m=20_000_000, tail=(300, 800, 10), label="long-tail: C2 core + 30% levelled-DAG tail (r=0.8, fan-in 10)"),
 }
+
+
+def make_config(name):
+    """(graph, scale, label) of a named BASELINE config, or of 'scale:m' / 'scale:m:tail_permille:ratio_permille:fanin'."""
+    if name in CONFIGS:
+        cfg = CONFIGS[name]
+        g = RmatGraph(cfg["scale"], cfg["m"], tail=cfg.get("tail"))
+        label = "%s (R-MAT scale %d, a,b,c,d=.57,.19,.19,.05, seed 0x5712AC7)" % (cfg["label"], cfg["scale"])
+        return g, cfg["scale"], label
+    parts = [int(x) for x in name.split(":")]
+    scale, m_target = parts[0], parts[1]
+    tail = tuple(parts[2:5]) if len(parts) >= 5 else None
+    label = "R-MAT scale %d / %d edges%s" % (scale, m_target, " + tail %s" % (tail,) if tail else "")
+    return RmatGraph(scale, m_target, tail=tail), scale, label

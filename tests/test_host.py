@@ -26,14 +26,14 @@ def test_header_symbols_all_exported():
     assert not missing, missing
     # and the Python binding covers exactly the declared set
     assert declared == set(_lib.SYMBOLS)
-    assert _lib.load().hb_abi_version() == 1
+    assert _lib.load().hb_abi_version() == 2
 
 
 def test_struct_layouts_match_header():
     assert ctypes.sizeof(_lib.HbOptions) == 4 * 7 + 128 + 32
     assert _lib.EDGE.itemsize == 40 and _lib.U128.itemsize == 16
-    assert ctypes.sizeof(_lib.HbStats) == 18 * 8
-    assert ctypes.sizeof(_lib.HbPassStats) == 4 * 8 + 4 * 4
+    assert ctypes.sizeof(_lib.HbStats) == 22 * 8
+    assert ctypes.sizeof(_lib.HbPassStats) == 4 * 8 + 6 * 4
 
 
 @pytest.mark.skipif(_lib.device_count() > 0, reason="only meaningful on a box without a GPU")

@@ -323,3 +323,38 @@ def test_oracle_under_sanitizers(tmp_path):
     env = dict(os.environ, LD_PRELOAD=" ".join(pre), ASAN_OPTIONS="detect_leaks=0", OMP_NUM_THREADS="2", PYTHONPATH=str(work))
     r = subprocess.run([sys.executable, "-c", script], cwd=str(work), capture_output=True, text=True, timeout=900, env=env)
     assert r.returncode == 0 and "sanitized oracle ok" in r.stdout, (r.stdout[-1000:], r.stderr[-3000:])
+
+
+def test_state_hash_definition():
+    """hbo_dense_state_hash (the checksum bench.py compares per pass at sizes too big to ship) against a
+    plain-Python statement of its definition."""
+    M = (1 << 64) - 1
+
+    def mix(x):
+        x ^= x >> 33
+        x = (x * 0xff51afd7ed558ccd) & M
+        x ^= x >> 33
+        x = (x * 0xc4ceb9fe1a85ec53) & M
+        x ^= x >> 33
+        return x
+
+    from stract_amd import synth
+
+    g = synth.RmatGraph(9, 3000)
+    o = hbo.Dense(g.id_low64(), g.row_ptr, g.src)
+    for _ in range(3):
+        o.step(hbo.FRONTIER)
+    regs = o.registers()
+    ks, ke = o.kahan()
+    hr = hk = 0
+    for v in range(g.n):
+        r = (v * 0x9E3779B97F4A7C15 + 1) & M
+        for w in regs[v].view("<u8"):
+            r = mix(r ^ int(w))
+        hr = (hr + r) & M
+        a, b = int(ks[v:v + 1].view(np.uint64)[0]), int(ke[v:v + 1].view(np.uint64)[0])
+        hk = (hk + mix(mix(((v + 0x632BE59BD9B4E019) & M) ^ a) ^ b)) & M
+    assert o.state_hash() == (hr, hk)
+    o2 = hbo.Dense(g.id_low64(), g.row_ptr, g.src)
+    o2.step(hbo.FRONTIER)
+    assert o2.state_hash() != (hr, hk)

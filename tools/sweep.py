@@ -14,8 +14,7 @@ from stract_amd import _lib, synth  # noqa: E402
 
 
 def main():
-    cfg = synth.CONFIGS[sys.argv[1]]
-    g = synth.RmatGraph(cfg["scale"], cfg["m"])
+    g, _, _ = synth.make_config(sys.argv[1])
     ref = None
     for spec in sys.argv[2:]:
         chunk, flags, tune = spec.split(":")
@@ -36,15 +35,16 @@ def main():
             if ref is None:
                 ref = sig
             dense = [p for p in ps if p["mode"] == 0]
-            front = [p for p in ps if p["mode"] == 1]
+            front = [p for p in ps if p["mode"] in (1, 3)]
             sparse = [p for p in ps if p["mode"] == 2]
             print(json.dumps({
                 "spec": spec, "ms_loop": round(best["ms_loop"], 3), "gteps": round(g.m * best["passes"] / best["ms_loop"] / 1e6, 2),
                 "passes": best["passes"], "dense_ms_gpu": round(float(np.mean([p["ms_gpu"] for p in dense])), 3) if dense else None,
                 "dense_ms_main": round(float(np.mean([p["ms_main"] for p in dense])), 3) if dense else None,
                 "front_ms_gpu": round(float(np.mean([p["ms_gpu"] for p in front])), 3) if front else None,
-                "sparse_ms_gpu": [round(p["ms_gpu"], 3) for p in sparse],
-                "changed": [p["changed"] for p in ps], "active_pct": [round(100.0 * p["active_edges"] / g.m, 1) for p in ps],
+                "front_ms_sum": round(float(np.sum([p["ms_gpu"] for p in front])), 3) if front else None,
+                "sparse_ms_sum": round(float(np.sum([p["ms_gpu"] for p in sparse])), 3) if sparse else None,
+                "changed": [p["changed"] for p in ps], "active_pct": [round(100.0 * p["active_edges"] / g.m, 2) for p in ps],
                 "modes": [p["mode"] for p in ps], "ms": [round(p["ms_gpu"], 2) for p in ps],
                 "virtual_rows": best["virtual_rows"], "s_load": round(t_load, 2), "ms_plan": round(best["ms_plan"]),
                 "same_result": sig == ref}), flush=True)
