@@ -71,7 +71,7 @@ typedef struct hb_edge {
 #define HB_FLAG_NO_XCD_MAP    0x20u /* plain blockIdx -> tile mapping, no XCD-affine chunk groups  */
 #define HB_FLAG_NO_RCCL       0x40u /* world_size > 1 bookkeeping without a communicator: the caller
                                        performs the exchange (hb_debug_exchange; tests)       */
-#define HB_FLAG_NO_SPARSE     0x100u /* never use the worklist-driven tail passes (debug; same results) */
+#define HB_FLAG_NO_SPARSE     0x100u /* never use the data-driven sweep passes (debug; same results)       */
 #define HB_FLAG_DEST_PARTITION 0x200u /* world_size > 1: destination partition instead of edge partition -
                                         rank r owns the nodes whose rank in ascending NodeID order is
                                         r mod world_size and must be given ALL in-edges of those nodes
@@ -79,9 +79,6 @@ typedef struct hb_edge {
                                         owned counter slices per pass instead of an all-reduce          */
 #define HB_FLAG_HOST_INGEST   0x400u /* hb_load_edges: reduce the records on the host (hb_host.cpp) instead of
                                         on the GPU (hb_ingest.hip); same result                      */
-#define HB_FLAG_BITMAP_FRONTIER 0x800u /* mid-tail passes: the bitmap frontier pass (every index read and bit-tested)
-                                         instead of the push mode (changed nodes set position bits in their readers'
-                                         64-bit row masks); multi-GPU contexts always use the bitmap pass; same results */
 #define HB_FLAG_RCCL_SELF     0x80u /* world_size == 1 but still create a 1-rank communicator and run
                                        the collectives (exercises the RCCL call path on one GPU)   */
 
@@ -101,7 +98,7 @@ typedef struct hb_options {
                              *  [3] log2 of the hotness slice width in counters (16 = 4 MiB; 1 = no slices)
                              *  [4] min sources of a chunk at a slice cut (8)
                              *  [5] largest row that is not split into chunks (chunk)
-                             *  [6] sparse worklist mode when A_t * tune[6] < edges (64; 1 = whenever frontier)
+                             *  [6] sweep mode (touched rows only) when A_t * tune[6] < edges (10; 1 = whenever frontier)
                              *  [7] reserved (hb_host_plan: owner slices)                          */
 } hb_options;
 
@@ -140,7 +137,8 @@ typedef struct hb_pass_stats {
                                nodes; with HB_FLAG_PASS_STATS counted edge by edge in frontier passes) */
     uint64_t touched;       /* frontier / sparse passes: node rows with >= 1 gathered source (<= V_t: a split
                                row counts only when one of its partials changed); dense passes: 0   */
-    uint32_t mode;          /* 0 = dense (no frontier test), 1 = frontier bitmap, 2 = sparse worklists, 3 = push masks */
+    uint32_t mode;          /* 0 = dense (no frontier test), 1 = frontier bitmap, 2 = sweep (touch bitmap of the rows
+                               that read a changed node; only those rows run)                                */
     float    ms_gpu;        /* GPU time of the pass (all its launches + collective)         */
     float    ms_main;       /* GPU time of the dominant launch (real rows)                  */
     float    ms_collective;

@@ -26,7 +26,6 @@ HB_FLAG_RCCL_SELF = 0x80
 HB_FLAG_NO_SPARSE = 0x100
 HB_FLAG_DEST_PARTITION = 0x200
 HB_FLAG_HOST_INGEST = 0x400
-HB_FLAG_BITMAP_FRONTIER = 0x800
 
 # numpy views of the plain-data structs
 U128 = np.dtype([("lo", "<u8"), ("hi", "<u8")])

@@ -66,11 +66,8 @@ struct hb_ctx {
     // sparse (data-driven) tail passes: transposed work-row graph + worklists
     uint64_t *d_out_ptr = nullptr;
     uint32_t *d_out_rows = nullptr;
-    uint8_t *d_out_pos = nullptr;             // position of the source in the reader row's list (push mode)
-    unsigned long long *d_mask = nullptr;     // push mode: active-source mask per work row
-    bool push_ok = false;
     uint32_t *d_touch = nullptr;
-    uint32_t *d_list_real = nullptr, *d_list_virt = nullptr, *d_seeds = nullptr, *d_heavy = nullptr, *d_medium = nullptr;
+    uint32_t *d_seeds = nullptr, *d_heavy = nullptr;
     unsigned int *d_sparse_counts = nullptr;
     bool sparse_ok = false;
     uint64_t plan_entries = 0; // entries of all work rows' source lists
@@ -158,11 +155,8 @@ void free_graph_buffers(hb_ctx *c)
     c->d_out = nullptr;
     c->d_out_ptr = nullptr;
     c->d_out_rows = nullptr;
-    c->d_out_pos = nullptr;
-    c->d_mask = nullptr;
-    c->push_ok = false;
     c->d_touch = nullptr;
-    c->d_list_real = c->d_list_virt = c->d_seeds = c->d_heavy = c->d_medium = nullptr;
+    c->d_seeds = c->d_heavy = nullptr;
     c->d_sparse_counts = nullptr;
     c->sparse_ok = false;
     if (c->h_out) (void)hipHostFree(c->h_out);
@@ -199,15 +193,13 @@ bool unfused(const hb_ctx *c)
     return edge_partitioned(c) || (c->comm && !dest_mode(c)) || (c->opt.flags & HB_FLAG_UNFUSED);
 }
 
-// Transposed work-row graph (who reads each node / virtual row) and worklists for the sparse
-// tail passes; built on the device from the uploaded plan, prefix sum on the host.
+// Transposed work-row graph (who reads each node / virtual row), touch bitmap and seed lists for the
+// sweep-mode passes; built on the device from the uploaded plan, prefix sum on the host.
 int build_sparse_support(hb_ctx *c)
 {
     const Plan &p = c->plan;
     c->sparse_ok = false;
-    c->push_ok = false;
     if (unfused(c) || multi_rank(c) || (c->opt.flags & HB_FLAG_NO_SPARSE) || p.n == 0) return HB_OK;
-    if (p.level_begin.size() > (size_t)hbk::kMaxSparseLevels + 1) return HB_OK; // very deep trees: bitmap modes only
     const uint64_t rows_total = p.n_pad + p.nv;
     const uint64_t entries = p.src.size();
     c->plan_entries = entries;
@@ -215,21 +207,12 @@ int build_sparse_support(hb_ctx *c)
     uint32_t *d_count = nullptr;
     if ((rc = dev_alloc(c, &c->d_out_ptr, rows_total + 1))) return rc;
     if ((rc = dev_alloc(c, &c->d_out_rows, entries))) return rc;
-    if ((rc = dev_alloc(c, &c->d_touch, c->bits_words))) return rc;
-    if ((rc = dev_alloc(c, &c->d_list_real, p.n_pad))) return rc;
-    if ((rc = dev_alloc(c, &c->d_list_virt, p.nv))) return rc;
+    if ((rc = dev_alloc(c, &c->d_touch, c->bits_words + 64))) return rc; // + 64: a wave reads 64 words at a time
     if ((rc = dev_alloc(c, &c->d_seeds, p.n_pad))) return rc;
     if ((rc = dev_alloc(c, &c->d_heavy, p.n_pad))) return rc;
-    if ((rc = dev_alloc(c, &c->d_medium, p.n_pad))) return rc;
     if ((rc = dev_alloc(c, &c->d_sparse_counts, 64))) return rc;
     if ((rc = dev_alloc(c, &d_count, rows_total))) return rc; // stays allocated (small next to out_rows)
-    // push mode (mid-tail passes): 64-bit masks, so every work row must have <= 64 sources
-    const bool want_push = p.chunk <= 64 && !(c->opt.flags & HB_FLAG_BITMAP_FRONTIER);
-    if (want_push) {
-        if ((rc = dev_alloc(c, &c->d_out_pos, entries))) return rc;
-        if ((rc = dev_alloc(c, &c->d_mask, rows_total))) return rc;
-        HB_HIP(hipMemsetAsync(c->d_mask, 0, rows_total * sizeof(unsigned long long), c->stream));
-    }
+    HB_HIP(hipMemsetAsync(c->d_touch, 0, (c->bits_words + 64) * sizeof(uint32_t), c->stream));
     HB_HIP(hipMemsetAsync(d_count, 0, rows_total * sizeof(uint32_t), c->stream));
     const unsigned blocks = (unsigned)std::min<uint64_t>((rows_total * 4 + 255) / 256, (uint64_t)c->num_cu * 16);
     hipLaunchKernelGGL(hbk::transpose_count_kernel, dim3(blocks), dim3(256), 0, c->stream, (const uint64_t *)c->d_row_ptr,
@@ -249,12 +232,10 @@ int build_sparse_support(hb_ctx *c)
     HB_HIP(hipMemcpyAsync(c->d_out_ptr, optr.data(), (rows_total + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
     HB_HIP(hipMemsetAsync(d_count, 0, rows_total * sizeof(uint32_t), c->stream));
     hipLaunchKernelGGL(hbk::transpose_fill_kernel, dim3(blocks), dim3(256), 0, c->stream, (const uint64_t *)c->d_row_ptr,
-                       (const uint32_t *)c->d_src, rows_total, (const uint64_t *)c->d_out_ptr, d_count, c->d_out_rows,
-                       c->d_out_pos);
+                       (const uint32_t *)c->d_src, rows_total, (const uint64_t *)c->d_out_ptr, d_count, c->d_out_rows);
     HB_HIP(hipGetLastError());
     HB_HIP(hipStreamSynchronize(c->stream));
     c->sparse_ok = true;
-    c->push_ok = want_push;
     return HB_OK;
 }
 
@@ -479,76 +460,49 @@ int step_local(hb_ctx *c)
     const uint32_t thr = c->opt.tune[2] ? c->opt.tune[2] : 50; // frontier when A_t < thr % of the edges
     const bool frontier = !(c->opt.flags & HB_FLAG_NO_FRONTIER) && c->t > 0 &&
                           (c->last_active * 100ull < (uint64_t)thr * c->m_global || thr > 100);
-    const uint64_t sparse_div = c->opt.tune[6] ? c->opt.tune[6] : 64; // sparse when A_t * div < edges
+    // sweep mode when A_t * div < edges: measured crossover with the bitmap pass at A_t = 10-12 % of the edges
+    // (profiles/r02c_sweep_*: 7.4 % -> 1.25 ms vs 2.15 ms, 16 % -> 4.1 ms vs 2.1 ms on the C3-sized graphs)
+    const uint64_t sparse_div = c->opt.tune[6] ? c->opt.tune[6] : 10;
     const bool sparse = frontier && c->sparse_ok && (c->last_active * sparse_div < c->m_global || c->opt.tune[6] == 1);
-    const bool push = frontier && !sparse && c->push_ok;
-    c->cur_mode = sparse ? 2 : (push ? 3 : (frontier ? 1 : 0));
+    c->cur_mode = sparse ? 2 : (frontier ? 1 : 0);
     const bool fused = !unfused(c);
     hbk::PassParams pp = make_params(c);
     HB_HIP(hipEventRecord(c->ev[0], c->stream));
-    if (sparse || push) {
-        hbk::SparseParams sp{};
+    if (sparse) {
+        // sweep mode: changed nodes -> touch bits of their readers; then the levels, then the node rows
+        hbk::SweepParams sp{};
         sp.p = pp;
         sp.out_ptr = c->d_out_ptr;
         sp.out_rows = c->d_out_rows;
-        sp.out_pos = c->d_out_pos;
-        sp.mask = c->d_mask;
         sp.touch = c->d_touch;
-        sp.list_real = c->d_list_real;
-        sp.list_virt = c->d_list_virt;
         sp.seeds = c->d_seeds;
         sp.heavy = c->d_heavy;
-        sp.medium = c->d_medium;
         sp.counts = c->d_sparse_counts;
-        sp.levels = (int)p.level_begin.size() - 1;
-        if (sp.levels < 0) sp.levels = 0;
-        for (size_t l = 0; l < p.level_begin.size(); l++) sp.level_begin[l] = p.level_begin[l];
         const uint64_t real_words = p.n_pad / 32;
         HB_HIP(hipMemsetAsync(c->d_sparse_counts, 0, 64 * sizeof(unsigned int), c->stream));
-        const unsigned sblocks = (unsigned)std::min<uint64_t>(std::max<uint64_t>(real_words / 256, 1), (uint64_t)c->num_cu * 4);
-        const unsigned wblocks = (unsigned)c->num_cu * 4;
-        if (push) {
-            // changed nodes -> bits in their readers' masks; then the levels, then the node rows
-            hipLaunchKernelGGL(hbk::sparse_collect_kernel<false>, dim3(sblocks), dim3(256), 0, c->stream, sp);
-            hipLaunchKernelGGL(hbk::sparse_expand_kernel<true>, dim3(wblocks), dim3(256), 0, c->stream, sp);
-            hipLaunchKernelGGL(hbk::sparse_expand_medium_kernel<true>, dim3(wblocks), dim3(256), 0, c->stream, sp);
-            hipLaunchKernelGGL(hbk::sparse_expand_heavy_kernel<true>, dim3(wblocks), dim3(256), 0, c->stream, sp);
-            const uint32_t bpc = c->opt.tune[0] ? c->opt.tune[0] : 8;
-            for (size_t l = 0; l + 1 < p.level_begin.size(); l++) {
-                sp.p.row_lo = p.level_begin[l];
-                sp.p.row_hi = p.level_begin[l + 1];
-                const uint64_t nt = (sp.p.row_hi - sp.p.row_lo + 63) / 64;
-                if (nt) {
-                    const unsigned blocks = (unsigned)std::min<uint64_t>(nt, (uint64_t)c->num_cu * bpc);
-                    hipLaunchKernelGGL(hbk::push_rows_kernel<false>, dim3(blocks), dim3(256), 0, c->stream, sp);
-                }
-                if (l == 0) HB_HIP(hipEventRecord(c->ev[5], c->stream));
-            }
-            HB_HIP(hipEventRecord(c->ev[1], c->stream));
-            sp.p.row_lo = 0;
-            sp.p.row_hi = p.n_pad;
-            if (p.n_pad) {
-                const unsigned blocks = (unsigned)std::min<uint64_t>(p.n_pad / 64, (uint64_t)c->num_cu * bpc);
-                hipLaunchKernelGGL(hbk::push_rows_kernel<true>, dim3(blocks), dim3(256), 0, c->stream, sp);
-            }
-            HB_HIP(hipEventRecord(c->ev[2], c->stream));
-        } else {
-        HB_HIP(hipMemsetAsync(c->d_touch, 0, c->bits_words * 4, c->stream));
         HB_HIP(hipMemsetAsync(c->d_bits[c->cur ^ 1], 0, c->bits_words * 4, c->stream));           // this pass' changed bits
         if (c->bits_words > real_words)                                                             // this pass' virtual bits
             HB_HIP(hipMemsetAsync(c->d_bits[c->cur] + real_words, 0, (c->bits_words - real_words) * 4, c->stream));
-        hipLaunchKernelGGL(hbk::sparse_collect_kernel<true>, dim3(sblocks), dim3(256), 0, c->stream, sp);
-        hipLaunchKernelGGL(hbk::sparse_expand_kernel<false>, dim3(wblocks), dim3(256), 0, c->stream, sp);
-        hipLaunchKernelGGL(hbk::sparse_expand_medium_kernel<false>, dim3(wblocks), dim3(256), 0, c->stream, sp);
-        hipLaunchKernelGGL(hbk::sparse_expand_heavy_kernel<false>, dim3(wblocks), dim3(256), 0, c->stream, sp);
-        for (int l = 0; l < sp.levels; l++) {
-            sp.level = l;
-            hipLaunchKernelGGL(hbk::sparse_rows_kernel<false>, dim3(wblocks), dim3(256), 0, c->stream, sp);
+        const unsigned sblocks = (unsigned)std::min<uint64_t>(std::max<uint64_t>(real_words / 256, 1), (uint64_t)c->num_cu * 4);
+        const unsigned wblocks = (unsigned)c->num_cu * 4;
+        hipLaunchKernelGGL(hbk::sweep_collect_kernel, dim3(sblocks), dim3(256), 0, c->stream, sp);
+        hipLaunchKernelGGL(hbk::sweep_expand_kernel, dim3(wblocks), dim3(256), 0, c->stream, sp);
+        hipLaunchKernelGGL(hbk::sweep_expand_heavy_kernel, dim3(wblocks), dim3(256), 0, c->stream, sp);
+        auto sweep_blocks = [&](uint64_t rows) { // a wave-iteration covers 16 groups of 128 rows
+            const uint64_t waves = (rows + 2047) / 2048;
+            return (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((waves + 3) / 4, (uint64_t)c->num_cu * 4));
+        };
+        for (size_t l = 0; l + 1 < p.level_begin.size(); l++) {
+            sp.p.row_lo = p.level_begin[l];
+            sp.p.row_hi = p.level_begin[l + 1];
+            if (sp.p.row_hi > sp.p.row_lo)
+                hipLaunchKernelGGL(hbk::sweep_rows_kernel<false>, dim3(sweep_blocks(sp.p.row_hi - sp.p.row_lo)), dim3(256), 0, c->stream, sp);
         }
         HB_HIP(hipEventRecord(c->ev[1], c->stream));
-        hipLaunchKernelGGL(hbk::sparse_rows_kernel<true>, dim3(wblocks), dim3(256), 0, c->stream, sp);
+        sp.p.row_lo = 0;
+        sp.p.row_hi = p.n_pad;
+        if (p.n_pad) hipLaunchKernelGGL(hbk::sweep_rows_kernel<true>, dim3(sweep_blocks(p.n_pad)), dim3(256), 0, c->stream, sp);
         HB_HIP(hipEventRecord(c->ev[2], c->stream));
-        }
     } else {
         for (size_t l = 0; l + 1 < p.level_begin.size(); l++) {
             pp.row_lo = p.level_begin[l];
@@ -623,9 +577,7 @@ int step_finish(hb_ctx *c, int *has_changes)
     hb_pass_stats ps{};
     ps.pass = c->t;
     ps.changed = c->h_counters[0];
-    // A_t: the out-degree sum of the nodes changed in the previous pass; counted pair by pair in push mode
-    // (set mask bits of rows with node sources) and, with HB_FLAG_PASS_STATS, edge by edge in the bitmap mode
-    ps.active_edges = (c->cur_mode == 3 || (c->opt.flags & HB_FLAG_PASS_STATS)) ? c->h_counters[1] : c->last_active;
+    ps.active_edges = (c->opt.flags & HB_FLAG_PASS_STATS) ? c->h_counters[1] : c->last_active; // A_t
     ps.touched = c->h_counters[2];
     ps.mode = c->cur_mode;
     float ms_all = 0.f, ms_main = 0.f;

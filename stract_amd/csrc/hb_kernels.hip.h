@@ -499,140 +499,79 @@ __global__ __launch_bounds__(256) void pass_kernel(const PassParams p)
     }
 }
 
-// ---- sparse (data-driven) pass: the convergence tail --------------------------------------
-// When few nodes changed in the previous pass, scanning every row (even with the frontier
-// test) costs far more than the work.  The reference switches to update_changed_counters
-// (harmonic.rs:75-114: only the out-edges of the exactly-tracked changed set) in the same
-// situation.  Here: the transposed work-row graph (out_ptr/out_rows: for every node or
-// virtual row, the work rows that read it) turns the changed set into per-level worklists;
-// only listed rows are processed, with exactly the frontier-mode row semantics of
-// pass_kernel, so registers / Kahan state / changed bits are bit-identical.
-constexpr int kMaxSparseLevels = 12;
-constexpr int kHeavySlot = 32;          // index into SparseParams::counts
-constexpr int kMediumSlot = 33;
-constexpr uint64_t kLightReaders = 8;   // a seed with at most this many readers is expanded by one lane
-constexpr uint64_t kHeavyReaders = 2048; // a seed with more readers than this is expanded grid-wide
+// ---- sweep mode (data-driven passes: the mid-tail and the convergence tail) -------------------
+// When a minority of the nodes changed in the previous pass, reading and bit-testing every index
+// (bitmap frontier pass) costs far more than the work.  The reference switches to
+// update_changed_counters (harmonic.rs:75-114: only the out-edges of the exactly-tracked changed set)
+// in the same situation.  Here: the transposed work-row graph (out_ptr/out_rows: for every node or
+// virtual row, the work rows that read it) turns the changed set into a TOUCH bitmap over the work rows
+// (one bit per row; a few MB, cache resident, so the atomic ORs are cheap - 64-bit per-row masks and
+// per-level worklists were both measured slower, profiles/r02a_*); every level is then one ordered sweep
+// over its slice of that bitmap: a wave takes 64 words (2048 rows), clears them, compacts the set bits into
+// a row list in LDS and runs the listed rows, one quad each, with exactly the frontier-mode row semantics
+// of pass_kernel - registers / Kahan state / changed bits are bit-identical.  A virtual row that changed
+// touches its parent, so changes climb the chunk trees inside the pass.  Rows are visited in ascending
+// order (their state arrays are read almost sequentially, unlike worklists filled in arrival order) and the
+// bitmap is left all-zero for the next pass.
+constexpr uint64_t kHeavyReaders = 4096; // a seed with more readers than this is expanded grid-wide
 
-struct SparseParams {
+struct SweepParams {
     PassParams p;
     const uint64_t *out_ptr;   // rows_total + 1
     const uint32_t *out_rows;  // work rows reading each source
-    const uint8_t *out_pos;    // ... and the position of the source inside that row's list (< 64)
-    unsigned long long *mask;  // push mode: per work row, bit k = the k-th source of the row is active in this pass;
-                               // all-zero between passes (the row kernels clear what they consume)
-    uint32_t *touch;           // 1 bit per work row: already on a worklist
-    uint32_t *list_real;       // worklist of node rows (capacity n_pad)
-    uint32_t *list_virt;       // worklists of virtual rows, level l at offset level_begin[l] - n_pad
+    uint32_t *touch;           // 1 bit per work row: has an active source / must be revisited
     uint32_t *seeds;           // nodes changed in the previous pass (capacity n_pad)
-    uint32_t *heavy;           // seeds with long reader lists (expanded by the whole grid)
-    uint32_t *medium;          // seeds expanded by one wave each
-    unsigned int *counts;      // [0] seeds, [1] real list, [2 + l] level-l list, [kHeavySlot] heavy seeds
-    uint64_t level_begin[kMaxSparseLevels + 1];
-    int levels;
-    int level;                 // level processed by this launch (sparse_rows_kernel<false>)
+    uint32_t *heavy;           // seeds with very long reader lists (expanded by the whole grid)
+    unsigned int *counts;      // [0] seeds, [1] heavy seeds
 };
 
-// Wave-aggregated append: every lane of the wave calls this (has = lane has a row to offer).  A row is
-// appended to its level's worklist the first time its touch bit is set; one atomicAdd per wave and
-// list instead of one per row (a single hot counter sustains only ~90 atomics/us).
-__device__ __forceinline__ void sparse_push(const SparseParams &sp, bool has, uint32_t r)
+__device__ __forceinline__ void touch_set(uint32_t *touch, uint32_t r)
 {
-    int lid = -1; // 0 = node rows, 1 + l = virtual level l
-    if (has) {
-        const uint32_t bit = 1u << (r & 31u);
-        bool fresh = !(__builtin_nontemporal_load(&sp.touch[r >> 5]) & bit); // cheap pre-test
-        if (fresh) fresh = !(atomicOr(&sp.touch[r >> 5], bit) & bit);
-        if (fresh) {
-            if ((uint64_t)r < sp.p.n_pad) {
-                lid = 0;
-            } else {
-                int l = 0;
-                while (l + 1 < sp.levels && (uint64_t)r >= sp.level_begin[l + 1]) l++;
-                lid = 1 + l;
-            }
-        }
-    }
-    const int lane = threadIdx.x & 63;
-    uint64_t todo = __ballot(lid >= 0);
-    while (todo) {
-        const int leader = __ffsll((long long)todo) - 1;
-        const int cur = __shfl(lid, leader);
-        const uint64_t mask = __ballot(lid == cur);
-        uint32_t base = 0;
-        if (lane == leader) base = atomicAdd(&sp.counts[cur == 0 ? 1 : 1 + cur], (unsigned)__popcll(mask));
-        base = __shfl(base, leader);
-        if (lid == cur) {
-            const uint32_t pos = base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
-            if (cur == 0) sp.list_real[pos] = r;
-            else sp.list_virt[(sp.level_begin[cur - 1] - sp.p.n_pad) + pos] = r;
-        }
-        todo &= ~mask;
-    }
+    const uint32_t bit = 1u << (r & 31u);
+    // cheap pre-test (a stale 0 only costs a redundant atomic; bits are never cleared while being set)
+    if (!(__builtin_nontemporal_load(&touch[r >> 5]) & bit)) atomicOr(&touch[r >> 5], bit);
 }
 
-// one thread per 32 node rows: changed-in-the-previous-pass nodes become seeds (their readers are
-// expanded by sparse_expand_kernel) and, like Kahan-dirty nodes, are visited themselves.
-// LISTS = false (push mode): only the seed list is built
-template <bool LISTS>
-__global__ __launch_bounds__(256) void sparse_collect_kernel(const SparseParams sp)
+// one thread per 32 node rows: nodes that changed in the previous pass become seeds (their readers are
+// touched by sweep_expand_kernel); like Kahan-dirty nodes they are also revisited themselves.
+__global__ __launch_bounds__(256) void sweep_collect_kernel(const SweepParams sp)
 {
     const uint64_t words = sp.p.n_pad >> 5;
     const int lane = threadIdx.x & 63;
     const uint64_t stride = (uint64_t)gridDim.x * 256;
     for (uint64_t w0 = (uint64_t)blockIdx.x * 256; w0 < words; w0 += stride) { // wave-uniform trip count
         const uint64_t w = w0 + threadIdx.x;
-        uint32_t ch = 0, both = 0;
+        uint32_t ch = 0;
         if (w < words) {
             ch = sp.p.bits_rd[w];
-            both = LISTS ? (ch | sp.p.kdirty[w]) : ch;
-            if (LISTS && both) sp.touch[w] = both; // first writer of these words (the buffer was just cleared)
+            const uint32_t both = ch | sp.p.kdirty[w];
+            if (both) sp.touch[w] = both; // first writer of these words in this pass (the bitmap is all-zero between passes)
         }
-        // wave-aggregated reservation in the seed list and in the node-row worklist
-        uint32_t nch = __popc(ch), nb = __popc(both);
-        uint32_t pch = nch, pb = nb; // inclusive prefix sums over the wave
+        // wave-aggregated reservation in the seed list
+        const uint32_t nch = __popc(ch);
+        uint32_t pch = nch; // inclusive prefix sum over the wave
 #pragma unroll
         for (int off = 1; off < 64; off <<= 1) {
-            const uint32_t a = __shfl_up(pch, off), b = __shfl_up(pb, off);
-            if (lane >= off) {
-                pch += a;
-                pb += b;
-            }
+            const uint32_t a = __shfl_up(pch, off);
+            if (lane >= off) pch += a;
         }
-        const uint32_t tot_ch = __shfl(pch, 63), tot_b = __shfl(pb, 63);
-        uint32_t base_ch = 0, base_b = 0;
-        if (lane == 0) {
-            if (tot_ch) base_ch = atomicAdd(&sp.counts[0], tot_ch);
-            if (LISTS && tot_b) base_b = atomicAdd(&sp.counts[1], tot_b);
-        }
-        base_ch = __shfl(base_ch, 0) + pch - nch;
-        base_b = __shfl(base_b, 0) + pb - nb;
-        while (both) {
-            const int b = __ffs((int)both) - 1;
-            both &= both - 1;
-            const uint32_t row = (uint32_t)(w << 5) + (uint32_t)b;
-            if ((ch >> b) & 1u) sp.seeds[base_ch++] = row;
-            if (LISTS) sp.list_real[base_b++] = row;
+        const uint32_t tot = __shfl(pch, 63);
+        uint32_t base = 0;
+        if (lane == 0 && tot) base = atomicAdd(&sp.counts[0], tot);
+        base = __shfl(base, 0) + pch - nch;
+        while (ch) {
+            const int b = __ffs((int)ch) - 1;
+            ch &= ch - 1;
+            sp.seeds[base++] = (uint32_t)(w << 5) + (uint32_t)b;
         }
     }
 }
 
-// what an expansion step does with reader entry k of a seed: worklist append (sparse mode) or, in push
-// mode, one fire-and-forget atomic OR of the source's position bit into the reader row's mask
-template <bool MASK>
-__device__ __forceinline__ void expand_emit(const SparseParams &sp, bool has, uint64_t k)
-{
-    if (MASK) {
-        if (has) atomicOr(&sp.mask[sp.out_rows[k]], 1ull << sp.out_pos[k]);
-    } else {
-        sparse_push(sp, has, has ? sp.out_rows[k] : 0u);
-    }
-}
-
-// Seeds -> worklists in three tiers by reader count: <= kLightReaders inline, one LANE per seed
-// (most late changers are read by one or two rows); up to kHeavyReaders one WAVE per seed
-// (sparse_expand_medium_kernel); beyond that the whole grid (hubs stay in the changed set longest).
-template <bool MASK>
-__global__ __launch_bounds__(256) void sparse_expand_kernel(const SparseParams sp)
+// Seeds -> touch bits.  A wave takes 64 seeds and walks the CONCATENATION of their reader lists 64 entries
+// at a time (exclusive prefix sums of the list lengths; every lane finds the seed of its entry by a binary
+// search over the lanes' offsets with ds_bpermute), so lanes stay busy whatever the out-degrees are.  Seeds
+// with more than kHeavyReaders readers (hubs stay in the changed set longest) go to the grid-wide kernel.
+__global__ __launch_bounds__(256) void sweep_expand_kernel(const SweepParams sp)
 {
     const int lane = threadIdx.x & 63;
     const uint32_t nseeds = sp.counts[0];
@@ -646,49 +585,50 @@ __global__ __launch_bounds__(256) void sparse_expand_kernel(const SparseParams s
             b = sp.out_ptr[u];
             e = sp.out_ptr[u + 1];
         }
-        const bool medium = e - b > kLightReaders;
-        const uint64_t mm = __ballot(medium);
-        if (mm) {
-            uint32_t base = 0;
-            const int leader = __ffsll((long long)mm) - 1;
-            if (lane == leader) base = atomicAdd(&sp.counts[kMediumSlot], (unsigned)__popcll(mm));
-            base = __shfl(base, leader);
-            if (medium) {
-                sp.medium[base + (uint32_t)__popcll(mm & ((1ull << lane) - 1ull))] = u;
-                b = e;
+        const bool is_heavy = e - b > kHeavyReaders;
+        const uint64_t hm = __ballot(is_heavy);
+        if (hm) {
+            uint32_t hb = 0;
+            const int leader = __ffsll((long long)hm) - 1;
+            if (lane == leader) hb = atomicAdd(&sp.counts[1], (unsigned)__popcll(hm));
+            hb = __shfl(hb, leader);
+            if (is_heavy) {
+                sp.heavy[hb + (uint32_t)__popcll(hm & ((1ull << lane) - 1ull))] = u;
+                e = b;
             }
         }
-        while (__ballot(b < e)) {
-            expand_emit<MASK>(sp, b < e, b);
-            b++;
+        const uint32_t len = (uint32_t)(e - b);
+        uint32_t incl = len;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t a = __shfl_up(incl, off);
+            if (lane >= off) incl += a;
+        }
+        const uint32_t total = __shfl(incl, 63);
+        const uint32_t excl = incl - len;
+        const uint32_t blo = (uint32_t)b, bhi = (uint32_t)(b >> 32);
+        for (uint32_t r = 0; r < total; r += 64) {
+            const uint32_t item = r + lane;
+            // owner = last lane whose exclusive offset is <= item (lanes with empty lists share offsets with
+            // their successor; the LAST such lane is the one that owns the entry)
+            int lo = 0, hi = 64;
+#pragma unroll
+            for (int step = 0; step < 6; step++) {
+                const int mid = (lo + hi) >> 1;
+                const uint32_t v = __shfl(excl, mid);
+                if (v <= item) lo = mid;
+                else hi = mid;
+            }
+            const uint32_t oex = __shfl(excl, lo);
+            const uint64_t ob = ((uint64_t)__shfl(bhi, lo) << 32) | __shfl(blo, lo);
+            if (item < total) touch_set(sp.touch, sp.out_rows[ob + (item - oex)]);
         }
     }
 }
 
-template <bool MASK>
-__global__ __launch_bounds__(256) void sparse_expand_medium_kernel(const SparseParams sp)
+__global__ __launch_bounds__(256) void sweep_expand_heavy_kernel(const SweepParams sp)
 {
-    const int lane = threadIdx.x & 63;
-    const uint32_t nmed = sp.counts[kMediumSlot];
-    const uint32_t wave = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
-    for (uint32_t i = wave; i < nmed; i += nwaves) {
-        const uint32_t u = sp.medium[i];
-        const uint64_t b = sp.out_ptr[u], e = sp.out_ptr[u + 1];
-        if (e - b > kHeavyReaders) {
-            if (lane == 0) sp.heavy[atomicAdd(&sp.counts[kHeavySlot], 1u)] = u;
-            continue;
-        }
-        for (uint64_t k0 = b; k0 < e; k0 += 64) {
-            const uint64_t k = k0 + lane;
-            expand_emit<MASK>(sp, k < e, k);
-        }
-    }
-}
-
-template <bool MASK>
-__global__ __launch_bounds__(256) void sparse_expand_heavy_kernel(const SparseParams sp)
-{
-    const uint32_t nheavy = sp.counts[kHeavySlot];
+    const uint32_t nheavy = sp.counts[1];
     const uint64_t wbase = ((uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 64, nthreads = (uint64_t)gridDim.x * 256;
     const int lane = threadIdx.x & 63;
     for (uint32_t i = 0; i < nheavy; i++) {
@@ -696,19 +636,22 @@ __global__ __launch_bounds__(256) void sparse_expand_heavy_kernel(const SparsePa
         const uint64_t b = sp.out_ptr[u], e = sp.out_ptr[u + 1];
         for (uint64_t k0 = b + wbase; k0 < e; k0 += nthreads) { // wave-uniform trip count
             const uint64_t k = k0 + lane;
-            expand_emit<MASK>(sp, k < e, k);
+            if (k < e) touch_set(sp.touch, sp.out_rows[k]);
         }
     }
 }
 
-// the listed rows, one quad each; REAL: node rows (self = rd[row], fused estimator + Kahan),
-// else virtual rows of level sp.level (self = part[row - n_pad]; changed rows push their readers)
+// the touched rows of [row_lo, row_hi) (multiples of 64), in ascending order, one quad each; REAL: node rows
+// (self = rd[row], fused estimator + Kahan), else virtual rows (self = part[row - n_pad]; a changed row sets
+// its changed bit of this pass and touches its readers)
 template <bool REAL>
-__global__ __launch_bounds__(256) void sparse_rows_kernel(const SparseParams sp)
+__global__ __launch_bounds__(256) void sweep_rows_kernel(const SweepParams sp)
 {
     __shared__ double s_raw[REAL ? kTableLen : 1];
     __shared__ double s_bias[REAL ? kTableLen : 1];
     __shared__ uint8_t s_lc[68];
+    __shared__ uint32_t s_rows[4][2048]; // per wave: the rows of its 64 bitmap words that are set
+    constexpr int kU = 2;                // index quads per gather round
     const PassParams &p = sp.p;
     if (REAL) {
         for (int i = threadIdx.x; i < kTableLen; i += 256) {
@@ -718,99 +661,147 @@ __global__ __launch_bounds__(256) void sparse_rows_kernel(const SparseParams sp)
         if (threadIdx.x < 65) s_lc[threadIdx.x] = p.lc[threadIdx.x];
         __syncthreads();
     }
-    const int lane = threadIdx.x & 63;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int g = lane >> 2, q = lane & 3, qshift = lane & ~3;
-    const uint32_t count = REAL ? sp.counts[1] : sp.counts[2 + sp.level];
-    const uint32_t *list = REAL ? sp.list_real : sp.list_virt + (sp.level_begin[sp.level] - p.n_pad);
-    const uint32_t nwaves = gridDim.x * 4;
+    uint32_t *list = s_rows[wv];
+    const uint64_t w_lo = p.row_lo >> 5, w_hi = (p.row_hi + 31) >> 5;
+    const uint64_t nwaves = (uint64_t)gridDim.x * 4, wid = (uint64_t)blockIdx.x * 4 + wv;
+    // A wave-iteration takes 64 bitmap words as 16 groups of 4 consecutive words (128 rows) that lie nwaves
+    // groups apart: touched rows cluster (the readers of late changers are cold chunks / low-degree rows, which
+    // the device order keeps together), and contiguous 2048-row slabs gave a few waves all the work.
+    const uint64_t ngroups = (w_hi - w_lo + 3) >> 2;
     unsigned long long cnt_changed = 0, cnt_out = 0, cnt_rows = 0;
-    for (uint32_t base = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 16; base < count; base += nwaves * 16) {
-        const uint32_t li = base + (uint32_t)g;
-        const bool valid = li < count;
-        const uint64_t row = valid ? (uint64_t)list[li] : 0;
-        uint64_t beg = 0, end = 0;
-        if (valid) {
-            beg = p.row_ptr[row];
-            end = p.row_ptr[row + 1];
+    for (uint64_t g0 = 0; g0 < ngroups; g0 += 16 * nwaves) { // wave-uniform trip count
+        const uint64_t gi = g0 + (uint64_t)(lane >> 2) * nwaves + wid;
+        const uint64_t w = w_lo + gi * 4 + (uint64_t)(lane & 3);
+        uint32_t word = (gi < ngroups && w < w_hi) ? sp.touch[w] : 0u;
+        if (word) sp.touch[w] = 0; // consumed: the bitmap is all-zero again after the pass
+        const uint32_t cnt = __popc(word);
+        uint32_t incl = cnt;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t a = __shfl_up(incl, off);
+            if (lane >= off) incl += a;
         }
-        const uint4 *selfp = REAL ? (p.rd + row * 4 + q) : (p.part + (row - p.n_pad) * 4 + q);
-        Acc acc;
-        acc_zero(acc);
-        bool lane_act = false;
-        if (beg < end) {
-            const uint32_t first = p.src[beg];
-            const uint4 *srcbase = (first >= p.n_pad) ? (const uint4 *)(p.part - p.n_pad * 4) : p.rd;
-            for (uint64_t e = beg; e < end; e += 4) {
-                const uint64_t ee = e + q;
-                uint32_t idx = (ee < end) ? p.src[ee] : kNone;
-                if (idx != kNone && !((p.bits_rd[idx >> 5] >> (idx & 31u)) & 1u)) idx = kNone;
-                lane_act |= (idx != kNone);
-                const uint32_t s0 = quad_bcast<0>(idx), s1 = quad_bcast<1>(idx);
-                const uint32_t s2 = quad_bcast<2>(idx), s3 = quad_bcast<3>(idx);
-                uint4 r0 = make_uint4(0, 0, 0, 0), r1 = r0, r2 = r0, r3 = r0;
-                if (s0 != kNone) r0 = srcbase[(uint64_t)s0 * 4 + q];
-                if (s1 != kNone) r1 = srcbase[(uint64_t)s1 * 4 + q];
-                if (s2 != kNone) r2 = srcbase[(uint64_t)s2 * 4 + q];
-                if (s3 != kNone) r3 = srcbase[(uint64_t)s3 * 4 + q];
-                acc_merge(acc, r0);
-                acc_merge(acc, r1);
-                acc_merge(acc, r2);
-                acc_merge(acc, r3);
-            }
+        const uint32_t total = __shfl(incl, 63);
+        if (total == 0) continue;
+        uint32_t pos = incl - cnt;
+        while (word) {
+            const int b = __ffs((int)word) - 1;
+            word &= word - 1;
+            list[pos++] = (uint32_t)(w << 5) + (uint32_t)b;
         }
-        uint4 selfv = make_uint4(0, 0, 0, 0);
-        if (valid) {
-            selfv = *selfp;
-            acc_merge(acc, selfv);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // software pipeline over the batches of 16 rows: the row pointers and the own counter of the NEXT batch
+        // are requested before the gathers of the current one (the chain list -> row_ptr -> index -> bit ->
+        // gather -> state is what bounds this kernel, not bandwidth)
+        uint64_t nrow = 0, nbeg = 0, nend = 0;
+        uint4 nself = make_uint4(0, 0, 0, 0);
+        bool nvalid = (uint32_t)g < total;
+        if (nvalid) {
+            nrow = (uint64_t)list[g];
+            nbeg = p.row_ptr[nrow];
+            nend = p.row_ptr[nrow + 1];
+            nself = REAL ? p.rd[nrow * 4 + q] : p.part[(nrow - p.n_pad) * 4 + q];
         }
-        const uint4 accv = acc_value(acc);
-        const uint64_t bal = __ballot(valid && u4_ne(accv, selfv));
-        const bool changed = ((bal >> qshift) & 0xFull) != 0;
-        const uint32_t bit = 1u << (row & 31u);
-        if (REAL) {
-            const bool touched = ((__ballot(lane_act) >> qshift) & 0xFull) != 0;
-            cnt_rows += (valid && touched && q == 0);
-            const bool self_prev = valid && ((p.bits_rd[row >> 5] >> (row & 31u)) & 1u);
-            const bool kd = valid && ((p.kdirty[row >> 5] >> (row & 31u)) & 1u);
-            if (valid && (changed || self_prev)) p.wr[row * 4 + q] = accv; // lazy double buffer
-            if (changed && q == 0) {
-                atomicOr(&p.bits_wr[row >> 5], bit);
-                cnt_out += p.outdeg[row];
-            }
-            cnt_changed += __popc(pack16(bal));
-            if (valid && (changed || kd)) {
-                const uint64_t sz_old = p.size[row];
-                const uint64_t sz_new = changed ? hll_size_quad(accv, s_raw, s_bias, s_lc) : sz_old;
-                if (q == 0) {
-                    double ks = p.ksum[row], ke = p.kerr[row];
-                    const bool err_nz = kahan_update(ks, ke, sz_new, sz_old, p.t_plus_1);
-                    if (err_nz) {
-                        p.ksum[row] = ks;
-                        p.kerr[row] = ke;
-                    }
-                    if (changed) p.size[row] = sz_new;
-                    if (err_nz && !kd) atomicOr(&p.kdirty[row >> 5], bit);
-                    if (!err_nz && kd) atomicAnd(&p.kdirty[row >> 5], ~bit);
+        for (uint32_t base = 0; base < total; base += 16) {
+            const bool valid = nvalid;
+            const uint64_t row = nrow, beg = nbeg, end = nend;
+            uint4 selfv = nself;
+            {
+                const uint32_t li = base + 16 + (uint32_t)g;
+                nvalid = li < total;
+                nrow = nbeg = nend = 0;
+                nself = make_uint4(0, 0, 0, 0);
+                if (nvalid) {
+                    nrow = (uint64_t)list[li];
+                    nbeg = p.row_ptr[nrow];
+                    nend = p.row_ptr[nrow + 1];
+                    nself = REAL ? p.rd[nrow * 4 + q] : p.part[(nrow - p.n_pad) * 4 + q];
                 }
             }
-        } else {
-            if (changed) {
+            Acc acc;
+            acc_zero(acc);
+            bool lane_act = false;
+            if (beg < end) {
+                const uint32_t first = p.src[beg];
+                const uint4 *srcbase = (first >= p.n_pad) ? (const uint4 *)(p.part - p.n_pad * 4) : p.rd;
+                for (uint64_t e = beg; e < end; e += 4 * kU) { // 4 * kU sources per round: indices, bit tests, gathers
+                    uint32_t idx[kU];
+#pragma unroll
+                    for (int u = 0; u < kU; u++) {
+                        const uint64_t ee = e + 4 * u + q;
+                        idx[u] = (ee < end) ? p.src[ee] : kNone;
+                    }
+                    uint32_t wb[kU];
+#pragma unroll
+                    for (int u = 0; u < kU; u++) wb[u] = (idx[u] != kNone) ? p.bits_rd[idx[u] >> 5] : 0u;
+#pragma unroll
+                    for (int u = 0; u < kU; u++) {
+                        if (!((wb[u] >> (idx[u] & 31u)) & 1u)) idx[u] = kNone;
+                        lane_act |= (idx[u] != kNone);
+                    }
+                    uint4 r[kU][4];
+#pragma unroll
+                    for (int u = 0; u < kU; u++) {
+                        const uint32_t s0 = quad_bcast<0>(idx[u]), s1 = quad_bcast<1>(idx[u]);
+                        const uint32_t s2 = quad_bcast<2>(idx[u]), s3 = quad_bcast<3>(idx[u]);
+                        r[u][0] = r[u][1] = r[u][2] = r[u][3] = make_uint4(0, 0, 0, 0); // max with 0 = identity
+                        if (s0 != kNone) r[u][0] = srcbase[(uint64_t)s0 * 4 + q];
+                        if (s1 != kNone) r[u][1] = srcbase[(uint64_t)s1 * 4 + q];
+                        if (s2 != kNone) r[u][2] = srcbase[(uint64_t)s2 * 4 + q];
+                        if (s3 != kNone) r[u][3] = srcbase[(uint64_t)s3 * 4 + q];
+                    }
+#pragma unroll
+                    for (int u = 0; u < kU; u++) {
+#pragma unroll
+                        for (int j = 0; j < 4; j++) acc_merge(acc, r[u][j]);
+                    }
+                }
+            }
+            acc_merge(acc, selfv);
+            const uint4 accv = acc_value(acc);
+            const uint64_t bal = __ballot(valid && u4_ne(accv, selfv));
+            const bool changed = ((bal >> qshift) & 0xFull) != 0;
+            const uint32_t bit = 1u << (row & 31u);
+            if (REAL) {
+                const bool touched = ((__ballot(lane_act) >> qshift) & 0xFull) != 0;
+                cnt_rows += (valid && touched && q == 0);
+                const bool self_prev = valid && ((p.bits_rd[row >> 5] >> (row & 31u)) & 1u);
+                const bool kd = valid && ((p.kdirty[row >> 5] >> (row & 31u)) & 1u);
+                if (valid && (changed || self_prev)) p.wr[row * 4 + q] = accv; // lazy double buffer
+                if (changed && q == 0) {
+                    atomicOr(&p.bits_wr[row >> 5], bit);
+                    cnt_out += p.outdeg[row];
+                }
+                cnt_changed += __popc(pack16(bal));
+                if (valid && (changed || kd)) {
+                    const uint64_t sz_old = p.size[row];
+                    const uint64_t sz_new = changed ? hll_size_quad(accv, s_raw, s_bias, s_lc) : sz_old;
+                    if (q == 0) {
+                        double ks = p.ksum[row], ke = p.kerr[row];
+                        const bool err_nz = kahan_update(ks, ke, sz_new, sz_old, p.t_plus_1);
+                        if (err_nz) {
+                            p.ksum[row] = ks;
+                            p.kerr[row] = ke;
+                        }
+                        if (changed) p.size[row] = sz_new;
+                        if (err_nz && !kd) atomicOr(&p.kdirty[row >> 5], bit);
+                        if (!err_nz && kd) atomicAnd(&p.kdirty[row >> 5], ~bit);
+                    }
+                }
+            } else if (changed) {
                 p.part[(row - p.n_pad) * 4 + q] = accv;
-                if (q == 0) atomicOr((uint32_t *)&p.bits_rd[row >> 5], bit); // this pass' virtual changed bit
-            }
-            // the readers (normally exactly one parent) of the changed rows join their level's worklist
-            const bool pusher = changed && q == 0;
-            uint64_t pb = 0, pe = 0;
-            if (pusher) {
-                pb = sp.out_ptr[row];
-                pe = sp.out_ptr[row + 1];
-            }
-            while (__ballot(pb < pe)) {
-                const bool has = pb < pe;
-                sparse_push(sp, has, has ? sp.out_rows[pb] : 0u);
-                pb++;
+                if (q == 0) {
+                    atomicOr((uint32_t *)&p.bits_rd[row >> 5], bit); // this pass' virtual changed bit
+                    // the readers (normally exactly one parent) must look at this partial
+                    for (uint64_t k = sp.out_ptr[row]; k < sp.out_ptr[row + 1]; k++) touch_set(sp.touch, sp.out_rows[k]);
+                }
             }
         }
+        __builtin_amdgcn_wave_barrier(); // the list is rewritten in the next iteration
     }
     if (REAL) {
 #pragma unroll
@@ -820,133 +811,6 @@ __global__ __launch_bounds__(256) void sparse_rows_kernel(const SparseParams sp)
         }
         const unsigned long long v[4] = {cnt_changed, 0, cnt_rows, cnt_out};
         block_add_counters(p.counters, v, 0xDu);
-    }
-}
-
-// ---- push mode: the mid-tail passes ---------------------------------------------------------
-// Between "most sources changed" (dense pull) and "almost none did" (worklists) the bitmap frontier
-// pass read and bit-tested EVERY index to gather a few per cent of them.  Here the changed nodes push
-// instead: the transposed graph gives, for every changed node, the rows that read it and its position in
-// their lists; one atomic OR per (changed source, reader) pair sets that bit in the row's 64-bit mask
-// (rows have <= 64 sources).  The row sweep then reads 8 bytes per row, skips rows with an empty mask
-// and otherwise loads exactly the indices whose bits are set - no index streaming, no bit tests.  A
-// virtual row that changed ORs its bit into its parent's mask, so changes climb the chunk trees inside
-// the pass (levels are swept in order).  Row semantics (lazy double buffer, Kahan fixed points,
-// changed bits) are those of the frontier pass, so registers / Kahan state stay bit-identical.
-template <bool REAL>
-__global__ __launch_bounds__(256) void push_rows_kernel(const SparseParams sp)
-{
-    __shared__ double s_raw[REAL ? kTableLen : 1];
-    __shared__ double s_bias[REAL ? kTableLen : 1];
-    __shared__ uint8_t s_lc[68];
-    const PassParams &p = sp.p;
-    if (REAL) {
-        for (int i = threadIdx.x; i < kTableLen; i += 256) {
-            s_raw[i] = p.raw[i];
-            s_bias[i] = p.bias[i];
-        }
-        if (threadIdx.x < 65) s_lc[threadIdx.x] = p.lc[threadIdx.x];
-        __syncthreads();
-    }
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int g = lane >> 2, q = lane & 3, qshift = lane & ~3;
-    const uint64_t ntiles = (p.row_hi - p.row_lo + 63) >> 6;
-    unsigned long long cnt_changed = 0, cnt_active = 0, cnt_rows = 0, cnt_out = 0;
-    for (uint64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const uint64_t row16 = p.row_lo + (tile << 6) + ((uint64_t)wave << 4);
-        const uint64_t row = row16 + (uint64_t)g;
-        const bool valid = row < p.row_hi;
-        unsigned long long mk = valid ? sp.mask[row] : 0ull;
-        const uint32_t prev16 = REAL ? (uint32_t)((const uint16_t *)p.bits_rd)[row16 >> 4] : 0u;
-        const uint32_t kd16 = REAL ? (uint32_t)((const uint16_t *)p.kdirty)[row16 >> 4] : 0u;
-        const bool self_prev = (prev16 >> g) & 1u;
-        const bool kd = (kd16 >> g) & 1u;
-        const bool need = valid && (mk != 0 || (REAL && (self_prev || kd)));
-        const bool touched = mk != 0;
-        Acc acc;
-        acc_zero(acc);
-        uint4 selfv = make_uint4(0, 0, 0, 0);
-        const uint4 *selfp = REAL ? (p.rd + row * 4 + q) : (p.part + (row - p.n_pad) * 4 + q);
-        if (need) {
-            selfv = *selfp;
-            acc_merge(acc, selfv);
-        }
-        if (mk) {
-            if (q == 0) sp.mask[row] = 0; // consumed
-            const uint64_t beg = p.row_ptr[row];
-            const uint32_t first = p.src[beg];
-            const uint4 *base = (first >= p.n_pad) ? (const uint4 *)(p.part - p.n_pad * 4) : p.rd;
-            if (first < p.n_pad && q == 0) cnt_active += __popcll(mk);
-            while (mk) { // quad-uniform: up to four active positions per round, one index load per lane
-                int pos = -1;
-#pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    const int b = mk ? __ffsll((long long)mk) - 1 : -1;
-                    mk &= mk - 1; // 0 stays 0
-                    if (j == q) pos = b;
-                }
-                const uint32_t idx = (pos >= 0) ? p.src[beg + (uint64_t)pos] : kNone;
-                const uint32_t s0 = quad_bcast<0>(idx), s1 = quad_bcast<1>(idx);
-                const uint32_t s2 = quad_bcast<2>(idx), s3 = quad_bcast<3>(idx);
-                uint4 r0 = make_uint4(0, 0, 0, 0), r1 = r0, r2 = r0, r3 = r0;
-                if (s0 != kNone) r0 = base[(uint64_t)s0 * 4 + q];
-                if (s1 != kNone) r1 = base[(uint64_t)s1 * 4 + q];
-                if (s2 != kNone) r2 = base[(uint64_t)s2 * 4 + q];
-                if (s3 != kNone) r3 = base[(uint64_t)s3 * 4 + q];
-                acc_merge(acc, r0);
-                acc_merge(acc, r1);
-                acc_merge(acc, r2);
-                acc_merge(acc, r3);
-            }
-        }
-        const uint4 accv = acc_value(acc);
-        const uint64_t bal = __ballot(need && u4_ne(accv, selfv));
-        const bool changed = ((bal >> qshift) & 0xFull) != 0;
-        const uint32_t ch16 = pack16(bal);
-        if (REAL) {
-            cnt_rows += (touched && q == 0);
-            if (need && (changed || self_prev)) p.wr[row * 4 + q] = accv; // lazy double buffer
-            if (lane == 0 && row16 < p.row_hi) ((uint16_t *)p.bits_wr)[row16 >> 4] = (uint16_t)ch16;
-            cnt_changed += __popc(ch16);
-            if (changed && q == 0) cnt_out += p.outdeg[row];
-            bool err_nz = false;
-            if (need && (changed || kd)) {
-                const uint64_t sz_old = p.size[row];
-                const uint64_t sz_new = changed ? hll_size_quad(accv, s_raw, s_bias, s_lc) : sz_old;
-                if (q == 0) {
-                    double ks = p.ksum[row], ke = p.kerr[row];
-                    err_nz = kahan_update(ks, ke, sz_new, sz_old, p.t_plus_1);
-                    if (err_nz) {
-                        p.ksum[row] = ks;
-                        p.kerr[row] = ke;
-                    }
-                    if (changed) p.size[row] = sz_new;
-                }
-            }
-            const uint32_t nk16 = pack16(__ballot(err_nz));
-            if (lane == 0 && row16 < p.row_hi && (nk16 | kd16)) ((uint16_t *)p.kdirty)[row16 >> 4] = (uint16_t)nk16;
-        } else if (changed) {
-            p.part[(row - p.n_pad) * 4 + q] = accv;
-            if (q == 0) { // the reader(s) of this partial (one parent) see it as an active source
-                for (uint64_t k = sp.out_ptr[row]; k < sp.out_ptr[row + 1]; k++)
-                    atomicOr(&sp.mask[sp.out_rows[k]], 1ull << sp.out_pos[k]);
-            }
-        }
-    }
-    if (REAL) {
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-            cnt_out += __shfl_down(cnt_out, off);
-            cnt_active += __shfl_down(cnt_active, off);
-            cnt_rows += __shfl_down(cnt_rows, off);
-        }
-        const unsigned long long v[4] = {cnt_changed, cnt_active, cnt_rows, cnt_out};
-        block_add_counters(p.counters, v, 0xFu);
-    } else {
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) cnt_active += __shfl_down(cnt_active, off);
-        const unsigned long long v[4] = {0, cnt_active, 0, 0};
-        block_add_counters(p.counters, v, 0x2u);
     }
 }
 
@@ -970,8 +834,7 @@ __global__ __launch_bounds__(256) void transpose_count_kernel(const uint64_t *ro
     }
 }
 __global__ __launch_bounds__(256) void transpose_fill_kernel(const uint64_t *row_ptr, const uint32_t *src, uint64_t rows,
-                                                             const uint64_t *out_ptr, uint32_t *cursor, uint32_t *out_rows,
-                                                             uint8_t *out_pos)
+                                                             const uint64_t *out_ptr, uint32_t *cursor, uint32_t *out_rows)
 {
     const uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     const uint64_t nq = (uint64_t)gridDim.x * 64;
@@ -980,9 +843,7 @@ __global__ __launch_bounds__(256) void transpose_fill_kernel(const uint64_t *row
         const uint64_t b = row_ptr[row], e = row_ptr[row + 1];
         for (uint64_t k = b + q; k < e; k += 4) {
             const uint32_t s = src[k];
-            const uint64_t o = out_ptr[s] + atomicAdd(&cursor[s], 1u);
-            out_rows[o] = (uint32_t)row;
-            if (out_pos) out_pos[o] = (uint8_t)(k - b); // rows longer than 256 entries: push mode is off (hb_api.hip)
+            out_rows[out_ptr[s] + atomicAdd(&cursor[s], 1u)] = (uint32_t)row;
         }
     }
 }

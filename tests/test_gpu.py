@@ -128,11 +128,9 @@ VARIANTS = {
     "chunk4_multilevel": dict(chunk=4),
     "chunk16": dict(chunk=16, tune=(0, 1)),
     "no_frontier": dict(flags=_lib.HB_FLAG_NO_FRONTIER),
-    "frontier_always": dict(tune=(0, 0, 101)),  # push masks whenever possible (t > 0)
-    "bitmap_frontier_always": dict(flags=_lib.HB_FLAG_BITMAP_FRONTIER, tune=(0, 0, 101)),
-    "push_always_multilevel": dict(chunk=8, tune=(0, 0, 101)),
-    "push_banded_no_sparse_tail": dict(chunk=16, tune=(0, 0, 101, 6, 4, 0, 1000000)),
-    "push_small_direct_pass_stats": dict(chunk=32, flags=_lib.HB_FLAG_PASS_STATS, tune=(0, 0, 101, 5, 8, 8)),
+    "frontier_always": dict(tune=(0, 0, 101, 0, 0, 0, 1000000)),  # bitmap frontier whenever t > 0, never the sweep
+    "frontier_always_multilevel": dict(chunk=8, tune=(0, 0, 101, 0, 0, 0, 1000000)),
+    "sweep_small_direct_pass_stats": dict(chunk=32, flags=_lib.HB_FLAG_PASS_STATS, tune=(0, 0, 101, 5, 8, 8, 1)),
     "no_reorder_unroll4": dict(flags=_lib.HB_FLAG_NO_REORDER, tune=(0, 4)),
     "unfused": dict(flags=_lib.HB_FLAG_UNFUSED),
     "unfused_frontier_always": dict(flags=_lib.HB_FLAG_UNFUSED, tune=(0, 0, 101), chunk=8),
@@ -148,8 +146,8 @@ VARIANTS = {
 }
 
 
-EXPECT_MODES = {"frontier_always": {0, 3}, "bitmap_frontier_always": {0, 1}, "push_always_multilevel": {0, 3},
-                "sparse_always_multilevel": {0, 2}, "long_tail_default": {0, 3, 2}}
+EXPECT_MODES = {"frontier_always": {0, 1}, "frontier_always_multilevel": {0, 1}, "sparse_always_multilevel": {0, 2},
+                "long_tail_default": {0, 2}}
 VARIANTS["long_tail_default"] = dict()
 VARIANTS["long_tail_chunk8"] = dict(chunk=8)
 
@@ -180,10 +178,9 @@ def test_per_pass_state_matches_oracle(gpu_ctx_factory, variant):
             assert np.array_equal(ctx.sizes(), o.sizes()), t
             ps = ctx.pass_stats()[t]
             assert ps["changed"] == ost["changed"], t
-            if ps["mode"] == 3:  # push masks: one bit per (changed source, reader) pair = A_t, counted by popcount
-                assert ps["active_edges"] == ost["active_edges"], t
-                assert 0 < ps["touched"] <= ost["touched"] or ost["touched"] == 0, t
-            elif kw.get("flags", 0) & _lib.HB_FLAG_PASS_STATS:
+            if ps["mode"] != 0:  # node rows with >= 1 gathered source (a split row counts only if a partial changed)
+                assert ps["touched"] <= ost["touched"], t
+            if kw.get("flags", 0) & _lib.HB_FLAG_PASS_STATS:
                 if ps["mode"] == 1:  # counted edge by edge in the frontier kernel
                     assert ps["active_edges"] == ost["active_edges"], t
             else:  # A_t from the out-degree sum of the nodes that changed in pass t-1

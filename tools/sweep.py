@@ -35,7 +35,7 @@ def main():
             if ref is None:
                 ref = sig
             dense = [p for p in ps if p["mode"] == 0]
-            front = [p for p in ps if p["mode"] in (1, 3)]
+            front = [p for p in ps if p["mode"] == 1]
             sparse = [p for p in ps if p["mode"] == 2]
             print(json.dumps({
                 "spec": spec, "ms_loop": round(best["ms_loop"], 3), "gteps": round(g.m * best["passes"] / best["ms_loop"] / 1e6, 2),
