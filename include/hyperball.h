@@ -99,7 +99,8 @@ typedef struct hb_options {
                              *  [4] min sources of a chunk at a slice cut (8)
                              *  [5] largest row that is not split into chunks (chunk)
                              *  [6] sweep mode (touched rows only) when A_t * tune[6] < edges (10; 1 = whenever frontier)
-                             *  [7] reserved (hb_host_plan: owner slices)                          */
+                             *  [7] experiment: hottest counters staged in LDS by the level-1 dense launch (0 = off, <= 2048;
+                             *      measured slower); hb_host_plan: owner slices                */
 } hb_options;
 
 typedef struct hb_ctx hb_ctx;

@@ -480,9 +480,8 @@ int step_local(hb_ctx *c)
         sp.counts = c->d_sparse_counts;
         const uint64_t real_words = p.n_pad / 32;
         HB_HIP(hipMemsetAsync(c->d_sparse_counts, 0, 64 * sizeof(unsigned int), c->stream));
-        HB_HIP(hipMemsetAsync(c->d_bits[c->cur ^ 1], 0, c->bits_words * 4, c->stream));           // this pass' changed bits
-        if (c->bits_words > real_words)                                                             // this pass' virtual bits
-            HB_HIP(hipMemsetAsync(c->d_bits[c->cur] + real_words, 0, (c->bits_words - real_words) * 4, c->stream));
+        // no bitmap is cleared here: the sweep kernels rewrite every word of this pass' changed bits (node rows in
+        // bits_wr, virtual rows in the upper part of bits_rd) and keep the touch bitmap all-zero between passes
         const unsigned sblocks = (unsigned)std::min<uint64_t>(std::max<uint64_t>(real_words / 256, 1), (uint64_t)c->num_cu * 4);
         const unsigned wblocks = (unsigned)c->num_cu * 4;
         hipLaunchKernelGGL(hbk::sweep_collect_kernel, dim3(sblocks), dim3(256), 0, c->stream, sp);
@@ -512,7 +511,19 @@ int step_local(hb_ctx *c)
                 pp.xcd_lo[x] = p.xcd_begin[x];
                 pp.xcd_hi[x] = p.xcd_begin[x + 1];
             }
-            launch_pass(c, pp, false, frontier, false);
+            const uint32_t lds_tile = std::min<uint32_t>(c->opt.tune[7], 2048u); // experiment, see hub_lds_tile_kernel
+            if (l == 0 && !frontier && lds_tile && !(c->opt.flags & HB_FLAG_PASS_STATS) && !multi_rank(c)) {
+                const uint64_t ntiles = (pp.row_hi - pp.row_lo + 63) / 64;
+                const size_t lds = (size_t)lds_tile * 64;
+                const uint64_t per_cu = std::max<uint64_t>(1, std::min<uint64_t>(8, (160 * 1024) / (lds + 1024)));
+                uint64_t blocks = std::min<uint64_t>(ntiles, (uint64_t)c->num_cu * per_cu);
+                if (pp.xcd_map) blocks = std::max<uint64_t>((blocks + 7) / 8 * 8, 8);
+                if (lds > 48 * 1024)
+                    HB_HIP(hipFuncSetAttribute((const void *)hbk::hub_lds_tile_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                if (ntiles) hipLaunchKernelGGL(hbk::hub_lds_tile_kernel, dim3((unsigned)blocks), dim3(256), lds, c->stream, pp, lds_tile);
+            } else {
+                launch_pass(c, pp, false, frontier, false);
+            }
             if (l == 0) HB_HIP(hipEventRecord(c->ev[5], c->stream));
         }
         pp.xcd_map = 0;

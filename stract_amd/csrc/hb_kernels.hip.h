@@ -528,12 +528,14 @@ struct SweepParams {
 __device__ __forceinline__ void touch_set(uint32_t *touch, uint32_t r)
 {
     const uint32_t bit = 1u << (r & 31u);
-    // cheap pre-test (a stale 0 only costs a redundant atomic; bits are never cleared while being set)
-    if (!(__builtin_nontemporal_load(&touch[r >> 5]) & bit)) atomicOr(&touch[r >> 5], bit);
+    // pre-test at the L2 (device-coherent load: a row usually has several changed sources, only the first
+    // needs the atomic; a stale 0 would only cost a redundant one - bits are never cleared while being set)
+    if (!(__hip_atomic_load(&touch[r >> 5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & bit)) atomicOr(&touch[r >> 5], bit);
 }
 
 // one thread per 32 node rows: nodes that changed in the previous pass become seeds (their readers are
-// touched by sweep_expand_kernel); like Kahan-dirty nodes they are also revisited themselves.
+// touched by sweep_expand_kernel).  They and the Kahan-dirty nodes are also revisited themselves, on the
+// cheap path of sweep_rows_kernel<true>, which reads those two bitmaps next to the touch bitmap.
 __global__ __launch_bounds__(256) void sweep_collect_kernel(const SweepParams sp)
 {
     const uint64_t words = sp.p.n_pad >> 5;
@@ -541,12 +543,8 @@ __global__ __launch_bounds__(256) void sweep_collect_kernel(const SweepParams sp
     const uint64_t stride = (uint64_t)gridDim.x * 256;
     for (uint64_t w0 = (uint64_t)blockIdx.x * 256; w0 < words; w0 += stride) { // wave-uniform trip count
         const uint64_t w = w0 + threadIdx.x;
-        uint32_t ch = 0;
-        if (w < words) {
-            ch = sp.p.bits_rd[w];
-            const uint32_t both = ch | sp.p.kdirty[w];
-            if (both) sp.touch[w] = both; // first writer of these words in this pass (the bitmap is all-zero between passes)
-        }
+        const uint32_t ch_in = (w < words) ? sp.p.bits_rd[w] : 0u;
+        uint32_t ch = ch_in;
         // wave-aggregated reservation in the seed list
         const uint32_t nch = __popc(ch);
         uint32_t pch = nch; // inclusive prefix sum over the wave
@@ -641,16 +639,23 @@ __global__ __launch_bounds__(256) void sweep_expand_heavy_kernel(const SweepPara
     }
 }
 
-// the touched rows of [row_lo, row_hi) (multiples of 64), in ascending order, one quad each; REAL: node rows
-// (self = rd[row], fused estimator + Kahan), else virtual rows (self = part[row - n_pad]; a changed row sets
-// its changed bit of this pass and touches its readers)
+// the touched rows of [row_lo, row_hi) (multiples of 64), one quad each; REAL: node rows (self = rd[row], fused
+// estimator + Kahan), else virtual rows (self = part[row - n_pad]; a changed row touches its readers).
+// A wave-iteration takes 64 bitmap words as 16 groups of 4 consecutive words (128 rows) that lie nwaves groups
+// apart: touched rows cluster (the readers of late changers are cold chunks / low-degree rows, which the device
+// order keeps together), and contiguous 2048-row slabs gave a few waves all the work.  The wave OWNS the rows of
+// its words for the whole pass, so their changed / Kahan-dirty words are assembled in LDS and stored once - no
+// global atomics and no clearing of those bitmaps (every word of the range is rewritten).
 template <bool REAL>
-__global__ __launch_bounds__(256) void sweep_rows_kernel(const SweepParams sp)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void sweep_rows_kernel(const SweepParams sp)
 {
     __shared__ double s_raw[REAL ? kTableLen : 1];
     __shared__ double s_bias[REAL ? kTableLen : 1];
     __shared__ uint8_t s_lc[68];
-    __shared__ uint32_t s_rows[4][2048]; // per wave: the rows of its 64 bitmap words that are set
+    __shared__ uint16_t s_list[4][2048]; // per wave: (owner lane << 5 | bit) of the set bits of its 64 words
+    __shared__ uint32_t s_word[4][64];   // bitmap word index loaded by each lane
+    __shared__ uint32_t s_chw[4][64];    // changed bits of this pass, per owned word
+    __shared__ uint32_t s_kdw[4][64];    // Kahan-dirty bits, per owned word (REAL)
     constexpr int kU = 2;                // index quads per gather round
     const PassParams &p = sp.p;
     if (REAL) {
@@ -663,45 +668,72 @@ __global__ __launch_bounds__(256) void sweep_rows_kernel(const SweepParams sp)
     }
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int g = lane >> 2, q = lane & 3, qshift = lane & ~3;
-    uint32_t *list = s_rows[wv];
+    uint16_t *list = s_list[wv];
+    uint32_t *wordof = s_word[wv], *chw = s_chw[wv], *kdw = s_kdw[wv];
     const uint64_t w_lo = p.row_lo >> 5, w_hi = (p.row_hi + 31) >> 5;
     const uint64_t nwaves = (uint64_t)gridDim.x * 4, wid = (uint64_t)blockIdx.x * 4 + wv;
-    // A wave-iteration takes 64 bitmap words as 16 groups of 4 consecutive words (128 rows) that lie nwaves
-    // groups apart: touched rows cluster (the readers of late changers are cold chunks / low-degree rows, which
-    // the device order keeps together), and contiguous 2048-row slabs gave a few waves all the work.
     const uint64_t ngroups = (w_hi - w_lo + 3) >> 2;
     unsigned long long cnt_changed = 0, cnt_out = 0, cnt_rows = 0;
-    for (uint64_t g0 = 0; g0 < ngroups; g0 += 16 * nwaves) { // wave-uniform trip count
-        const uint64_t gi = g0 + (uint64_t)(lane >> 2) * nwaves + wid;
-        const uint64_t w = w_lo + gi * 4 + (uint64_t)(lane & 3);
-        uint32_t word = (gi < ngroups && w < w_hi) ? sp.touch[w] : 0u;
-        if (word) sp.touch[w] = 0; // consumed: the bitmap is all-zero again after the pass
-        const uint32_t cnt = __popc(word);
-        uint32_t incl = cnt;
+    auto wave_sync = [] {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
+    auto wave_scan = [&](uint32_t v, uint32_t &total) { // inclusive prefix sum over the wave
+        uint32_t incl = v;
 #pragma unroll
         for (int off = 1; off < 64; off <<= 1) {
             const uint32_t a = __shfl_up(incl, off);
             if (lane >= off) incl += a;
         }
-        const uint32_t total = __shfl(incl, 63);
-        if (total == 0) continue;
-        uint32_t pos = incl - cnt;
-        while (word) {
-            const int b = __ffs((int)word) - 1;
-            word &= word - 1;
-            list[pos++] = (uint32_t)(w << 5) + (uint32_t)b;
+        total = __shfl(incl, 63);
+        return incl;
+    };
+    for (uint64_t g0 = 0; g0 < ngroups; g0 += 16 * nwaves) { // wave-uniform trip count
+        const uint64_t gi = g0 + (uint64_t)(lane >> 2) * nwaves + wid;
+        const uint64_t w = w_lo + gi * 4 + (uint64_t)(lane & 3);
+        const bool in_range = gi < ngroups && w < w_hi;
+        uint32_t word = in_range ? sp.touch[w] : 0u;
+        if (word) sp.touch[w] = 0; // consumed: the bitmap is all-zero again after the pass
+        // node rows that no changed source reaches but that changed in the previous pass (lazy double buffer:
+        // their counter must be carried over to the other buffer) or whose Kahan state is still moving (the
+        // reference adds +0.0 to every node in every pass): cheap path below, no index or counter gathers
+        const uint32_t pw = (REAL && in_range) ? p.bits_rd[w] : 0u;
+        const uint32_t kw = (REAL && in_range) ? p.kdirty[w] : 0u;
+        uint32_t cheap = (pw | kw) & ~word;
+        uint32_t total = 0;
+        const uint32_t incl = wave_scan(__popc(word), total);
+        const bool any_cheap = REAL && __ballot(cheap != 0) != 0;
+        if (total == 0 && !any_cheap) {
+            // nothing to run: the owned words of this pass' changed bitmap still have to be (re)written
+            if (in_range) {
+                if (REAL) p.bits_wr[w] = 0;
+                else ((uint32_t *)p.bits_rd)[w] = 0;
+            }
+            continue;
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        wordof[lane] = (uint32_t)w;
+        chw[lane] = 0;
+        kdw[lane] = kw;
+        {
+            uint32_t pos = incl - __popc(word);
+            while (word) {
+                const int b = __ffs((int)word) - 1;
+                word &= word - 1;
+                list[pos++] = (uint16_t)((lane << 5) | b);
+            }
+        }
+        wave_sync();
         // software pipeline over the batches of 16 rows: the row pointers and the own counter of the NEXT batch
         // are requested before the gathers of the current one (the chain list -> row_ptr -> index -> bit ->
         // gather -> state is what bounds this kernel, not bandwidth)
         uint64_t nrow = 0, nbeg = 0, nend = 0;
+        uint32_t nent = 0;
         uint4 nself = make_uint4(0, 0, 0, 0);
         bool nvalid = (uint32_t)g < total;
         if (nvalid) {
-            nrow = (uint64_t)list[g];
+            nent = list[g];
+            nrow = ((uint64_t)wordof[nent >> 5] << 5) + (nent & 31u);
             nbeg = p.row_ptr[nrow];
             nend = p.row_ptr[nrow + 1];
             nself = REAL ? p.rd[nrow * 4 + q] : p.part[(nrow - p.n_pad) * 4 + q];
@@ -709,14 +741,17 @@ __global__ __launch_bounds__(256) void sweep_rows_kernel(const SweepParams sp)
         for (uint32_t base = 0; base < total; base += 16) {
             const bool valid = nvalid;
             const uint64_t row = nrow, beg = nbeg, end = nend;
-            uint4 selfv = nself;
+            const uint32_t ent = nent;
+            const uint4 selfv = nself;
             {
                 const uint32_t li = base + 16 + (uint32_t)g;
                 nvalid = li < total;
                 nrow = nbeg = nend = 0;
+                nent = 0;
                 nself = make_uint4(0, 0, 0, 0);
                 if (nvalid) {
-                    nrow = (uint64_t)list[li];
+                    nent = list[li];
+                    nrow = ((uint64_t)wordof[nent >> 5] << 5) + (nent & 31u);
                     nbeg = p.row_ptr[nrow];
                     nend = p.row_ptr[nrow + 1];
                     nself = REAL ? p.rd[nrow * 4 + q] : p.part[(nrow - p.n_pad) * 4 + q];
@@ -765,18 +800,15 @@ __global__ __launch_bounds__(256) void sweep_rows_kernel(const SweepParams sp)
             const uint4 accv = acc_value(acc);
             const uint64_t bal = __ballot(valid && u4_ne(accv, selfv));
             const bool changed = ((bal >> qshift) & 0xFull) != 0;
-            const uint32_t bit = 1u << (row & 31u);
+            const uint32_t owner = ent >> 5, bit = 1u << (ent & 31u);
+            if (changed && q == 0) atomicOr(&chw[owner], bit); // LDS
             if (REAL) {
                 const bool touched = ((__ballot(lane_act) >> qshift) & 0xFull) != 0;
                 cnt_rows += (valid && touched && q == 0);
                 const bool self_prev = valid && ((p.bits_rd[row >> 5] >> (row & 31u)) & 1u);
                 const bool kd = valid && ((p.kdirty[row >> 5] >> (row & 31u)) & 1u);
                 if (valid && (changed || self_prev)) p.wr[row * 4 + q] = accv; // lazy double buffer
-                if (changed && q == 0) {
-                    atomicOr(&p.bits_wr[row >> 5], bit);
-                    cnt_out += p.outdeg[row];
-                }
-                cnt_changed += __popc(pack16(bal));
+                if (changed && q == 0) cnt_out += p.outdeg[row];
                 if (valid && (changed || kd)) {
                     const uint64_t sz_old = p.size[row];
                     const uint64_t sz_new = changed ? hll_size_quad(accv, s_raw, s_bias, s_lc) : sz_old;
@@ -788,29 +820,148 @@ __global__ __launch_bounds__(256) void sweep_rows_kernel(const SweepParams sp)
                             p.kerr[row] = ke;
                         }
                         if (changed) p.size[row] = sz_new;
-                        if (err_nz && !kd) atomicOr(&p.kdirty[row >> 5], bit);
-                        if (!err_nz && kd) atomicAnd(&p.kdirty[row >> 5], ~bit);
+                        if (err_nz && !kd) atomicOr(&kdw[owner], bit);  // LDS
+                        if (!err_nz && kd) atomicAnd(&kdw[owner], ~bit); // LDS
                     }
                 }
             } else if (changed) {
                 p.part[(row - p.n_pad) * 4 + q] = accv;
-                if (q == 0) {
-                    atomicOr((uint32_t *)&p.bits_rd[row >> 5], bit); // this pass' virtual changed bit
-                    // the readers (normally exactly one parent) must look at this partial
+                if (q == 0) { // the readers (normally exactly one parent) must look at this partial
                     for (uint64_t k = sp.out_ptr[row]; k < sp.out_ptr[row + 1]; k++) touch_set(sp.touch, sp.out_rows[k]);
                 }
             }
         }
-        __builtin_amdgcn_wave_barrier(); // the list is rewritten in the next iteration
+        if (REAL && any_cheap) {
+            wave_sync(); // the list is rewritten
+            uint32_t total2 = 0;
+            const uint32_t incl2 = wave_scan(__popc(cheap), total2);
+            uint32_t pos2 = incl2 - __popc(cheap);
+            while (cheap) {
+                const int b = __ffs((int)cheap) - 1;
+                cheap &= cheap - 1;
+                list[pos2++] = (uint16_t)((lane << 5) | b);
+            }
+            wave_sync();
+            for (uint32_t base = 0; base < total2; base += 32) { // two rows per quad and round
+                uint64_t row2[2];
+                uint32_t ent2[2];
+                bool sp2[2], kd2[2];
+                uint4 cv[2];
+                double ks[2], ke[2];
+#pragma unroll
+                for (int j = 0; j < 2; j++) {
+                    const uint32_t li = base + 16 * j + (uint32_t)g;
+                    const bool v = li < total2;
+                    ent2[j] = v ? (uint32_t)list[li] : 0u;
+                    row2[j] = ((uint64_t)wordof[ent2[j] >> 5] << 5) + (ent2[j] & 31u);
+                    sp2[j] = v && ((p.bits_rd[row2[j] >> 5] >> (row2[j] & 31u)) & 1u);
+                    kd2[j] = v && ((p.kdirty[row2[j] >> 5] >> (row2[j] & 31u)) & 1u);
+                }
+#pragma unroll
+                for (int j = 0; j < 2; j++) {
+                    cv[j] = make_uint4(0, 0, 0, 0);
+                    ks[j] = ke[j] = 0.0;
+                    if (sp2[j]) cv[j] = p.rd[row2[j] * 4 + q];
+                    if (kd2[j] && q == 0) {
+                        ks[j] = p.ksum[row2[j]];
+                        ke[j] = p.kerr[row2[j]];
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < 2; j++) {
+                    if (sp2[j]) p.wr[row2[j] * 4 + q] = cv[j]; // unchanged: carried over to the other buffer
+                    if (kd2[j] && q == 0) {
+                        // update_centralities with size(new) == size(old): `+= 0.0` (harmonic.rs:159-176)
+                        const bool moved = kahan_update(ks[j], ke[j], 0, 0, p.t_plus_1);
+                        if (moved) {
+                            p.ksum[row2[j]] = ks[j];
+                            p.kerr[row2[j]] = ke[j];
+                        } else {
+                            atomicAnd(&kdw[ent2[j] >> 5], ~(1u << (ent2[j] & 31u))); // LDS
+                        }
+                    }
+                }
+            }
+        }
+        wave_sync();
+        // the owner lanes store the words of the bitmaps this wave owns
+        if (in_range) {
+            const uint32_t cw = chw[lane];
+            cnt_changed += __popc(cw);
+            if (REAL) {
+                p.bits_wr[w] = cw;
+                if (kdw[lane] != kw) p.kdirty[w] = kdw[lane];
+            } else {
+                ((uint32_t *)p.bits_rd)[w] = cw; // this pass' changed bits of the virtual rows
+            }
+        }
+        wave_sync(); // LDS arrays are rewritten in the next iteration
     }
     if (REAL) {
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) {
             cnt_out += __shfl_down(cnt_out, off);
             cnt_rows += __shfl_down(cnt_rows, off);
+            cnt_changed += __shfl_down(cnt_changed, off);
         }
         const unsigned long long v[4] = {cnt_changed, 0, cnt_rows, cnt_out};
         block_add_counters(p.counters, v, 0xDu);
+    }
+}
+
+// ---- experiment (north-star "LDS-staged counter tiles"; off by default, hb_options.tune[7]) -----------
+// Dense pull over the level-1 hub chunks with the `tile` hottest counters (device rows [0, tile)) staged in
+// LDS once per workgroup: gathers of those sources are served from LDS instead of L2.  Same results as
+// pass_kernel<false,false,false,false,4>; measured against it in profiles/r02*_lds_tile*.txt.
+__global__ __launch_bounds__(256) void hub_lds_tile_kernel(const PassParams p, uint32_t tile)
+{
+    extern __shared__ uint4 s_tile[]; // tile * 4 uint4
+    for (uint32_t i = threadIdx.x; i < tile * 4; i += 256) s_tile[i] = p.rd[i];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int g = lane >> 2, q = lane & 3;
+    uint64_t row_lo = p.row_lo, row_hi = p.row_hi, tile0 = blockIdx.x, tstride = gridDim.x;
+    if (p.xcd_map) {
+        const int x = blockIdx.x & 7;
+        row_lo = p.xcd_lo[x];
+        row_hi = p.xcd_hi[x];
+        tile0 = blockIdx.x >> 3;
+        tstride = gridDim.x >> 3;
+    }
+    const uint64_t ntiles = (row_hi - row_lo + 63) >> 6;
+    for (uint64_t t = tile0; t < ntiles; t += tstride) {
+        const uint64_t row = row_lo + (t << 6) + ((uint64_t)wave << 4) + (uint64_t)g;
+        if (row >= row_hi) continue;
+        const uint64_t beg = p.row_ptr[row], end = p.row_ptr[row + 1];
+        Acc acc;
+        acc_zero(acc);
+        if (beg < end) {
+            const uint32_t first = p.src[beg];
+            for (uint64_t e = beg; e < end; e += 16) {
+                uint32_t idx[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const uint64_t ee = e + 4 * u + q;
+                    idx[u] = (ee < end) ? p.src[ee] : first;
+                }
+                uint4 r[4][4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const uint32_t sv[4] = {quad_bcast<0>(idx[u]), quad_bcast<1>(idx[u]), quad_bcast<2>(idx[u]), quad_bcast<3>(idx[u])};
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        if (sv[j] < tile) r[u][j] = s_tile[sv[j] * 4 + q];
+                        else r[u][j] = p.rd[(uint64_t)sv[j] * 4 + q];
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+#pragma unroll
+                    for (int j = 0; j < 4; j++) acc_merge(acc, r[u][j]);
+                }
+            }
+        }
+        p.part[(row - p.n_pad) * 4 + q] = acc_value(acc); // dense: the partial is overwritten unread (see pass_kernel)
     }
 }
 

@@ -136,6 +136,7 @@ VARIANTS = {
     "unfused_frontier_always": dict(flags=_lib.HB_FLAG_UNFUSED, tune=(0, 0, 101), chunk=8),
     "pass_stats": dict(flags=_lib.HB_FLAG_PASS_STATS),
     "few_blocks": dict(tune=(1,)),
+    "lds_tile_experiment": dict(chunk=16, tune=(0, 0, 0, 6, 4, 0, 0, 256)),
     "sparse_always_multilevel": dict(chunk=8, tune=(0, 0, 101, 0, 0, 0, 1)),
     "sparse_always_banded": dict(chunk=16, tune=(0, 0, 101, 6, 4, 0, 1)),
     "no_sparse": dict(flags=_lib.HB_FLAG_NO_SPARSE),
