@@ -79,6 +79,8 @@ typedef struct hb_edge {
                                         owned counter slices per pass instead of an all-reduce          */
 #define HB_FLAG_HOST_INGEST   0x400u /* hb_load_edges: reduce the records on the host (hb_host.cpp) instead of
                                         on the GPU (hb_ingest.hip); same result                      */
+#define HB_FLAG_HOST_PLAN     0x800u /* build the device work layout on the host (hb_host.cpp) instead of on the GPU
+                                        (hb_plan.hip); same layout.  The destination partition always uses the host planner */
 #define HB_FLAG_RCCL_SELF     0x80u /* world_size == 1 but still create a 1-rank communicator and run
                                        the collectives (exercises the RCCL call path on one GPU)   */
 
@@ -241,8 +243,14 @@ int hb_debug_hll_size(hb_ctx *ctx, const uint8_t *regs, uint64_t count, uint64_t
  * Kahan state of its own rows only); out[0] covers all counters (every rank holds them after the collective). */
 int hb_debug_state_hash(hb_ctx *ctx, uint64_t out[2]);
 /* Reduced graph as the library sees it after ingest (ascending-NodeID indexing):
- * any pointer may be NULL; row_ptr has n+1 entries, src has m_eff. */
+ * any pointer may be NULL; row_ptr has n+1 entries, src has m_eff.  row_ptr / src are kept on the host only for
+ * graphs of up to 2^26 edges, or with HB_FLAG_HOST_PLAN (HB_ERR_LIMIT otherwise). */
 int hb_debug_copy_graph(hb_ctx *ctx, hb_u128 *ids, uint64_t *row_ptr, uint32_t *src);
+/* The device work layout of the loaded graph as it lies in HBM (same conventions as hb_host_plan: two-call
+ * pattern, sizes = {n_pad, nv, plan_src_len, levels}; order[n_pad], plan_row_ptr[n_pad+nv+1], plan_src[plan_src_len],
+ * level_begin[levels+1]).  The device planner must reproduce the host planner's layout entry for entry. */
+int hb_debug_copy_plan(hb_ctx *ctx, uint64_t sizes[4], uint32_t *order, uint64_t *plan_row_ptr, uint32_t *plan_src,
+                       uint64_t *level_begin);
 /* Emulates the collective of one pass between `count` logical ranks that live on ONE device
  * (contexts created with HB_FLAG_NO_RCCL; RCCL refuses two ranks on one device).
  *   phase 0, between hb_step_local and hb_step_finish of every context:

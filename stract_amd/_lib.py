@@ -26,6 +26,7 @@ HB_FLAG_RCCL_SELF = 0x80
 HB_FLAG_NO_SPARSE = 0x100
 HB_FLAG_DEST_PARTITION = 0x200
 HB_FLAG_HOST_INGEST = 0x400
+HB_FLAG_HOST_PLAN = 0x800
 
 # numpy views of the plain-data structs
 U128 = np.dtype([("lo", "<u8"), ("hi", "<u8")])
@@ -128,6 +129,7 @@ _SIGNATURES = [
     ("hb_debug_hll_size", ctypes.c_int, [_P, _P, _U64, _P]),
     ("hb_debug_state_hash", ctypes.c_int, [_P, _P]),
     ("hb_debug_copy_graph", ctypes.c_int, [_P, _P, _P, _P]),
+    ("hb_debug_copy_plan", ctypes.c_int, [_P, _P, _P, _P, _P, _P]),
     ("hb_debug_exchange", ctypes.c_int, [_P, ctypes.c_int, ctypes.c_int]),
     ("hb_step_local", ctypes.c_int, [_P]),
     ("hb_step_finish", ctypes.c_int, [_P, ctypes.POINTER(ctypes.c_int)]),
@@ -351,6 +353,18 @@ class Context:
         out = np.zeros(len(regs), dtype=np.uint64)
         self._check(self.lib.hb_debug_hll_size(self.h, _ptr(regs), len(regs), _ptr(out)))
         return out
+
+    def plan(self):
+        """The device work layout as it lies in HBM (hb_debug_copy_plan), same dict as host_plan()."""
+        sizes = np.zeros(4, dtype=np.uint64)
+        self._check(self.lib.hb_debug_copy_plan(self.h, _ptr(sizes), None, None, None, None))
+        n_pad, nv, slen, levels = (int(x) for x in sizes)
+        order = np.zeros(n_pad, dtype=np.uint32)
+        prp = np.zeros(n_pad + nv + 1, dtype=np.uint64)
+        psrc = np.zeros(slen, dtype=np.uint32)
+        lb = np.zeros(levels + 1, dtype=np.uint64)
+        self._check(self.lib.hb_debug_copy_plan(self.h, _ptr(sizes), _ptr(order), _ptr(prp), _ptr(psrc), _ptr(lb)))
+        return dict(order=order, row_ptr=prp, src=psrc, level_begin=lb, n_pad=n_pad, nv=nv)
 
     def graph(self):
         st = self.stats()

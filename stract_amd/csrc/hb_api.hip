@@ -201,8 +201,7 @@ int build_sparse_support(hb_ctx *c)
     c->sparse_ok = false;
     if (unfused(c) || multi_rank(c) || (c->opt.flags & HB_FLAG_NO_SPARSE) || p.n == 0) return HB_OK;
     const uint64_t rows_total = p.n_pad + p.nv;
-    const uint64_t entries = p.src.size();
-    c->plan_entries = entries;
+    const uint64_t entries = c->plan_entries;
     int rc;
     uint32_t *d_count = nullptr;
     if ((rc = dev_alloc(c, &c->d_out_ptr, rows_total + 1))) return rc;
@@ -218,18 +217,10 @@ int build_sparse_support(hb_ctx *c)
     hipLaunchKernelGGL(hbk::transpose_count_kernel, dim3(blocks), dim3(256), 0, c->stream, (const uint64_t *)c->d_row_ptr,
                        (const uint32_t *)c->d_src, rows_total, d_count);
     HB_HIP(hipGetLastError());
-    std::vector<uint32_t> cnt(rows_total);
-    HB_HIP(hipMemcpyAsync(cnt.data(), d_count, rows_total * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
-    HB_HIP(hipStreamSynchronize(c->stream));
-    std::vector<uint64_t> optr(rows_total + 1);
-    uint64_t acc = 0;
-    for (uint64_t i = 0; i < rows_total; i++) {
-        optr[i] = acc;
-        acc += cnt[i];
+    {   // out_ptr = exclusive prefix sums of the reader counts (rows_total + 1 entries), on the device
+        std::string e = device_offsets((void *)c->stream, d_count, rows_total, c->d_out_ptr, entries);
+        if (!e.empty()) return fail(c, HB_ERR_HIP, e);
     }
-    optr[rows_total] = acc;
-    if (acc != entries) return fail(c, HB_ERR_HIP, "transposed plan graph: entry count mismatch");
-    HB_HIP(hipMemcpyAsync(c->d_out_ptr, optr.data(), (rows_total + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
     HB_HIP(hipMemsetAsync(d_count, 0, rows_total * sizeof(uint32_t), c->stream));
     hipLaunchKernelGGL(hbk::transpose_fill_kernel, dim3(blocks), dim3(256), 0, c->stream, (const uint64_t *)c->d_row_ptr,
                        (const uint32_t *)c->d_src, rows_total, (const uint64_t *)c->d_out_ptr, d_count, c->d_out_rows);
@@ -240,7 +231,26 @@ int build_sparse_support(hb_ctx *c)
 }
 
 // ---- plan + upload (common tail of every load entry point) -------------------------------
-int plan_and_upload(hb_ctx *c)
+// The reduced graph arrives either on the host (c->g.row_ptr / c->g.src) or already on the device (csr, e.g. from
+// the GPU ingest).  Default: everything from here on happens on the device (hb_plan.hip); HB_FLAG_HOST_PLAN and the
+// destination partition use the host planner (hb_host.cpp), which produces the same layout.
+bool device_plan(const hb_ctx *c) { return !(c->opt.flags & HB_FLAG_HOST_PLAN) && !dest_mode(c); }
+
+__global__ __launch_bounds__(256) void idlow_kernel(const uint64_t *lo_by_sid, const uint32_t *order, uint64_t n_pad, uint64_t *idlow)
+{
+    const uint64_t d = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (d >= n_pad) return;
+    const uint32_t s = order[d];
+    idlow[d] = s == kNone ? 0ull : lo_by_sid[s];
+}
+
+void adopt(hb_ctx *c, void *p, size_t bytes) // a buffer allocated elsewhere becomes the context's
+{
+    c->allocs.push_back({p, bytes});
+    c->stats.device_bytes += bytes;
+}
+
+int plan_and_upload(hb_ctx *c, DeviceCsr *csr_in, uint64_t m_eff)
 {
     const uint64_t n = c->g.ids.size();
     c->loaded = false;
@@ -249,49 +259,99 @@ int plan_and_upload(hb_ctx *c)
     c->stats.n = n;
     c->stats.m_input = c->g.m_input;
     c->stats.m_unique = c->g.m_unique;
-    c->stats.m_eff = n ? c->g.row_ptr[n] : 0;
+    c->stats.m_eff = m_eff;
     double t0 = now_ms();
-    // global out-degree (device order must be identical on every rank)
-    std::vector<uint32_t> outdeg;
+    const bool on_device = device_plan(c);
+    // the input CSR on the device (uploaded here if it is not there yet); freed when the plan exists
+    struct InputCsr {
+        DeviceCsr d;
+        ~InputCsr()
+        {
+            if (d.d_row_ptr) (void)hipFree(d.d_row_ptr);
+            if (d.d_src) (void)hipFree(d.d_src);
+        }
+    } in;
+    if (csr_in) {
+        in.d = *csr_in;
+        *csr_in = DeviceCsr{};
+    }
+    if (!on_device && n && c->g.row_ptr.size() != n + 1) {
+        // host planner, but the reduced graph only exists on the device: bring it back
+        try {
+            c->g.row_ptr.resize(n + 1);
+            c->g.src.resize(m_eff);
+        } catch (const std::bad_alloc &) {
+            return fail(c, HB_ERR_NOMEM, "out of host memory for the reduced graph");
+        }
+        HB_HIP(hipMemcpyAsync(c->g.row_ptr.data(), in.d.d_row_ptr, (n + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+        if (m_eff) HB_HIP(hipMemcpyAsync(c->g.src.data(), in.d.d_src, m_eff * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+        HB_HIP(hipStreamSynchronize(c->stream));
+    }
+    if (n && !in.d.d_src) {
+        HB_HIP(hipMalloc((void **)&in.d.d_src, std::max<uint64_t>(m_eff, 1) * sizeof(uint32_t)));
+        if (m_eff) HB_HIP(hipMemcpyAsync(in.d.d_src, c->g.src.data(), m_eff * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+        if (on_device) {
+            HB_HIP(hipMalloc((void **)&in.d.d_row_ptr, (n + 1) * sizeof(uint64_t)));
+            HB_HIP(hipMemcpyAsync(in.d.d_row_ptr, c->g.row_ptr.data(), (n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
+        }
+        in.d.m = m_eff;
+    }
+    // global out-degree (the device order must be identical on every rank): histogram on the device
     bool reorder = !(c->opt.flags & HB_FLAG_NO_REORDER);
     if (multi_rank(c) && !c->comm) reorder = false; // logical ranks without a communicator
-    {
-        // out-degree histogram on the device (the host version is a scatter of m random increments)
-        const uint64_t m_local = n ? c->g.row_ptr[n] : 0;
-        outdeg.assign(n, 0);
-        if (n) {
-            uint32_t *d_deg = nullptr, *d_rawsrc = nullptr;
-            HB_HIP(hipMalloc((void **)&d_deg, n * sizeof(uint32_t)));
-            hipError_t e = hipMalloc((void **)&d_rawsrc, std::max<uint64_t>(m_local, 1) * sizeof(uint32_t));
-            ncclResult_t r = ncclSuccess;
-            if (e == hipSuccess) e = hipMemsetAsync(d_deg, 0, n * sizeof(uint32_t), c->stream);
-            if (e == hipSuccess && m_local)
-                e = hipMemcpyAsync(d_rawsrc, c->g.src.data(), m_local * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream);
-            if (e == hipSuccess && m_local) {
-                const unsigned blocks = (unsigned)std::min<uint64_t>((m_local + 255) / 256, (uint64_t)c->num_cu * 16);
-                hipLaunchKernelGGL(hbk::histogram_kernel, dim3(blocks), dim3(256), 0, c->stream, (const uint32_t *)d_rawsrc, m_local, d_deg);
-                e = hipGetLastError();
-            }
-            if (e == hipSuccess && c->comm) r = ncclAllReduce(d_deg, d_deg, n, ncclUint32, ncclSum, c->comm, c->stream);
-            if (e == hipSuccess && r == ncclSuccess)
-                e = hipMemcpyAsync(outdeg.data(), d_deg, n * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream);
-            if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-            (void)hipFree(d_deg);
-            if (d_rawsrc) (void)hipFree(d_rawsrc);
-            if (r != ncclSuccess) return fail(c, HB_ERR_RCCL, std::string("out-degree all-reduce: ") + ncclGetErrorString(r));
-            if (e != hipSuccess) return fail(c, HB_ERR_HIP, std::string("out-degree histogram: ") + hipGetErrorString(e));
+    struct Tmp {
+        uint32_t *d_deg = nullptr;
+        uint64_t *d_lo = nullptr;
+        ~Tmp()
+        {
+            if (d_deg) (void)hipFree(d_deg);
+            if (d_lo) (void)hipFree(d_lo);
         }
+    } tmp;
+    if (n) {
+        HB_HIP(hipMalloc((void **)&tmp.d_deg, n * sizeof(uint32_t)));
+        HB_HIP(hipMemsetAsync(tmp.d_deg, 0, n * sizeof(uint32_t), c->stream));
+        if (m_eff) {
+            const unsigned blocks = (unsigned)std::min<uint64_t>((m_eff + 255) / 256, (uint64_t)c->num_cu * 16);
+            hipLaunchKernelGGL(hbk::histogram_kernel, dim3(blocks), dim3(256), 0, c->stream, (const uint32_t *)in.d.d_src, m_eff, tmp.d_deg);
+            HB_HIP(hipGetLastError());
+        }
+        if (c->comm) HB_NCCL(ncclAllReduce(tmp.d_deg, tmp.d_deg, n, ncclUint32, ncclSum, c->comm, c->stream));
     }
     PlanTune pt = plan_tune(c->opt.chunk, c->opt.tune);
     pt.xcd_map = !(c->opt.flags & HB_FLAG_NO_XCD_MAP);
     if (dest_mode(c)) pt.world = (uint32_t)std::max(c->opt.world_size, 1);
-    std::string perr = build_plan(n, c->g.row_ptr.data(), c->g.src.data(), outdeg, reorder, pt, &c->plan);
-    if (!perr.empty()) return fail(c, perr.find("memory") != std::string::npos ? HB_ERR_NOMEM : HB_ERR_LIMIT, perr);
+    std::vector<uint32_t> outdeg; // host planner only
+    DevicePlan dp;
+    if (on_device) {
+        std::string perr = gpu_build_plan((void *)c->stream, n, in.d.d_row_ptr, in.d.d_src, tmp.d_deg, reorder, pt, &c->plan, &dp);
+        if (!perr.empty()) {
+            for (void *q : {(void *)dp.d_row_ptr, (void *)dp.d_src, (void *)dp.d_order, (void *)dp.d_dev_of, (void *)dp.d_outdeg_dev})
+                if (q) (void)hipFree(q);
+            (void)hipGetLastError();
+            return fail(c, perr.find("memory") != std::string::npos ? HB_ERR_NOMEM : (perr.find("exhausted") != std::string::npos ? HB_ERR_LIMIT : HB_ERR_HIP), perr);
+        }
+    } else {
+        outdeg.assign(n, 0);
+        if (n) {
+            HB_HIP(hipMemcpyAsync(outdeg.data(), tmp.d_deg, n * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+            HB_HIP(hipStreamSynchronize(c->stream));
+        }
+        static const uint64_t zero = 0;
+        std::string perr = build_plan(n, n ? c->g.row_ptr.data() : &zero, c->g.src.data(), outdeg, reorder, pt, &c->plan);
+        if (!perr.empty()) return fail(c, perr.find("memory") != std::string::npos ? HB_ERR_NOMEM : HB_ERR_LIMIT, perr);
+    }
+    // the input CSR is no longer needed on the device
+    if (in.d.d_row_ptr) (void)hipFree(in.d.d_row_ptr);
+    if (in.d.d_src) (void)hipFree(in.d.d_src);
+    in.d = DeviceCsr{};
     c->stats.ms_plan = now_ms() - t0;
     const Plan &p = c->plan;
-    c->stats.work_rows = p.n_pad + p.nv;
+    const uint64_t rows_total = p.n_pad + p.nv;
+    const uint64_t src_len = on_device ? dp.src_len : p.src.size();
+    c->plan_entries = src_len;
+    c->stats.work_rows = rows_total;
     c->stats.virtual_rows = p.nv;
-    c->stats.virtual_edges = p.row_ptr.empty() ? 0 : p.row_ptr[p.n_pad + p.nv] - p.row_ptr[p.n_pad];
     c->stats.levels = p.level_begin.size() > 1 ? p.level_begin.size() - 1 : 0;
     c->stats.level1_edges = p.level1_edges;
     c->stats.level1_rows = p.level1_rows;
@@ -300,11 +360,27 @@ int plan_and_upload(hb_ctx *c)
 
     // ---- device memory
     t0 = now_ms();
-    const uint64_t rows_total = p.n_pad + p.nv;
     c->bits_words = (rows_total + 31) / 32 + 2;
     int rc;
-    if ((rc = dev_alloc(c, &c->d_row_ptr, rows_total + 1))) return rc;
-    if ((rc = dev_alloc(c, &c->d_src, p.src.size() + 4))) return rc;
+    if (on_device) {
+        c->d_row_ptr = dp.d_row_ptr;
+        c->d_src = dp.d_src;
+        c->d_sid_of = dp.d_order;
+        c->d_dev_of = dp.d_dev_of;
+        c->d_outdeg = dp.d_outdeg_dev;
+        adopt(c, dp.d_row_ptr, (rows_total + 2) * sizeof(uint64_t));
+        adopt(c, dp.d_src, (src_len + 4) * sizeof(uint32_t));
+        adopt(c, dp.d_order, std::max<uint64_t>(p.n_pad, 64) * sizeof(uint32_t));
+        adopt(c, dp.d_dev_of, std::max<uint64_t>(n, 64) * sizeof(uint32_t));
+        adopt(c, dp.d_outdeg_dev, std::max<uint64_t>(p.n_pad, 64) * sizeof(uint32_t));
+        c->m_global = dp.m_global;
+    } else {
+        if ((rc = dev_alloc(c, &c->d_row_ptr, rows_total + 1))) return rc;
+        if ((rc = dev_alloc(c, &c->d_src, src_len + 4))) return rc;
+        if ((rc = dev_alloc(c, &c->d_dev_of, n))) return rc;
+        if ((rc = dev_alloc(c, &c->d_sid_of, p.n_pad))) return rc;
+        if ((rc = dev_alloc(c, &c->d_outdeg, p.n_pad))) return rc;
+    }
     if ((rc = dev_alloc(c, &c->d_regs[0], p.n_pad * 4))) return rc;
     if ((rc = dev_alloc(c, &c->d_regs[1], p.n_pad * 4))) return rc;
     if ((rc = dev_alloc(c, &c->d_part, p.nv * 4))) return rc;
@@ -319,9 +395,6 @@ int plan_and_upload(hb_ctx *c)
     if ((rc = dev_alloc(c, &c->d_kerr, p.n_pad))) return rc;
     if ((rc = dev_alloc(c, &c->d_size, p.n_pad))) return rc;
     if ((rc = dev_alloc(c, &c->d_idlow, p.n_pad))) return rc;
-    if ((rc = dev_alloc(c, &c->d_dev_of, n))) return rc;
-    if ((rc = dev_alloc(c, &c->d_sid_of, p.n_pad))) return rc;
-    if ((rc = dev_alloc(c, &c->d_outdeg, p.n_pad))) return rc;
     if ((rc = dev_alloc(c, &c->d_counters, ((size_t)c->max_passes + 1) * hbk::kCounterWords))) return rc;
     if ((rc = dev_alloc(c, &c->d_raw, HLL64_TABLE_LEN))) return rc;
     if ((rc = dev_alloc(c, &c->d_bias, HLL64_TABLE_LEN))) return rc;
@@ -338,32 +411,61 @@ int plan_and_upload(hb_ctx *c)
     HB_HIP(hipMemcpyAsync(c->d_raw, HLL64_RAW_ESTIMATE, sizeof(HLL64_RAW_ESTIMATE), hipMemcpyHostToDevice, c->stream));
     HB_HIP(hipMemcpyAsync(c->d_bias, HLL64_BIAS, sizeof(HLL64_BIAS), hipMemcpyHostToDevice, c->stream));
     HB_HIP(hipMemcpyAsync(c->d_lc, lc, 68, hipMemcpyHostToDevice, c->stream));
-    HB_HIP(hipMemcpyAsync(c->d_row_ptr, p.row_ptr.data(), (rows_total + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
-    if (!p.src.empty())
-        HB_HIP(hipMemcpyAsync(c->d_src, p.src.data(), p.src.size() * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
-    std::vector<uint64_t> idlow(p.n_pad, 0);
-    for (uint64_t d = 0; d < p.n_pad; d++)
-        if (p.order[d] != kNone) idlow[d] = c->g.ids[p.order[d]].lo;
-    HB_HIP(hipMemcpyAsync(c->d_idlow, idlow.data(), p.n_pad * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
-    if (p.n_pad)
-        HB_HIP(hipMemcpyAsync(c->d_sid_of, p.order.data(), p.n_pad * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
-    std::vector<uint32_t> outdeg_dev(p.n_pad, 0);
-    c->m_global = 0;
-    for (uint64_t d = 0; d < p.n_pad; d++)
-        if (p.order[d] != kNone) {
-            outdeg_dev[d] = outdeg[p.order[d]];
-            c->m_global += outdeg[p.order[d]];
-        }
-    if (p.n_pad)
-        HB_HIP(hipMemcpyAsync(c->d_outdeg, outdeg_dev.data(), p.n_pad * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
-    if (n) HB_HIP(hipMemcpyAsync(c->d_dev_of, p.dev_of.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
-    HB_HIP(hipStreamSynchronize(c->stream));
+    if (!on_device) {
+        c->stats.virtual_edges = p.row_ptr.empty() ? 0 : p.row_ptr[rows_total] - p.row_ptr[p.n_pad];
+        HB_HIP(hipMemcpyAsync(c->d_row_ptr, p.row_ptr.data(), (rows_total + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
+        if (!p.src.empty())
+            HB_HIP(hipMemcpyAsync(c->d_src, p.src.data(), p.src.size() * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+        if (p.n_pad)
+            HB_HIP(hipMemcpyAsync(c->d_sid_of, p.order.data(), p.n_pad * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+        std::vector<uint32_t> outdeg_dev(p.n_pad, 0);
+        c->m_global = 0;
+        for (uint64_t d = 0; d < p.n_pad; d++)
+            if (p.order[d] != kNone) {
+                outdeg_dev[d] = outdeg[p.order[d]];
+                c->m_global += outdeg[p.order[d]];
+            }
+        if (p.n_pad)
+            HB_HIP(hipMemcpyAsync(c->d_outdeg, outdeg_dev.data(), p.n_pad * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+        if (n) HB_HIP(hipMemcpyAsync(c->d_dev_of, p.dev_of.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+        HB_HIP(hipStreamSynchronize(c->stream)); // outdeg_dev goes out of scope
+    } else {
+        uint64_t ends[2] = {0, 0};
+        HB_HIP(hipMemcpyAsync(&ends[0], c->d_row_ptr + p.n_pad, sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+        HB_HIP(hipMemcpyAsync(&ends[1], c->d_row_ptr + rows_total, sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+        HB_HIP(hipStreamSynchronize(c->stream));
+        c->stats.virtual_edges = ends[1] - ends[0];
+    }
+    // low 64 bits of every NodeID in device order (HyperLogLog::add_u128 hashes only those, hyperloglog.rs:4398-4400)
+    if (n) {
+        std::vector<uint64_t> lo(n);
+        for (uint64_t s = 0; s < n; s++) lo[s] = c->g.ids[s].lo;
+        HB_HIP(hipMalloc((void **)&tmp.d_lo, n * sizeof(uint64_t)));
+        HB_HIP(hipMemcpyAsync(tmp.d_lo, lo.data(), n * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
+        hipLaunchKernelGGL(idlow_kernel, dim3((unsigned)((p.n_pad + 255) / 256)), dim3(256), 0, c->stream, (const uint64_t *)tmp.d_lo,
+                           (const uint32_t *)c->d_sid_of, p.n_pad, c->d_idlow);
+        HB_HIP(hipGetLastError());
+        HB_HIP(hipStreamSynchronize(c->stream));
+    }
     if ((rc = build_sparse_support(c))) return rc;
     // the plan's big host arrays are no longer needed
     decltype(c->plan.row_ptr)().swap(c->plan.row_ptr);
     decltype(c->plan.src)().swap(c->plan.src);
     c->stats.ms_h2d = now_ms() - t0;
     c->loaded = true;
+    return HB_OK;
+}
+
+// sid -> device row on the host (debug exports): downloaded on first use when the plan was built on the device
+int need_host_dev_of(hb_ctx *c)
+{
+    const uint64_t n = c->plan.n;
+    if (c->plan.dev_of.size() == n) return HB_OK;
+    c->plan.dev_of.resize(n);
+    if (n) {
+        HB_HIP(hipMemcpyAsync(c->plan.dev_of.data(), c->d_dev_of, n * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+        HB_HIP(hipStreamSynchronize(c->stream));
+    }
     return HB_OK;
 }
 
@@ -777,8 +879,10 @@ int hb_load_edges(hb_ctx *c, const hb_u128 *node_ids, uint64_t n, const hb_edge 
             const double need = 100.0 * (double)m + 48.0 * (double)((node_ids && n) ? n : 0) + 512e6;
             if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && need > (double)free_b) on_host = true;
         }
+        DeviceCsr csr;
+        const bool keep_on_device = !on_host && device_plan(c);
         std::string e = on_host ? ingest_edges(node_ids, n, edges, m, &c->g)
-                                : gpu_ingest_edges((void *)c->stream, node_ids, n, edges, m, &c->g);
+                                : gpu_ingest_edges((void *)c->stream, node_ids, n, edges, m, &c->g, keep_on_device ? &csr : nullptr);
         if (!on_host && !e.empty() && (e.find("out of memory") != std::string::npos || e.find("OutOfMemory") != std::string::npos)) {
             (void)hipGetLastError(); // clear the sticky allocation error
             e = ingest_edges(node_ids, n, edges, m, &c->g);
@@ -786,9 +890,13 @@ int hb_load_edges(hb_ctx *c, const hb_u128 *node_ids, uint64_t n, const hb_edge 
         if (!e.empty())
             return fail(c, e.find("memory") != std::string::npos ? HB_ERR_NOMEM : (e.find("hip") != std::string::npos ? HB_ERR_HIP : HB_ERR_LIMIT), e);
         if (dest_mode(c)) keep_owned_rows(&c->g, (uint64_t)std::max(c->opt.world_size, 1), (uint64_t)c->opt.rank);
+        const uint64_t nn = c->g.ids.size();
+        const uint64_t m_eff = csr.d_row_ptr ? csr.m : (nn && c->g.row_ptr.size() == nn + 1 ? c->g.row_ptr[nn] : 0);
         c->stats.ms_ingest = now_ms() - t0;
         double ing = c->stats.ms_ingest;
-        rc = plan_and_upload(c);
+        rc = plan_and_upload(c, csr.d_row_ptr ? &csr : nullptr, m_eff);
+        if (csr.d_row_ptr) (void)hipFree(csr.d_row_ptr); // only if plan_and_upload bailed out before taking them
+        if (csr.d_src) (void)hipFree(csr.d_src);
         c->stats.ms_ingest = ing;
         return rc;
     });
@@ -826,19 +934,43 @@ int hb_load_dense(hb_ctx *c, const hb_u128 *sorted_ids, uint64_t n, const uint64
         double t0 = now_ms();
         std::string e = check_dense(sorted_ids, n, row_ptr, src, m_eff);
         if (!e.empty()) return fail(c, e.find("too many") != std::string::npos ? HB_ERR_LIMIT : HB_ERR_INVALID, e);
+        const bool on_device = device_plan(c);
+        const bool keep_host = !on_device || m_eff <= kKeepHostGraph; // host copies: host planner, hb_debug_copy_graph
         try {
             c->g.ids.assign(sorted_ids, sorted_ids + n);
-            c->g.row_ptr.assign(row_ptr, row_ptr + n + 1);
-            if (n == 0) c->g.row_ptr.assign(1, 0);
-            c->g.src.assign(src, src + m_eff);
+            if (keep_host) {
+                c->g.row_ptr.assign(row_ptr, row_ptr + n + 1);
+                if (n == 0) c->g.row_ptr.assign(1, 0);
+                c->g.src.assign(src, src + m_eff);
+            } else {
+                std::vector<uint64_t>().swap(c->g.row_ptr);
+                std::vector<uint32_t>().swap(c->g.src);
+            }
         } catch (const std::bad_alloc &) {
             return fail(c, HB_ERR_NOMEM, "out of host memory copying the graph");
         }
         c->g.m_input = m_eff;
         c->g.m_unique = m_eff;
         if (dest_mode(c)) keep_owned_rows(&c->g, (uint64_t)std::max(c->opt.world_size, 1), (uint64_t)c->opt.rank);
+        DeviceCsr csr;
+        if (on_device && n) { // straight from the caller's arrays to the device: no host copy of a multi-GB CSR
+            HB_HIP(hipMalloc((void **)&csr.d_row_ptr, (n + 1) * sizeof(uint64_t)));
+            hipError_t he = hipMalloc((void **)&csr.d_src, std::max<uint64_t>(m_eff, 1) * sizeof(uint32_t));
+            if (he == hipSuccess) he = hipMemcpyAsync(csr.d_row_ptr, row_ptr, (n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream);
+            if (he == hipSuccess && m_eff) he = hipMemcpyAsync(csr.d_src, src, m_eff * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream);
+            if (he == hipSuccess) he = hipStreamSynchronize(c->stream);
+            if (he != hipSuccess) {
+                (void)hipFree(csr.d_row_ptr);
+                if (csr.d_src) (void)hipFree(csr.d_src);
+                return fail(c, he == hipErrorOutOfMemory ? HB_ERR_NOMEM : HB_ERR_HIP, std::string("uploading the graph: ") + hipGetErrorString(he));
+            }
+            csr.m = m_eff;
+        }
+        const uint64_t m_local = (dest_mode(c) && n) ? c->g.row_ptr[n] : m_eff;
         double ing = now_ms() - t0;
-        rc = plan_and_upload(c);
+        rc = plan_and_upload(c, csr.d_row_ptr ? &csr : nullptr, m_local);
+        if (csr.d_row_ptr) (void)hipFree(csr.d_row_ptr);
+        if (csr.d_src) (void)hipFree(csr.d_src);
         c->stats.ms_ingest = ing;
         return rc;
     });
@@ -1067,6 +1199,7 @@ int hb_debug_copy_kahan(hb_ctx *c, double *sum, double *err)
         if (!c->begun) return fail(c, HB_ERR_INVALID, "call hb_begin first");
         int rc = set_device(c);
         if (rc) return rc;
+        if ((rc = need_host_dev_of(c))) return rc;
         const Plan &p = c->plan;
         std::vector<double> tmp(p.n_pad ? p.n_pad : 1);
         for (int k = 0; k < 2; k++) {
@@ -1087,6 +1220,7 @@ int hb_debug_copy_sizes(hb_ctx *c, uint64_t *out)
         if (!c->begun) return fail(c, HB_ERR_INVALID, "call hb_begin first");
         int rc = set_device(c);
         if (rc) return rc;
+        if ((rc = need_host_dev_of(c))) return rc;
         const Plan &p = c->plan;
         if (!p.n_pad) return HB_OK;
         std::vector<uint64_t> tmp(p.n_pad);
@@ -1168,9 +1302,34 @@ int hb_debug_copy_graph(hb_ctx *c, hb_u128 *ids, uint64_t *row_ptr, uint32_t *sr
         if (!c) return HB_ERR_INVALID;
         if (!c->loaded) return fail(c, HB_ERR_INVALID, "no graph loaded");
         const uint64_t n = c->g.ids.size();
+        if ((row_ptr || src) && c->g.row_ptr.size() != n + 1)
+            return fail(c, HB_ERR_LIMIT, "the reduced graph is kept on the host only up to 2^26 edges (or with HB_FLAG_HOST_PLAN)");
         if (ids && n) std::memcpy(ids, c->g.ids.data(), n * sizeof(hb_u128));
         if (row_ptr) std::memcpy(row_ptr, c->g.row_ptr.data(), (n + 1) * sizeof(uint64_t));
         if (src && !c->g.src.empty()) std::memcpy(src, c->g.src.data(), c->g.src.size() * sizeof(uint32_t));
+        return HB_OK;
+    });
+}
+
+int hb_debug_copy_plan(hb_ctx *c, uint64_t sizes[4], uint32_t *order, uint64_t *plan_row_ptr, uint32_t *plan_src, uint64_t *level_begin)
+{
+    return guarded(c, [&]() -> int {
+        if (!c || !sizes) return HB_ERR_INVALID;
+        if (!c->loaded) return fail(c, HB_ERR_INVALID, "no graph loaded");
+        int rc = set_device(c);
+        if (rc) return rc;
+        const Plan &p = c->plan;
+        const uint64_t rows_total = p.n_pad + p.nv;
+        sizes[0] = p.n_pad;
+        sizes[1] = p.nv;
+        sizes[2] = c->plan_entries;
+        sizes[3] = p.level_begin.size() ? p.level_begin.size() - 1 : 0;
+        if (order && p.n_pad) HB_HIP(hipMemcpyAsync(order, c->d_sid_of, p.n_pad * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+        if (plan_row_ptr) HB_HIP(hipMemcpyAsync(plan_row_ptr, c->d_row_ptr, (rows_total + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+        if (plan_src && c->plan_entries)
+            HB_HIP(hipMemcpyAsync(plan_src, c->d_src, c->plan_entries * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+        HB_HIP(hipStreamSynchronize(c->stream));
+        if (level_begin) std::memcpy(level_begin, p.level_begin.data(), p.level_begin.size() * sizeof(uint64_t));
         return HB_OK;
     });
 }

@@ -456,24 +456,25 @@ std::string build_plan(uint64_t n, const uint64_t *row_ptr, const uint32_t *src,
             return chunks[a].len > chunks[b2].len;
         });
         if (groups > 1) {
-            uint64_t load[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-            for (size_t k = 0; k < chunks.size(); k++) {
+            // warm-slice chunks are pinned (slice mod 8); the flexible ones - hot (slice 0: every L2 holds it) and
+            // cold (no reuse to protect) - level the groups: group x gets the share Q_x / sum(Q) of EACH flexible
+            // class, Q_x = what it lacks to the mean load, as one contiguous range of the class in (slice, longer
+            // first) order.  Prefix sums and eight thresholds per class: the same rule runs on the device
+            // (hb_plan.hip) with scans instead of this loop.
+            XcdQuota quota;
+            for (size_t k = 0; k < chunks.size(); k++) quota.add(chunks[k].key, chunks[k].len, kWarmSlices);
+            quota.finish();
+            uint64_t prefix[2] = {0, 0}; // running load of the hot / cold class in corder order
+            for (size_t r = 0; r < corder.size(); r++) {
+                const uint32_t k = corder[r];
                 const uint32_t key = chunks[k].key;
                 if (key >= 1 && key <= kWarmSlices) {
                     grp[k] = (uint8_t)(key & 7u);
-                    load[grp[k]] += chunks[k].len + 4; // +4: per-row overhead in gather units
+                } else {
+                    const int cls = key == 0 ? 0 : 1;
+                    grp[k] = (uint8_t)quota.group_of(cls, prefix[cls]);
+                    prefix[cls] += chunks[k].len + 4; // +4: per-row overhead in gather units
                 }
-            }
-            // the flexible chunks, coldest first so that the hot ones (cheap: L2 hits) settle the remainder
-            for (size_t r = corder.size(); r-- > 0;) {
-                const uint32_t k = corder[r];
-                const uint32_t key = chunks[k].key;
-                if (key >= 1 && key <= kWarmSlices) continue;
-                int best = 0;
-                for (int x = 1; x < 8; x++)
-                    if (load[x] < load[best]) best = x;
-                grp[k] = (uint8_t)best;
-                load[best] += chunks[k].len + 4;
             }
             HB_STABLE_SORT_CMP(corder.begin(), corder.end(), [&](uint32_t a, uint32_t b2) { return grp[a] < grp[b2]; });
         }

@@ -166,8 +166,9 @@ unsigned grid_for(uint64_t count) { return (unsigned)((count + 255) / 256); }
 namespace hb {
 
 std::string gpu_ingest_edges(void *stream_v, const hb_u128 *node_ids, uint64_t n_in, const hb_edge *edges, uint64_t m,
-                             DenseGraph *out)
+                             DenseGraph *out, DeviceCsr *keep)
 {
+    if (keep) *keep = DeviceCsr{};
     hipStream_t stream = (hipStream_t)stream_v;
     out->ids.clear();
     out->row_ptr.clear();
@@ -340,15 +341,31 @@ std::string gpu_ingest_edges(void *stream_v, const hb_u128 *node_ids, uint64_t n
     }
     IG_HIP(hipStreamSynchronize(stream));
     for (int s = 0; s < 64; s++) out->m_unique += h_counts[s];
-    try {
-        out->src.resize(m_eff);
-    } catch (const std::bad_alloc &) {
-        return "out of host memory for the edge set";
+    const bool to_host = !keep || m_eff <= kKeepHostGraph;
+    if (to_host) {
+        try {
+            out->src.resize(m_eff);
+        } catch (const std::bad_alloc &) {
+            return "out of host memory for the edge set";
+        }
+        IG_HIP(hipMemcpyAsync(out->row_ptr.data(), d_row_ptr, (n + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost, stream));
+        if (m_eff) IG_HIP(hipMemcpyAsync(out->src.data(), d_src, m_eff * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+        IG_HIP(hipStreamSynchronize(stream));
+        if (out->row_ptr[n] != m_eff) return "gpu ingest: row pointer / edge count mismatch";
+    } else {
+        std::vector<uint64_t>().swap(out->row_ptr); // the reduced graph exists on the device only
     }
-    IG_HIP(hipMemcpyAsync(out->row_ptr.data(), d_row_ptr, (n + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost, stream));
-    if (m_eff) IG_HIP(hipMemcpyAsync(out->src.data(), d_src, m_eff * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
-    IG_HIP(hipStreamSynchronize(stream));
-    if (out->row_ptr[n] != m_eff) return "gpu ingest: row pointer / edge count mismatch";
+    if (keep) { // hand the device CSR to the caller (the device planner continues from it)
+        uint64_t last = 0;
+        IG_HIP(hipMemcpyAsync(&last, d_row_ptr + n, sizeof(uint64_t), hipMemcpyDeviceToHost, stream));
+        IG_HIP(hipStreamSynchronize(stream));
+        if (last != m_eff) return "gpu ingest: row pointer / edge count mismatch";
+        for (auto &q : mem.ptrs)
+            if (q == (void *)d_row_ptr || q == (void *)d_src) q = nullptr; // not freed by ~DevMem
+        keep->d_row_ptr = d_row_ptr;
+        keep->d_src = d_src;
+        keep->m = m_eff;
+    }
     return "";
 }
 

@@ -3,6 +3,8 @@
 #define HB_INTERNAL_H
 
 #include <cstdint>
+#include <cstdio>
+#include <cstdlib>
 #include <string>
 #include <vector>
 
@@ -76,6 +78,56 @@ struct Plan {
     uint64_t rows_with_in_edges = 0; // nodes with in-degree > 0
 };
 
+// XCD-group quotas of the flexible (hot / cold) level-1 chunks; shared by the host planner (hb_host.cpp) and the
+// device planner (hb_plan.hip), which must produce identical plans.  Integer arithmetic only.
+struct XcdQuota {
+    uint64_t warm[8] = {0, 0, 0, 0, 0, 0, 0, 0}; // load of the pinned warm-slice chunks per group
+    uint64_t flex[2] = {0, 0};                   // total load of the hot (0) / cold (1) class
+    uint64_t bound[2][8];                        // class prefix load at which group x starts
+    static constexpr uint64_t load_of(uint32_t len) { return (uint64_t)len + 4; } // +4: per-row overhead in gather units
+    void add(uint32_t key, uint32_t len, uint32_t warm_slices)
+    {
+        if (key >= 1 && key <= warm_slices) warm[key & 7u] += load_of(len);
+        else flex[key == 0 ? 0 : 1] += load_of(len);
+    }
+    void finish()
+    {
+        uint64_t total = flex[0] + flex[1];
+        for (int x = 0; x < 8; x++) total += warm[x];
+        const uint64_t target = (total + 7) / 8;
+        uint64_t q[8], sq = 0;
+        for (int x = 0; x < 8; x++) {
+            q[x] = target > warm[x] ? target - warm[x] : 0;
+            sq += q[x];
+        }
+        if (sq == 0) {
+            for (int x = 0; x < 8; x++) q[x] = 1;
+            sq = 8;
+        }
+        for (int c = 0; c < 2; c++) {
+            uint64_t cum = 0;
+            for (int x = 0; x < 8; x++) {
+                bound[c][x] = (uint64_t)(((unsigned __int128)cum * flex[c]) / sq);
+                cum += q[x];
+            }
+        }
+    }
+    // The class (in slice / longer-first order) is cut into kStripes stripes of equal load and EVERY stripe is
+    // shared out by the quotas, so that each group gets long and short chunks alike (contiguous ranges gave one
+    // group all the short chunks, whose per-row overhead is higher than the load model says).
+    static constexpr uint64_t kStripes = 64;
+    uint64_t stripe(int cls) const { return flex[cls] / kStripes ? flex[cls] / kStripes : 1; }
+    // group of the flexible chunk whose class-prefix load (exclusive) is `prefix`
+    int group_of(int cls, uint64_t prefix) const
+    {
+        const uint64_t scaled = (prefix % stripe(cls)) * kStripes;
+        int gsel = 0;
+        for (int x = 1; x < 8; x++)
+            if (bound[cls][x] <= scaled) gsel = x;
+        return gsel;
+    }
+};
+
 // Planner knobs (hb_options.chunk / tune[3..5]).
 struct PlanTune {
     uint32_t chunk = kDefaultChunk; // max sources per work row
@@ -94,8 +146,11 @@ std::string ingest_edges(const hb_u128 *node_ids, uint64_t n, const hb_edge *edg
                          DenseGraph *out);
 void keep_owned_rows(DenseGraph *g, uint64_t world, uint64_t rank);
 // --- hb_ingest.hip: the same reduction on the GPU (stream = hipStream_t); identical output
+// keep != NULL: the CSR stays on the device (returned in *keep, owned by the caller) and out->row_ptr / out->src
+// are only filled for small graphs (m_eff <= kKeepHostGraph, for hb_debug_copy_graph)
 std::string gpu_ingest_edges(void *stream, const hb_u128 *node_ids, uint64_t n, const hb_edge *edges, uint64_t m,
-                             DenseGraph *out);
+                             DenseGraph *out, struct DeviceCsr *keep = nullptr);
+constexpr uint64_t kKeepHostGraph = 1ull << 26;
 std::string check_dense(const hb_u128 *sorted_ids, uint64_t n, const uint64_t *row_ptr,
                         const uint32_t *src, uint64_t m);
 // out_degree[sid] over the local edges.
@@ -111,6 +166,30 @@ std::string build_plan(uint64_t n, const uint64_t *row_ptr, const uint32_t *src,
 // host libm; returns false if some value sits too close to an integer/threshold to be
 // libm-independent.
 bool build_lc_table(uint8_t lc[68]);
+
+// --- hb_plan.hip: the same plan built on the device ----------------------------------------------------------
+// A CSR by destination that lives in device memory (sid indexing), e.g. the output of the GPU ingest.
+struct DeviceCsr {
+    uint64_t *d_row_ptr = nullptr; // n + 1
+    uint32_t *d_src = nullptr;     // m
+    uint64_t m = 0;
+};
+// Device buffers of a finished plan (hipMalloc'ed; the caller owns them).
+struct DevicePlan {
+    uint64_t *d_row_ptr = nullptr; // n_pad + nv + 1
+    uint32_t *d_src = nullptr;     // src_len (+ 4 slack)
+    uint64_t src_len = 0;
+    uint32_t *d_order = nullptr;      // n_pad: device row -> sid, kNone = padding row
+    uint32_t *d_dev_of = nullptr;     // n: sid -> device row
+    uint32_t *d_outdeg_dev = nullptr; // n_pad: (global) out-degree per device row
+    uint64_t m_global = 0;            // sum of the out-degrees
+};
+// Fills the host-side meta data of `plan` (sizes, level_begin, xcd_begin, statistics; its big vectors stay empty) and
+// `out`.  d_outdeg_sid: global out-degree per sid.  Must produce exactly build_plan()'s layout.
+// d_offsets[i] = sum of d_counts[0 .. i), i = 0 .. count; fails unless the total equals `expect`
+std::string device_offsets(void *stream, uint32_t *d_counts, uint64_t count, uint64_t *d_offsets, uint64_t expect);
+std::string gpu_build_plan(void *stream, uint64_t n, const uint64_t *d_row_ptr, const uint32_t *d_src, const uint32_t *d_outdeg_sid,
+                           bool reorder, const PlanTune &tune, Plan *plan, DevicePlan *out);
 
 double now_ms();
 

@@ -136,6 +136,8 @@ VARIANTS = {
     "unfused_frontier_always": dict(flags=_lib.HB_FLAG_UNFUSED, tune=(0, 0, 101), chunk=8),
     "pass_stats": dict(flags=_lib.HB_FLAG_PASS_STATS),
     "few_blocks": dict(tune=(1,)),
+    "host_plan": dict(flags=_lib.HB_FLAG_HOST_PLAN),
+    "host_plan_chunk8_sweep": dict(flags=_lib.HB_FLAG_HOST_PLAN, chunk=8, tune=(0, 0, 101, 0, 0, 0, 1)),
     "lds_tile_experiment": dict(chunk=16, tune=(0, 0, 0, 6, 4, 0, 0, 256)),
     "sparse_always_multilevel": dict(chunk=8, tune=(0, 0, 101, 0, 0, 0, 1)),
     "sparse_always_banded": dict(chunk=16, tune=(0, 0, 101, 6, 4, 0, 1)),
@@ -304,6 +306,35 @@ def test_randomized_graphs_and_knobs(gpu_ctx_factory):
             assert np.array_equal(gvals.view(np.uint64), vals[keep].view(np.uint64)), what
             if len(ids):
                 assert np.array_equal(ctx.registers(), o.registers()), what
+
+
+# ---- device planner ------------------------------------------------------------------------------
+def test_device_plan_equals_host_plan(gpu_ctx_factory):
+    """hb_plan.hip (rocPRIM sorts / scans on the device) must reproduce build_plan() of hb_host.cpp entry for entry:
+    device order, work-row offsets, every source list (hub chunk trees, slice cuts, XCD groups), level boundaries."""
+    graphs_ = [synth.RmatGraph(13, 60_000), synth.RmatGraph(12, 30_000, tail=(300, 800, 10)), synth.RmatGraph(15, 400_000)]
+    star = graphs.dense_from_tuples([(i, 1, 0) for i in range(2, 3002)] + [(5000 + i, 5001 + i, 0) for i in range(300)] + [(1, 5000, 0)])
+    knobs = [dict(), dict(chunk=4), dict(chunk=8, tune=(0, 0, 0, 4, 2)), dict(chunk=16, tune=(0, 0, 0, 6, 4)),
+             dict(flags=_lib.HB_FLAG_NO_XCD_MAP, chunk=16, tune=(0, 0, 0, 6, 4)), dict(flags=_lib.HB_FLAG_NO_REORDER),
+             dict(chunk=32, tune=(0, 0, 0, 5, 8, 8)), dict(chunk=64, tune=(0, 0, 0, 1)), dict(chunk=256)]
+    cases = [(g.ids, g.row_ptr, g.src) for g in graphs_] + [star]
+    empty = (np.zeros(0, _lib.U128), np.zeros(1, np.uint64), np.zeros(0, np.uint32))
+    for gi, (ids, row_ptr, src) in enumerate(cases + [empty]):
+        for kw in knobs:
+            with gpu_ctx_factory(**kw) as ctx:
+                ctx.load_dense(ids, row_ptr, src)
+                dev = ctx.plan()
+                st = ctx.stats()
+            host = _lib.host_plan(row_ptr, src, flags=kw.get("flags", 0), chunk=kw.get("chunk", 0), tune=kw.get("tune", ()))
+            what = (gi, kw)
+            n = len(ids)
+            assert dev["n_pad"] == host["n_pad"] and dev["nv"] == host["nv"], what
+            assert np.array_equal(dev["level_begin"], host["level_begin"]), what
+            assert np.array_equal(dev["order"][:n], host["order"][:n]), what
+            assert np.all(dev["order"][n:] == 0xFFFFFFFF), what
+            assert np.array_equal(dev["row_ptr"], host["row_ptr"]), what
+            assert np.array_equal(dev["src"], host["src"]), what
+            assert st["level1_edges"] + st["direct_edges"] == len(src), what
 
 
 # ---- edge-partition mode ------------------------------------------------------------------------
