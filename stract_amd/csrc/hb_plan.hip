@@ -36,33 +36,101 @@ using hb::kRowAlign;
         if (e_ != hipSuccess) return std::string(#call) + ": " + hipGetErrorString(e_); \
     } while (0)
 
+// Work memory of the planner.  Every temporary is carved out of ONE device slab by a small first-fit heap:
+// hipMalloc / hipFree of multi-GB buffers are cheap in isolation, but the planner's churn of them (tens of GB
+// allocated and freed between kernels) cost 3.5 s of host time at 2 B edges against 0.4 s of kernels
+// (profiles/r02j_C4_load_kernel_stats.csv) - freed memory seems to be handed back lazily, on later calls.
+// Buffers that outlive the planner (the plan itself) are separate hipMallocs (alloc_out).
 struct DevMem {
-    std::vector<void *> ptrs;
+    struct Block {
+        size_t off, size;
+        bool free;
+    };
+    char *slab = nullptr;
+    size_t slab_bytes = 0;
+    std::vector<Block> blocks;   // address-ordered, covers the slab
+    std::vector<void *> extra;   // overflow: plain hipMallocs
+    std::vector<void *> outputs; // alloc_out results not yet handed over
     ~DevMem()
     {
-        for (void *p : ptrs)
+        for (void *p : extra)
             if (p) (void)hipFree(p);
+        for (void *p : outputs)
+            if (p) (void)hipFree(p);
+        if (slab) (void)hipFree(slab);
+    }
+    hipError_t init(size_t bytes)
+    {
+        bytes = (bytes + 4095) & ~(size_t)4095;
+        hipError_t e = hipMalloc((void **)&slab, bytes);
+        if (e != hipSuccess) { // no slab: every alloc() falls back to hipMalloc
+            (void)hipGetLastError();
+            slab = nullptr;
+            return hipSuccess;
+        }
+        slab_bytes = bytes;
+        blocks.push_back({0, bytes, true});
+        return hipSuccess;
     }
     template <typename T>
     hipError_t alloc(T **out, size_t count)
     {
+        const size_t need = (std::max<size_t>(count * sizeof(T), 256) + 255) & ~(size_t)255;
+        for (size_t i = 0; i < blocks.size(); i++) {
+            if (!blocks[i].free || blocks[i].size < need) continue;
+            if (blocks[i].size > need) {
+                const Block rest{blocks[i].off + need, blocks[i].size - need, true};
+                blocks[i].size = need;
+                blocks.insert(blocks.begin() + (long)i + 1, rest);
+            }
+            blocks[i].free = false;
+            *out = (T *)(slab + blocks[i].off);
+            return hipSuccess;
+        }
         void *p = nullptr;
-        hipError_t e = hipMalloc(&p, std::max<size_t>(count * sizeof(T), 256));
-        if (e == hipSuccess) ptrs.push_back(p);
+        hipError_t e = hipMalloc(&p, need);
+        if (e == hipSuccess) extra.push_back(p);
         *out = (T *)p;
         return e;
     }
-    void release(void *p) // free now
+    void release(void *p)
     {
-        for (auto &q : ptrs)
-            if (q == p && p) {
+        if (!p) return;
+        if (slab && (char *)p >= slab && (char *)p < slab + slab_bytes) {
+            const size_t off = (size_t)((char *)p - slab);
+            for (size_t i = 0; i < blocks.size(); i++) {
+                if (blocks[i].off != off) continue;
+                blocks[i].free = true;
+                if (i + 1 < blocks.size() && blocks[i + 1].free) {
+                    blocks[i].size += blocks[i + 1].size;
+                    blocks.erase(blocks.begin() + (long)i + 1);
+                }
+                if (i > 0 && blocks[i - 1].free) {
+                    blocks[i - 1].size += blocks[i].size;
+                    blocks.erase(blocks.begin() + (long)i);
+                }
+                return;
+            }
+            return;
+        }
+        for (auto &q : extra)
+            if (q == p) {
                 (void)hipFree(p);
                 q = nullptr;
             }
     }
-    void *disown(void *p) // the caller keeps it
+    template <typename T>
+    hipError_t alloc_out(T **out, size_t count) // outlives the planner
     {
-        for (auto &q : ptrs)
+        void *p = nullptr;
+        hipError_t e = hipMalloc(&p, std::max<size_t>(count * sizeof(T), 256));
+        if (e == hipSuccess) outputs.push_back(p);
+        *out = (T *)p;
+        return e;
+    }
+    void *disown(void *p) // the caller keeps an alloc_out buffer
+    {
+        for (auto &q : outputs)
             if (q == p) q = nullptr;
         return p;
     }
@@ -488,6 +556,9 @@ std::string gpu_build_plan(void *stream_v, uint64_t n, const uint64_t *d_row_ptr
     };
 
     DevMem mem;
+    // peak of the live temporaries: the edge sort (hotness ranks 4m + row ids 4m + two 8m key buffers + its scratch);
+    // everything later (chunk / level arrays, the level-1 lists) fits into what the sort leaves behind
+    PL_HIP(mem.init(24 * m + m / 2 + 96 * n_pad + (512ull << 20)));
     void *tmp = nullptr;
     size_t tmp_bytes = 0;
     auto need_tmp = [&](size_t bytes) -> hipError_t {
@@ -502,9 +573,9 @@ std::string gpu_build_plan(void *stream_v, uint64_t n, const uint64_t *d_row_ptr
 
     // ---- device order ------------------------------------------------------------------------------
     uint32_t *d_order = nullptr, *d_dev_of = nullptr, *d_outdeg_dev = nullptr;
-    PL_HIP(mem.alloc(&d_order, n_pad));
-    PL_HIP(mem.alloc(&d_dev_of, n));
-    PL_HIP(mem.alloc(&d_outdeg_dev, n_pad));
+    PL_HIP(mem.alloc_out(&d_order, n_pad));
+    PL_HIP(mem.alloc_out(&d_dev_of, n));
+    PL_HIP(mem.alloc_out(&d_outdeg_dev, n_pad));
     PL_HIP(hipMemsetAsync(d_order, 0xFF, std::max<uint64_t>(n_pad, 1) * sizeof(uint32_t), stream));
     if (n) {
         if (reorder) {
@@ -550,19 +621,23 @@ std::string gpu_build_plan(void *stream_v, uint64_t n, const uint64_t *d_row_ptr
         PL_HIP(rocprim::inclusive_scan(nullptr, bytes, d_rowid, d_rowid, (size_t)m, rocprim::maximum<uint32_t>(), stream));
         PL_HIP(need_tmp(bytes));
         PL_HIP(rocprim::inclusive_scan(tmp, bytes, d_rowid, d_rowid, (size_t)m, rocprim::maximum<uint32_t>(), stream));
+        lap("  rows: row id per edge");
         PL_HIP(mem.alloc(&k_in, m));
         hipLaunchKernelGGL(edge_keys_kernel, dim3(grid_for(m)), dim3(256), 0, stream, (const uint32_t *)d_rowid, d_src_in, m,
                            (const uint32_t *)d_dev_of, slice, world, k_in);
         PL_HIP(hipGetLastError());
         PL_HIP(hipStreamSynchronize(stream));
         mem.release(d_rowid);
+        lap("  rows: keys");
         PL_HIP(mem.alloc(&k_out, m));
         const unsigned end_bit = 32 + (unsigned)bits_for(std::max<uint64_t>(n_pad, 2));
         bytes = 0;
-        PL_HIP(rocprim::radix_sort_keys(nullptr, bytes, k_in, k_out, (size_t)m, 0u, end_bit, stream));
+        rocprim::double_buffer<uint64_t> keys(k_in, k_out); // ping-pong between the two buffers: no third copy as scratch
+        PL_HIP(rocprim::radix_sort_keys(nullptr, bytes, keys, (size_t)m, 0u, end_bit, stream));
         PL_HIP(need_tmp(bytes));
-        PL_HIP(rocprim::radix_sort_keys(tmp, bytes, k_in, k_out, (size_t)m, 0u, end_bit, stream));
-        hipLaunchKernelGGL(low_half_kernel, dim3(grid_for(m)), dim3(256), 0, stream, (const uint64_t *)k_out, m, d_rs);
+        PL_HIP(rocprim::radix_sort_keys(tmp, bytes, keys, (size_t)m, 0u, end_bit, stream));
+        lap("  rows: 64-bit radix sort");
+        hipLaunchKernelGGL(low_half_kernel, dim3(grid_for(m)), dim3(256), 0, stream, (const uint64_t *)keys.current(), m, d_rs);
         PL_HIP(hipGetLastError());
         PL_HIP(hipStreamSynchronize(stream));
         mem.release(k_in);
@@ -672,6 +747,7 @@ std::string gpu_build_plan(void *stream_v, uint64_t n, const uint64_t *d_row_ptr
         PL_HIP(rocprim::radix_sort_pairs(nullptr, bytes, k1, k1s, v1, corder, (size_t)C, 0u, 32u, stream));
         PL_HIP(need_tmp(bytes));
         PL_HIP(rocprim::radix_sort_pairs(tmp, bytes, k1, k1s, v1, corder, (size_t)C, 0u, 32u, stream));
+        lap("  chunks: sort by slice/len");
         if (groups > 1) {
             PL_HIP(hipMemsetAsync(d_sums, 0, 32 * sizeof(unsigned long long), stream));
             hipLaunchKernelGGL(quota_sums_kernel, dim3((unsigned)std::min<uint64_t>(grid_for(C), 2048)), dim3(256), 0, stream, (const uint32_t *)d_clen,
@@ -684,6 +760,7 @@ std::string gpu_build_plan(void *stream_v, uint64_t n, const uint64_t *d_row_ptr
             quota.flex[0] = h_sums[8];
             quota.flex[1] = h_sums[9];
             quota.finish();
+            lap("  chunks: quota sums");
             QuotaBounds qb;
             for (int c = 0; c < 2; c++)
                 for (int x = 0; x < 8; x++) qb.bound[c][x] = quota.bound[c][x];
@@ -709,6 +786,7 @@ std::string gpu_build_plan(void *stream_v, uint64_t n, const uint64_t *d_row_ptr
             hipLaunchKernelGGL(assign_groups_kernel, dim3(grid_for(C)), dim3(256), 0, stream, (const uint32_t *)corder, (const uint32_t *)d_ckey,
                                (const uint64_t *)d_prefix, C, warm_slices, qb, d_grp_sorted, d_grp_of, d_gcount);
             PL_HIP(hipGetLastError());
+            lap("  chunks: prefix + groups");
             bytes = 0;
             PL_HIP(rocprim::radix_sort_pairs(nullptr, bytes, d_grp_sorted, d_grp_sorted2, corder, d_forder, (size_t)C, 0u, 3u, stream));
             PL_HIP(need_tmp(bytes));
@@ -859,7 +937,7 @@ std::string gpu_build_plan(void *stream_v, uint64_t n, const uint64_t *d_row_ptr
     uint64_t *d_len = nullptr, *d_row_ptr = nullptr;
     PL_HIP(mem.alloc(&d_hub_index, n_pad + 1));
     PL_HIP(mem.alloc(&d_len, n_pad + 1));
-    PL_HIP(mem.alloc(&d_row_ptr, rows_total + 2));
+    PL_HIP(mem.alloc_out(&d_row_ptr, rows_total + 2));
     PL_HIP(hipMemsetAsync(d_len, 0, (n_pad + 1) * sizeof(uint64_t), stream));
     if (H) {
         hipLaunchKernelGGL(hub_index_kernel, dim3(grid_for(H)), dim3(256), 0, stream, (const uint32_t *)d_hub_rows, H, d_hub_index);
@@ -890,7 +968,7 @@ std::string gpu_build_plan(void *stream_v, uint64_t n, const uint64_t *d_row_ptr
     PL_HIP(hipGetLastError());
     const uint64_t src_len = real_total + vsrc_len;
     uint32_t *d_src = nullptr;
-    PL_HIP(mem.alloc(&d_src, src_len + 4));
+    PL_HIP(mem.alloc_out(&d_src, src_len + 4));
     if (n_pad) {
         hipLaunchKernelGGL(real_fill_kernel, dim3(grid_for(n_pad * 4)), dim3(256), 0, stream, (const uint64_t *)d_row_ptr, (const uint8_t *)d_is_split,
                            (const uint32_t *)d_hub_index, (const uint64_t *)d_lptr, (const uint32_t *)d_lids, (const uint64_t *)d_rp,
