@@ -43,6 +43,36 @@ RAW, BIAS = _load_tables()
 THRESHOLD_B6 = 40  # THRESHOLD_DATA_VEC[6 - 4], hyperloglog.rs:27-45
 
 
+def _load_extra():
+    """Rows of the same reference tables for other register counts (oracle/hll_tables_extra.json, extracted from
+    hyperloglog.rs by the snippet in oracle/gen_tables.py's header): b - 1 - 4 = 2 (N = 128) and 11 (N = 65 536),
+    plus THRESHOLD_DATA_VEC - what the reference's own HyperLogLog tests use (hyperloglog.rs:4553-4611)."""
+    import json
+    d = json.load(open(os.path.join(_HERE, "hll_tables_extra.json")))
+    raw = {int(k): v for k, v in d["raw"].items()}
+    bias = {int(k): v for k, v in d["bias"].items()}
+    assert raw[1] == RAW and bias[1] == BIAS  # the N = 64 rows agree with hll64_tables.h
+    return raw, bias, d["threshold"]
+
+
+RAW_ROWS, BIAS_ROWS, THRESHOLDS = _load_extra()
+
+
+def hll_b(n):
+    return int(math.log2(n))  # (N as f64).log2() as usize, hyperloglog.rs:4381-4383
+
+
+def hll_am(m):
+    """am(), hyperloglog.rs:4366-4378"""
+    if m >= 128:
+        return 0.7213 / (1.0 + (1.079 / float(m)))
+    if m >= 64:
+        return 0.709
+    if m >= 32:
+        return 0.697
+    return 0.673
+
+
 def fast_hash(item):
     return (item * 11400714819323198549) & MASK64  # wrapping_mul
 
@@ -51,12 +81,12 @@ def leading_zeros64(w):
     return 64 - w.bit_length()
 
 
-def hll_new():
-    return [0] * N
+def hll_new(n=N):
+    return [0] * n
 
 
 def hll_add(reg, item):
-    b = int(math.log2(N))  # (N as f64).log2() as usize == 6
+    b = hll_b(len(reg))  # (N as f64).log2() as usize (6 for the 64-register counters of the centrality path)
     h = fast_hash(item & MASK64)  # add_u128: `item as u64`
     j = h >> (64 - b)
     w = (h << b) & MASK64
@@ -65,7 +95,7 @@ def hll_add(reg, item):
 
 
 def hll_merge(dst, src):
-    for i in range(N):
+    for i in range(len(dst)):
         dst[i] = max(dst[i], src[i])
 
 
@@ -97,9 +127,10 @@ def binary_search_by(arr, e):
     return ("Err", base + (1 if cmp < 0 else 0))
 
 
-def estimate_bias(e):
+def estimate_bias(e, n=N):
     K = 6
-    lookup = RAW  # RAW_ESTIMATE_DATA_VEC[b - 1 - 4] with b = 6
+    row = hll_b(n) - 1 - 4  # hyperloglog.rs:4411: RAW_ESTIMATE_DATA_VEC[b - 1 - RAW_ESTIMATE_DATA_OFFSET]
+    lookup, bias_row = RAW_ROWS[row], BIAS_ROWS[row]
     kind, i = binary_search_by(lookup, e)
     if kind == "Err" and i == len(lookup):
         idx_left = i - 1
@@ -128,7 +159,7 @@ def estimate_bias(e):
             idx_left = idx - 1 if idx > 0 else None
     s = 0.0
     for i in neighbors:  # Iterator::sum is a left fold
-        s = s + BIAS[i]
+        s = s + bias_row[i]
     return s / float(K)
 
 
@@ -142,15 +173,22 @@ def as_usize(x):
 
 
 def hll_size(reg):
-    m = float(len(reg))
-    s = 0.0
-    for val in reg:  # ONE_OVER_POWER_OF_TWO[val] == 2^-val exactly (hyperloglog.rs:4043-4300)
-        s = s + math.ldexp(1.0, -val)
+    """HyperLogLog<N>::size for N = len(reg) (hyperloglog.rs:4484-4516)."""
+    n = len(reg)
+    m = float(n)
+    mx = max(reg) if n else 0
+    if mx <= 30 and n <= (1 << 22):
+        # every partial sum of the left fold is a multiple of 2^-30 below 2^22: exact in f64 whatever the order,
+        # so the fold can be done in integers (what makes N = 65 536 affordable in Python)
+        s = float(sum(1 << (30 - int(val)) for val in reg)) / float(1 << 30)
+    else:
+        s = 0.0
+        for val in reg:  # ONE_OVER_POWER_OF_TWO[val] == 2^-val exactly (hyperloglog.rs:4043-4300)
+            s = s + math.ldexp(1.0, -val)
     z = 1.0 / s
-    am = 0.709  # m == 64
-    e = am * (m * m) * z  # am() * m.powi(2) * z, left to right
+    e = hll_am(n) * (m * m) * z  # am() * m.powi(2) * z, left to right
     if e <= 5.0 * m:
-        e_star = e - estimate_bias(e)
+        e_star = e - estimate_bias(e, n)
     else:
         e_star = e
     v = sum(1 for r in reg if r == 0)
@@ -158,9 +196,20 @@ def hll_size(reg):
         h = m * math.log(m / float(v))
     else:
         h = e_star
-    if h <= float(THRESHOLD_B6):
+    if h <= float(THRESHOLDS[hll_b(n) - 4]):  # threshold(): THRESHOLD_DATA_VEC[b - THRESHOLD_DATA_OFFSET]
         return as_usize(h)
     return as_usize(e_star)
+
+
+def hll_relative_error(n):
+    return 1.04 / math.sqrt(float(n))  # hyperloglog.rs:4519-4521
+
+
+def hll_size_bounds(reg):
+    """size_bounds(), hyperloglog.rs:4523-4529"""
+    size = hll_size(reg)
+    delta = as_usize(hll_relative_error(len(reg)) * 2.0 * float(size))
+    return size - delta, size + delta
 
 
 class Kahan:

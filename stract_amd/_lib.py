@@ -137,6 +137,19 @@ _SIGNATURES = [
                                       ctypes.POINTER(_U64), _P, _P, _P]),
     ("hb_host_plan", ctypes.c_int, [_U64, _P, _P, ctypes.c_uint32, ctypes.c_uint32, _P, _P, _P, _P, _P, _P]),
 ]
+# include/hb_webgraph.h
+_SIGNATURES += [
+    ("hbw_open", ctypes.c_int, [ctypes.c_char_p, ctypes.c_uint32, ctypes.POINTER(_P)]),
+    ("hbw_close", None, [_P]),
+    ("hbw_last_error", ctypes.c_char_p, [_P]),
+    ("hbw_num_segments", ctypes.c_int, [_P, ctypes.POINTER(_U64)]),
+    ("hbw_segment_info", ctypes.c_int, [_P, _U64, ctypes.c_char_p, ctypes.POINTER(_U64)]),
+    ("hbw_total_rows", ctypes.c_int, [_P, ctypes.POINTER(_U64)]),
+    ("hbw_read_host_edges", ctypes.c_int, [_P, _U64, _U64, _P]),
+    ("hb_load_webgraph", ctypes.c_int, [_P, ctypes.c_char_p, ctypes.c_uint32]),
+    ("hbw_debug_sstable", ctypes.c_int, [_P, _U64, ctypes.c_int, _P, _U64, _P, _U64, ctypes.POINTER(_U64)]),
+    ("hbw_debug_crc32", ctypes.c_uint32, [_P, _U64]),
+]
 SYMBOLS = [s[0] for s in _SIGNATURES]
 
 _lib = None

@@ -1,0 +1,621 @@
+// hb_webgraph.cpp - native reader of Stract's webgraph edge store (include/hb_webgraph.h states the format and
+// cites the reference serialisers it follows).  Host C++ only; nothing is copied from the reference.
+#include "../../include/hb_webgraph.h"
+
+#include <dlfcn.h>
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+namespace {
+
+thread_local std::string g_open_error;
+
+struct Bytes {
+    const uint8_t *p = nullptr;
+    uint64_t n = 0;
+    Bytes() = default;
+    Bytes(const uint8_t *p_, uint64_t n_) : p(p_), n(n_) {}
+    Bytes sub(uint64_t off, uint64_t len) const { return Bytes(p + off, len); }
+};
+
+uint32_t rd_u32(const uint8_t *p)
+{
+    uint32_t v;
+    std::memcpy(&v, p, 4);
+    return v; // little-endian host (x86-64): the format is little-endian throughout (common/serialize.rs Endianness)
+}
+uint64_t rd_u64(const uint8_t *p)
+{
+    uint64_t v;
+    std::memcpy(&v, p, 8);
+    return v;
+}
+
+// ---- CRC-32 (IEEE 802.3, the polynomial of crc32fast), slicing-by-8 ------------------------------------
+struct Crc32Tables {
+    uint32_t t[8][256];
+    Crc32Tables()
+    {
+        for (uint32_t i = 0; i < 256; i++) {
+            uint32_t c = i;
+            for (int k = 0; k < 8; k++) c = (c & 1) ? 0xEDB88320u ^ (c >> 1) : c >> 1;
+            t[0][i] = c;
+        }
+        for (uint32_t i = 0; i < 256; i++)
+            for (int s = 1; s < 8; s++) t[s][i] = (t[s - 1][i] >> 8) ^ t[0][t[s - 1][i] & 0xFF];
+    }
+};
+uint32_t crc32_ieee(const uint8_t *p, uint64_t n)
+{
+    static const Crc32Tables T;
+    uint32_t c = 0xFFFFFFFFu;
+    while (n >= 8) {
+        const uint32_t a = rd_u32(p) ^ c, b = rd_u32(p + 4);
+        c = T.t[7][a & 0xFF] ^ T.t[6][(a >> 8) & 0xFF] ^ T.t[5][(a >> 16) & 0xFF] ^ T.t[4][a >> 24] ^ T.t[3][b & 0xFF] ^
+            T.t[2][(b >> 8) & 0xFF] ^ T.t[1][(b >> 16) & 0xFF] ^ T.t[0][b >> 24];
+        p += 8;
+        n -= 8;
+    }
+    while (n--) c = T.t[0][(c ^ *p++) & 0xFF] ^ (c >> 8);
+    return c ^ 0xFFFFFFFFu;
+}
+
+// ---- zstd, only if a dictionary block is compressed (blocks above 2048 bytes, sstable/delta.rs:58-80) --------
+typedef size_t (*zstd_decompress_fn)(void *, size_t, const void *, size_t);
+typedef unsigned long long (*zstd_bound_fn)(const void *, size_t);
+typedef unsigned (*zstd_iserr_fn)(size_t);
+bool zstd_decompress(Bytes in, std::vector<uint8_t> *out, std::string *err)
+{
+    static void *lib = nullptr;
+    static zstd_decompress_fn dec = nullptr;
+    static zstd_bound_fn bound = nullptr;
+    static zstd_iserr_fn iserr = nullptr;
+    if (!lib) {
+        for (const char *name : {"libzstd.so.1", "libzstd.so"}) {
+            lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+            if (lib) break;
+        }
+        if (lib) {
+            dec = (zstd_decompress_fn)dlsym(lib, "ZSTD_decompress");
+            bound = (zstd_bound_fn)dlsym(lib, "ZSTD_getFrameContentSize");
+            iserr = (zstd_iserr_fn)dlsym(lib, "ZSTD_isError");
+        }
+    }
+    if (!dec || !bound || !iserr) {
+        *err = "a dictionary block is zstd-compressed and libzstd.so.1 cannot be loaded";
+        return false;
+    }
+    unsigned long long sz = bound(in.p, in.n);
+    if (sz == 0xFFFFFFFFFFFFFFFFull || sz == 0xFFFFFFFFFFFFFFFEull) sz = 1024 * 1024; // unknown: the reference's fallback
+    out->resize((size_t)sz);
+    const size_t got = dec(out->data(), out->size(), in.p, in.n);
+    if (iserr(got)) {
+        *err = "zstd: corrupt dictionary block";
+        return false;
+    }
+    out->resize(got);
+    return true;
+}
+
+// ---- sstable (sstable/mod.rs, delta.rs, block_reader.rs, vint.rs, value/range.rs) --------------------------
+// LEB128: continue bit on every byte but the last (sstable/vint.rs - NOT common/vint.rs, whose stop bit is inverted)
+bool sst_vint(Bytes *b, uint64_t *out)
+{
+    uint64_t r = 0;
+    int shift = 0;
+    while (b->n) {
+        const uint8_t c = *b->p;
+        b->p++;
+        b->n--;
+        r |= (uint64_t)(c & 127u) << shift;
+        if (c < 128) {
+            *out = r;
+            return true;
+        }
+        shift += 7;
+        if (shift > 63) return false;
+    }
+    return false;
+}
+
+struct SstEntry {
+    std::string key;
+    uint64_t start = 0, end = 0;
+};
+
+// value_mode 0: VoidSSTable (no value block); 1: RangeSSTable
+std::string read_sstable(Bytes dict, int value_mode, std::vector<SstEntry> *out)
+{
+    if (dict.n < 20) return "sstable shorter than its footer";
+    const uint64_t index_offset = rd_u64(dict.p + dict.n - 20);
+    const uint64_t num_terms = rd_u64(dict.p + dict.n - 12);
+    const uint32_t version = rd_u32(dict.p + dict.n - 4);
+    if (version != 2 && version != 3) return "unsupported sstable version " + std::to_string(version);
+    if (index_offset > dict.n - 20) return "sstable: index offset out of range";
+    Bytes blocks = dict.sub(0, index_offset); // the block index (fst + block addresses) is not needed to stream all entries
+    std::vector<uint8_t> scratch;
+    std::string key;
+    while (blocks.n) {
+        if (blocks.n < 4) return "sstable: truncated block length";
+        uint64_t block_len = rd_u32(blocks.p);
+        blocks = blocks.sub(4, blocks.n - 4);
+        if (block_len <= 1) break; // end marker
+        if (blocks.n < block_len) return "sstable: truncated block";
+        const uint8_t compress = blocks.p[0];
+        Bytes body = blocks.sub(1, block_len - 1);
+        blocks = blocks.sub(block_len, blocks.n - block_len);
+        if (compress == 1) {
+            std::string err;
+            if (!zstd_decompress(body, &scratch, &err)) return err;
+            body = Bytes(scratch.data(), scratch.size());
+        } else if (compress != 0) {
+            return "sstable: unknown block compression flag";
+        }
+        // values of the block first (value/range.rs: count, first start, then end - start deltas)
+        std::vector<uint64_t> bounds;
+        if (value_mode == 1) {
+            uint64_t cnt = 0;
+            if (!sst_vint(&body, &cnt)) return "sstable: bad value block";
+            uint64_t prev = 0;
+            for (uint64_t i = 0; i < cnt; i++) {
+                uint64_t d = 0;
+                if (!sst_vint(&body, &d)) return "sstable: bad value block";
+                prev += d;
+                bounds.push_back(prev);
+            }
+        }
+        // keys: (keep, add) packed in one byte when both < 16, else 0x01 followed by two vints (delta.rs:90-100,160-180)
+        key.clear(); // the first key of a block is stored whole (the writer clears previous_key per block)
+        uint64_t idx = 0;
+        while (body.n) {
+            const uint8_t b0 = body.p[0];
+            body = body.sub(1, body.n - 1);
+            uint64_t keep, add;
+            if (b0 == 1) {
+                if (!sst_vint(&body, &keep) || !sst_vint(&body, &add)) return "sstable: bad key header";
+            } else {
+                keep = b0 & 15u;
+                add = b0 >> 4;
+            }
+            if (keep > key.size() || add > body.n) return "sstable: bad key delta";
+            key.resize(keep);
+            key.append((const char *)body.p, add);
+            body = body.sub(add, body.n - add);
+            SstEntry e;
+            e.key = key;
+            if (value_mode == 1) {
+                if (idx + 1 >= bounds.size()) return "sstable: fewer values than keys";
+                e.start = bounds[idx];
+                e.end = bounds[idx + 1];
+            }
+            out->push_back(e);
+            idx++;
+        }
+    }
+    if (out->size() != num_terms) return "sstable: term count mismatch";
+    return "";
+}
+
+// ---- minimal JSON (meta.json) ---------------------------------------------------------------------------------
+struct Json {
+    const char *p, *e;
+    std::string err;
+    void ws()
+    {
+        while (p < e && (*p == ' ' || *p == '\n' || *p == '\t' || *p == '\r')) p++;
+    }
+    bool lit(char c)
+    {
+        ws();
+        if (p < e && *p == c) {
+            p++;
+            return true;
+        }
+        return false;
+    }
+    bool str(std::string *out)
+    {
+        ws();
+        if (p >= e || *p != '"') return false;
+        p++;
+        out->clear();
+        while (p < e && *p != '"') {
+            if (*p == '\\' && p + 1 < e) {
+                p++;
+                switch (*p) {
+                case 'n': out->push_back('\n'); break;
+                case 't': out->push_back('\t'); break;
+                case 'u': p += std::min<long>(4, (long)(e - p - 1)); out->push_back('?'); break;
+                default: out->push_back(*p);
+                }
+                p++;
+            } else {
+                out->push_back(*p++);
+            }
+        }
+        if (p >= e) return false;
+        p++;
+        return true;
+    }
+    bool skip() // any value
+    {
+        ws();
+        if (p >= e) return false;
+        if (*p == '"') {
+            std::string s;
+            return str(&s);
+        }
+        if (*p == '{' || *p == '[') {
+            const char open = *p, close = open == '{' ? '}' : ']';
+            p++;
+            if (lit(close)) return true;
+            while (true) {
+                if (open == '{') {
+                    std::string k;
+                    if (!str(&k) || !lit(':')) return false;
+                }
+                if (!skip()) return false;
+                if (lit(',')) continue;
+                return lit(close);
+            }
+        }
+        while (p < e && *p != ',' && *p != '}' && *p != ']' && *p != ' ' && *p != '\n') p++; // number / true / false / null
+        return true;
+    }
+    bool number(uint64_t *out)
+    {
+        ws();
+        if (p >= e || *p < '0' || *p > '9') return false;
+        uint64_t v = 0;
+        while (p < e && *p >= '0' && *p <= '9') v = v * 10 + (uint64_t)(*p++ - '0');
+        *out = v;
+        return true;
+    }
+};
+
+struct SegmentMeta {
+    std::string uuid; // 32 hex chars
+    uint64_t max_doc = 0;
+};
+
+std::string parse_meta(const std::string &text, std::vector<SegmentMeta> *segs)
+{
+    Json j{text.data(), text.data() + text.size(), ""};
+    if (!j.lit('{')) return "meta.json: not an object";
+    bool found = false;
+    if (!j.lit('}')) {
+        while (true) {
+            std::string k;
+            if (!j.str(&k) || !j.lit(':')) return "meta.json: malformed";
+            if (k == "segments") {
+                found = true;
+                if (!j.lit('[')) return "meta.json: \"segments\" is not an array";
+                if (!j.lit(']')) {
+                    while (true) {
+                        if (!j.lit('{')) return "meta.json: segment entry is not an object";
+                        SegmentMeta s;
+                        bool have_id = false, have_docs = false;
+                        if (!j.lit('}')) {
+                            while (true) {
+                                std::string sk;
+                                if (!j.str(&sk) || !j.lit(':')) return "meta.json: malformed segment entry";
+                                if (sk == "segment_id") {
+                                    std::string id;
+                                    if (!j.str(&id)) return "meta.json: segment_id is not a string";
+                                    for (char ch : id)
+                                        if (ch != '-') s.uuid.push_back((char)std::tolower((unsigned char)ch)); // serde writes the hyphenated form
+                                    have_id = true;
+                                } else if (sk == "max_doc") {
+                                    if (!j.number(&s.max_doc)) return "meta.json: max_doc is not a number";
+                                    have_docs = true;
+                                } else if (!j.skip()) {
+                                    return "meta.json: malformed segment entry";
+                                }
+                                if (j.lit(',')) continue;
+                                if (!j.lit('}')) return "meta.json: malformed segment entry";
+                                break;
+                            }
+                        }
+                        if (!have_id || !have_docs || s.uuid.size() != 32) return "meta.json: segment entry without segment_id / max_doc";
+                        segs->push_back(s);
+                        if (j.lit(',')) continue;
+                        if (!j.lit(']')) return "meta.json: malformed segment list";
+                        break;
+                    }
+                }
+            } else if (!j.skip()) {
+                return "meta.json: malformed";
+            }
+            if (j.lit(',')) continue;
+            if (!j.lit('}')) return "meta.json: malformed";
+            break;
+        }
+    }
+    if (!found) return "meta.json: no \"segments\"";
+    return "";
+}
+
+// ---- one segment ------------------------------------------------------------------------------------------------
+struct Segment {
+    SegmentMeta meta;
+    void *map = nullptr;
+    uint64_t map_len = 0;
+    const uint8_t *from = nullptr, *to = nullptr, *flags = nullptr; // raw little-endian values, num_rows each
+    uint64_t num_rows = 0;
+    uint64_t first = 0; // stream position of its first document
+};
+
+// column bytes -> raw value array (column/serialize.rs:27-59)
+std::string open_raw_column(Bytes col, int value_bytes, uint8_t want_codec, uint64_t expect_rows, const uint8_t **data)
+{
+    if (col.n < 4) return "column shorter than its trailer";
+    const uint32_t index_bytes = rd_u32(col.p + col.n - 4);
+    Bytes body = col.sub(0, col.n - 4);
+    if (index_bytes < 1 || index_bytes > body.n) return "column index length out of range";
+    if (body.p[0] != 0) return "column cardinality is not Full (code " + std::to_string(body.p[0]) + ")";
+    Bytes vals = body.sub(index_bytes, body.n - index_bytes);
+    const uint64_t header = 1 + 4 + 2 * (uint64_t)value_bytes; // codec, num_rows, min, max
+    if (vals.n < header) return "column values shorter than their header";
+    if (vals.p[0] != want_codec)
+        return "column codec " + std::to_string(vals.p[0]) + " is not Raw (" + std::to_string(want_codec) +
+               "): the reference snapshot only writes Raw (column/serialize.rs:23,53)";
+    const uint64_t rows = rd_u32(vals.p + 1);
+    if (rows != expect_rows) return "column holds " + std::to_string(rows) + " rows, the segment " + std::to_string(expect_rows);
+    if (vals.n - header < rows * (uint64_t)value_bytes) return "column data truncated";
+    *data = vals.p + header;
+    return "";
+}
+
+std::string open_segment(const std::string &dir, uint32_t flags, Segment *s)
+{
+    const std::string path = dir + "/" + s->meta.uuid + ".col";
+    const int fd = ::open(path.c_str(), O_RDONLY);
+    if (fd < 0) return path + ": cannot open";
+    struct stat st;
+    if (fstat(fd, &st) != 0 || st.st_size < 8) {
+        ::close(fd);
+        return path + ": too small";
+    }
+    s->map_len = (uint64_t)st.st_size;
+    s->map = mmap(nullptr, s->map_len, PROT_READ, MAP_PRIVATE, fd, 0);
+    ::close(fd);
+    if (s->map == MAP_FAILED) {
+        s->map = nullptr;
+        return path + ": mmap failed";
+    }
+    Bytes file((const uint8_t *)s->map, s->map_len);
+    // directory footer (footer.rs:45-102): ... [json][json_len u32][1337 u32]
+    const uint32_t magic = rd_u32(file.p + file.n - 4), json_len = rd_u32(file.p + file.n - 8);
+    if (magic != 1337) return path + ": footer magic mismatch";
+    if (json_len > 50000 || (uint64_t)json_len + 8 > file.n) return path + ": footer length out of range";
+    Bytes body = file.sub(0, file.n - 8 - json_len);
+    if (flags & HBW_VERIFY_CRC) {
+        const std::string js((const char *)file.p + body.n, json_len);
+        const size_t at = js.find("\"crc\":");
+        if (at == std::string::npos) return path + ": footer without crc";
+        const uint64_t want = std::strtoull(js.c_str() + at + 6, nullptr, 10);
+        if ((uint64_t)crc32_ieee(body.p, body.n) != want) return path + ": CRC mismatch";
+    }
+    // columnar footer (reader/mod.rs:85-103): [column data][sstable][sstable_len u64][num_rows u32][version u32][magic 4]
+    if (body.n < 20) return path + ": columnar body too small";
+    const uint8_t *tail = body.p + body.n - 20;
+    const uint64_t sstable_len = rd_u64(tail);
+    const uint32_t num_rows = rd_u32(tail + 8), version = rd_u32(tail + 12);
+    static const uint8_t kMagic[4] = {2, 113, 119, 66};
+    if (std::memcmp(tail + 16, kMagic, 4) != 0) return path + ": not a columnar file";
+    if (version != 1) return path + ": unsupported columnar version";
+    if (sstable_len > body.n - 20) return path + ": dictionary length out of range";
+    if (num_rows != s->meta.max_doc) return path + ": num_rows differs from meta.json max_doc";
+    const Bytes column_data = body.sub(0, body.n - 20 - sstable_len);
+    const Bytes dict = body.sub(column_data.n, sstable_len);
+    std::vector<SstEntry> cols;
+    std::string e = read_sstable(dict, 1, &cols);
+    if (!e.empty()) return path + ": " + e;
+    s->num_rows = num_rows;
+    struct Want {
+        const char *name;
+        uint8_t type_code; // column_type.rs: U64 = 1, U128 = 6
+        int value_bytes;
+        uint8_t codec;     // Raw: 0 among the u128 codecs, 3 among the u64 codecs
+        const uint8_t **dst;
+    } wants[3] = {{"from_host_id", 6, 16, 0, &s->from}, {"to_host_id", 6, 16, 0, &s->to}, {"rel_flags", 1, 8, 3, &s->flags}};
+    for (const Want &w : wants) {
+        std::string key(w.name);
+        key.push_back('\0');
+        key.push_back((char)w.type_code);
+        const SstEntry *hit = nullptr;
+        for (const SstEntry &c : cols)
+            if (c.key == key) hit = &c;
+        if (!hit) return path + ": no column `" + w.name + "` of the expected type";
+        if (hit->end < hit->start || hit->end > column_data.n) return path + ": column range out of bounds";
+        e = open_raw_column(column_data.sub(hit->start, hit->end - hit->start), w.value_bytes, w.codec, num_rows, w.dst);
+        if (!e.empty()) return path + ": `" + w.name + "`: " + e;
+    }
+    return "";
+}
+
+} // namespace
+
+struct hbw_reader {
+    std::string dir;
+    std::vector<Segment> segs;
+    uint64_t total = 0;
+    std::string err;
+    ~hbw_reader()
+    {
+        for (Segment &s : segs)
+            if (s.map) munmap(s.map, s.map_len);
+    }
+};
+
+namespace {
+template <class F>
+int guarded(hbw_reader *r, F &&f)
+{
+    try {
+        return f();
+    } catch (const std::bad_alloc &) {
+        try { (r ? r->err : g_open_error) = "out of host memory"; } catch (...) {}
+        return HB_ERR_NOMEM;
+    } catch (...) {
+        try { (r ? r->err : g_open_error) = "unexpected C++ exception"; } catch (...) {}
+        return HB_ERR_INVALID;
+    }
+}
+} // namespace
+
+extern "C" {
+
+const char *hbw_last_error(const hbw_reader *r) { return r ? r->err.c_str() : g_open_error.c_str(); }
+
+int hbw_open(const char *edges_dir, uint32_t flags, hbw_reader **out)
+{
+    return guarded(nullptr, [&]() -> int {
+        if (!edges_dir || !out) {
+            g_open_error = "NULL argument";
+            return HB_ERR_INVALID;
+        }
+        *out = nullptr;
+        const std::string dir(edges_dir);
+        std::string text;
+        {
+            FILE *f = std::fopen((dir + "/meta.json").c_str(), "rb");
+            if (!f) {
+                g_open_error = dir + "/meta.json: cannot open";
+                return HB_ERR_INVALID;
+            }
+            char buf[65536];
+            size_t got;
+            while ((got = std::fread(buf, 1, sizeof(buf), f)) > 0) text.append(buf, got);
+            std::fclose(f);
+        }
+        hbw_reader *r = new hbw_reader();
+        r->dir = dir;
+        std::vector<SegmentMeta> metas;
+        std::string e = parse_meta(text, &metas);
+        for (size_t i = 0; e.empty() && i < metas.size(); i++) {
+            r->segs.emplace_back();
+            Segment &s = r->segs.back();
+            s.meta = metas[i];
+            s.first = r->total;
+            e = open_segment(dir, flags, &s);
+            r->total += s.num_rows;
+        }
+        if (!e.empty()) {
+            g_open_error = e;
+            delete r;
+            return HB_ERR_INVALID;
+        }
+        *out = r;
+        return HB_OK;
+    });
+}
+
+void hbw_close(hbw_reader *r) { delete r; }
+
+int hbw_num_segments(const hbw_reader *r, uint64_t *count)
+{
+    if (!r || !count) return HB_ERR_INVALID;
+    *count = r->segs.size();
+    return HB_OK;
+}
+
+int hbw_segment_info(const hbw_reader *r, uint64_t segment, char uuid[33], uint64_t *num_rows)
+{
+    if (!r || segment >= r->segs.size()) return HB_ERR_INVALID;
+    if (uuid) std::snprintf(uuid, 33, "%s", r->segs[segment].meta.uuid.c_str());
+    if (num_rows) *num_rows = r->segs[segment].num_rows;
+    return HB_OK;
+}
+
+int hbw_total_rows(const hbw_reader *r, uint64_t *rows)
+{
+    if (!r || !rows) return HB_ERR_INVALID;
+    *rows = r->total;
+    return HB_OK;
+}
+
+int hbw_read_host_edges(const hbw_reader *r, uint64_t first, uint64_t count, hb_edge *out)
+{
+    if (!r || (count && !out)) return HB_ERR_INVALID;
+    if (first > r->total || count > r->total - first) return HB_ERR_INVALID;
+    uint64_t done = 0;
+    for (const Segment &s : r->segs) {
+        if (done == count) break;
+        const uint64_t pos = first + done;
+        if (pos >= s.first + s.num_rows) continue;
+        const uint64_t b = pos - s.first, n = std::min<uint64_t>(count - done, s.num_rows - b);
+        hb_edge *dst = out + done;
+#pragma omp parallel for schedule(static) if (n > 65536)
+        for (int64_t i = 0; i < (int64_t)n; i++) {
+            std::memcpy(&dst[i].from, s.from + 16 * (b + (uint64_t)i), 16); // u128 little-endian = {lo, hi}
+            std::memcpy(&dst[i].to, s.to + 16 * (b + (uint64_t)i), 16);
+            std::memcpy(&dst[i].rel_flags, s.flags + 8 * (b + (uint64_t)i), 8);
+        }
+        done += n;
+    }
+    return HB_OK;
+}
+
+int hb_load_webgraph(hb_ctx *ctx, const char *edges_dir, uint32_t flags)
+{
+    if (!ctx) return HB_ERR_INVALID;
+    hbw_reader *r = nullptr;
+    int rc = hbw_open(edges_dir, flags, &r);
+    if (rc != HB_OK) return rc; // message: hbw_last_error(NULL)
+    return guarded(r, [&]() -> int {
+        const uint64_t slab = 1ull << 22; // 4 Mi records (160 MiB) per hand-over
+        std::vector<hb_edge> buf((size_t)std::min<uint64_t>(slab, std::max<uint64_t>(r->total, 1)));
+        int rc2 = HB_OK;
+        for (uint64_t at = 0; at < r->total && rc2 == HB_OK; at += slab) {
+            const uint64_t n = std::min(slab, r->total - at);
+            rc2 = hbw_read_host_edges(r, at, n, buf.data());
+            if (rc2 == HB_OK) rc2 = hb_append_edges(ctx, buf.data(), n);
+        }
+        if (rc2 == HB_OK) rc2 = hb_finalize(ctx, nullptr, 0); // node set = all endpoints = host_nodes() (store.rs:338-357)
+        hbw_close(r);
+        return rc2;
+    });
+}
+
+int hbw_debug_sstable(const uint8_t *bytes, uint64_t len, int value_mode, uint8_t *keys_out, uint64_t keys_cap, uint64_t *ranges_out,
+                      uint64_t ranges_cap, uint64_t *count)
+{
+    return guarded(nullptr, [&]() -> int {
+        if (!bytes || !count) return HB_ERR_INVALID;
+        std::vector<SstEntry> ents;
+        const std::string e = read_sstable(Bytes(bytes, len), value_mode, &ents);
+        if (!e.empty()) {
+            g_open_error = e;
+            return HB_ERR_INVALID;
+        }
+        *count = ents.size();
+        uint64_t kpos = 0;
+        for (size_t i = 0; i < ents.size(); i++) {
+            const uint32_t kl = (uint32_t)ents[i].key.size();
+            if (keys_out && kpos + 4 + kl <= keys_cap) {
+                std::memcpy(keys_out + kpos, &kl, 4);
+                std::memcpy(keys_out + kpos + 4, ents[i].key.data(), kl);
+            }
+            kpos += 4 + kl;
+            if (ranges_out && 2 * i + 1 < ranges_cap) {
+                ranges_out[2 * i] = ents[i].start;
+                ranges_out[2 * i + 1] = ents[i].end;
+            }
+        }
+        return HB_OK;
+    });
+}
+
+uint32_t hbw_debug_crc32(const uint8_t *bytes, uint64_t len) { return crc32_ieee(bytes, len); }
+
+} // extern "C"

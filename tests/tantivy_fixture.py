@@ -1,0 +1,155 @@
+"""Writes a Stract webgraph edge store (`<webgraph>/edges`: meta.json + one `.col` file per segment) for tests of the
+native reader (include/hb_webgraph.h).  TEST INFRASTRUCTURE: a plain-Python restatement of the reference's
+serialisers, each function citing what it follows (paths under /root/reference/crates/tantivy/src):
+
+  columnar file   columnar/columnar/writer/mod.rs:264-300 (columns sorted by (name, type)), writer/serializer.rs:20-69
+  one column      columnar/column/serialize.rs:17-26,47-56 + column_index/serialize.rs:21-36 (cardinality Full = 0)
+  u128 values     column_values/u128_based/mod.rs:97-102 (codec byte 0 = Raw) + raw.rs:94-113
+  u64 values      column_values/u64_based/mod.rs:27-32,121-126 (codec byte 3 = Raw) + raw.rs
+  dictionary      sstable/mod.rs:231-316 (Writer), delta.rs:45-110 (blocks, keep/add), value/range.rs:44-63, vint.rs:3-16
+  file footer     directory/footer.rs:33-41 (JSON + len + 1337), CRC-32 of the body (footer.rs FooterProxy)
+  meta.json       index/index_meta.rs:215-225,325-342,436-440
+
+"Format unpinned": nothing here was checked against a file written by the reference (no Rust toolchain in this
+image); tools/ref_fixture.rs writes the same fixture with the reference itself."""
+import json
+import os
+import struct
+import uuid
+import zlib
+
+import numpy as np
+
+U64, U128 = 1, 6  # ColumnType codes, columnar/columnar/column_type.rs:13-21
+
+
+def sst_vint(v):
+    """sstable/vint.rs:3-16: 7 bits per byte, continue bit on all but the last byte."""
+    out = bytearray()
+    while True:
+        b = v & 127
+        v >>= 7
+        if v == 0:
+            out.append(b)
+            return bytes(out)
+        out.append(b | 128)
+
+
+def sstable_ranges(entries, block_len=4000):
+    """Dictionary<RangeSSTable> bytes for sorted [(key, (start, end))].  Follows Writer::insert / DeltaWriter::flush_block /
+    Writer::finish; blocks above 2048 bytes would be zstd-compressed by the reference (not available here: asserted)."""
+    out = bytearray()
+    block, vals, prev_key, nblocks = bytearray(), [], b"", 0
+
+    def flush():
+        nonlocal block, vals, nblocks
+        if not block:
+            return
+        vb = bytearray(sst_vint(len(vals)))
+        prev = 0
+        for v in vals:
+            vb += sst_vint(v - prev)
+            prev = v
+        total = len(vb) + len(block)
+        assert total <= 2048, "the reference would zstd-compress this block (delta.rs:58)"
+        out.extend(struct.pack("<I", total + 1))
+        out.append(0)
+        out.extend(vb)
+        out.extend(block)
+        block, vals = bytearray(), []
+        nblocks += 1
+
+    for key, (start, end) in entries:
+        keep = 0
+        while keep < min(len(prev_key), len(key)) and prev_key[keep] == key[keep]:
+            keep += 1
+        add = len(key) - keep
+        assert not prev_key or key > prev_key, "keys must increase"
+        if keep < 16 and add < 16:
+            block.append(keep | (add << 4))
+        else:
+            block.append(1)
+            block.extend(sst_vint(keep))
+            block.extend(sst_vint(add))
+        block.extend(key[keep:])
+        if vals:
+            assert vals[-1] == start
+            vals.append(end)
+        else:
+            vals.extend([start, end])
+        prev_key = key
+        if len(block) > block_len:
+            flush()
+            prev_key = b""
+    flush()
+    out.extend(struct.pack("<I", 0))  # end marker
+    offset = len(out)
+    assert nblocks <= 1, "multi-block dictionaries need the fst index (sstable_index_v3.rs:281-303)"
+    out.extend(struct.pack("<Q", 0))           # fst length: 0 = no index (<= 1 block)
+    out.extend(struct.pack("<Q", offset))      # index start offset
+    out.extend(struct.pack("<Q", len(entries)))
+    out.extend(struct.pack("<I", 3))           # SSTABLE_VERSION
+    return bytes(out)
+
+
+def column_bytes(ctype, values):
+    """[column index][column values][column_index_num_bytes u32]"""
+    n = len(values)
+    out = bytearray([0])  # Cardinality::Full
+    if ctype == U128:
+        v = np.ascontiguousarray(values)  # structured (lo, hi) little-endian = u128 little-endian
+        ints = [(int(h) << 64) | int(l) for l, h in zip(v["lo"], v["hi"])] or [0]
+        out.append(0)  # u128 CodecType::Raw
+        out += struct.pack("<I", n)
+        for x in (min(ints), max(ints)):
+            out += struct.pack("<QQ", x & 0xFFFFFFFFFFFFFFFF, x >> 64)
+        out += v.tobytes()
+    else:
+        v = np.ascontiguousarray(values, dtype="<u8")
+        out.append(3)  # u64 CodecType::Raw
+        out += struct.pack("<I", n)
+        out += struct.pack("<QQ", int(v.min()) if n else 0, int(v.max()) if n else 0)
+        out += v.tobytes()
+    out += struct.pack("<I", 1)  # the column index is the single cardinality byte
+    return bytes(out)
+
+
+def columnar_bytes(columns, num_rows):
+    """columns: {name: (type code, values)}"""
+    data, entries = bytearray(), []
+    for name, (ctype, values) in sorted(columns.items(), key=lambda kv: (kv[0].encode(), kv[1][0])):
+        start = len(data)
+        data += column_bytes(ctype, values)
+        entries.append((name.encode().replace(b"\0", b"0") + b"\0" + bytes([ctype]), (start, len(data))))
+    sst = sstable_ranges(entries)
+    return bytes(data) + sst + struct.pack("<QI", len(sst), num_rows) + struct.pack("<I", 1) + bytes([2, 113, 119, 66])
+
+
+def with_footer(body):
+    js = json.dumps({"version": {"major": 0, "minor": 23, "patch": 0, "index_format_version": 6},
+                     "crc": zlib.crc32(body) & 0xFFFFFFFF}, separators=(",", ":")).encode()
+    return body + js + struct.pack("<II", len(js), 1337)
+
+
+def write_edge_store(path, segments, extra_columns=True):
+    """segments: list of EDGE record arrays (stract_amd._lib.EDGE), one tantivy segment each.  Returns the uuids."""
+    os.makedirs(path, exist_ok=True)
+    metas, ids = [], []
+    for i, edges in enumerate(segments):
+        sid = uuid.UUID(int=(0xA5C4DFCBDFE645089129E308E26D5500 + i))
+        n = len(edges)
+        cols = {"from_host_id": (U128, edges["from"]), "to_host_id": (U128, edges["to"]), "rel_flags": (U64, edges["rel_flags"])}
+        if extra_columns:  # other columnar fields of the webgraph schema (webgraph/schema.rs), ignored by the reader
+            cols["from_id"] = (U128, edges["to"])
+            cols["to_id"] = (U128, edges["from"])
+            cols["sort_score"] = (U64, np.arange(n, dtype=np.uint64))
+        with open(os.path.join(path, sid.hex + ".col"), "wb") as f:
+            f.write(with_footer(columnar_bytes(cols, n)))
+        metas.append({"segment_id": str(sid), "max_doc": n, "deletes": None})
+        ids.append(sid.hex)
+    meta = {"index_settings": {"sort_by_field": {"field": "sort_score", "order": "Asc"}, "docstore_compression": "lz4",
+                               "docstore_blocksize": 16384},
+            "segments": metas, "schema": [{"name": "from_host_id", "type": "u128", "options": {"columnar": True}}], "opstamp": 7}
+    with open(os.path.join(path, "meta.json"), "w") as f:
+        json.dump(meta, f, separators=(",", ":"))
+    return ids

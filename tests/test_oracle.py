@@ -8,7 +8,7 @@ import os
 import numpy as np
 import pytest
 
-from oracle import hbo
+from oracle import hbo, pyref
 from tests import graphs
 
 GOLD = os.path.join(os.path.dirname(__file__), "golden", "hyperball_golden.json")
@@ -358,3 +358,63 @@ def test_state_hash_definition():
     o2 = hbo.Dense(g.id_low64(), g.row_ptr, g.src)
     o2.step(hbo.FRONTIER)
     assert o2.state_hash() != (hr, hk)
+
+
+# ---- the reference's own HyperLogLog tests (hyperloglog.rs:4553-4611), through the generalised restatement ---------
+def _np_registers(n, items):
+    """Registers after adding `items` (numpy u64) to a fresh HyperLogLog<n> with FastHasher - vectorised
+    hyperloglog.rs:4385-4396; checked against pyref.hll_add on a sample."""
+    b = pyref.hll_b(n)
+    with np.errstate(over="ignore"):
+        h = items.astype(np.uint64) * np.uint64(11400714819323198549)
+    j = (h >> np.uint64(64 - b)).astype(np.int64)
+    w = h << np.uint64(b)
+    lz = np.full(len(w), 64, dtype=np.int64)  # leading_zeros of a u64 (64 for 0)
+    x = w.copy()
+    nz = x != 0
+    lz[nz] = 0
+    for shift in (32, 16, 8, 4, 2, 1):
+        top = (x >> np.uint64(64 - shift)) == 0
+        m = nz & top
+        lz[m] += shift
+        x[m] = x[m] << np.uint64(shift)
+    reg = np.zeros(n, dtype=np.int64)
+    np.maximum.at(reg, j, lz + 1)
+    return [int(v) for v in reg]
+
+
+def test_reference_hll_size_estimate_within_bounds():
+    # hyperloglog.rs:4554-4564 (10 M items) and :4566-4576 (10 k items), HyperLogLog<128>
+    for count in (10_000_000, 10_000):
+        reg = _np_registers(128, np.arange(count, dtype=np.uint64))
+        if count == 10_000:  # the vectorised add equals the line-by-line one
+            slow = pyref.hll_new(128)
+            for item in range(count):
+                pyref.hll_add(slow, item)
+            assert slow == reg
+        size = pyref.hll_size(reg)
+        lo, hi = pyref.hll_size_bounds(reg)
+        assert lo < size < hi  # all the reference asserts (its FastHasher on sequential ids is far off at 10 M: 18.5 M)
+
+
+def test_reference_hll_merge():
+    # hyperloglog.rs:4578-4598
+    without_merge = _np_registers(128, np.concatenate([np.arange(10_000), np.arange(10_001, 20_000)]).astype(np.uint64))
+    a = _np_registers(128, np.arange(10_000, dtype=np.uint64))
+    b = _np_registers(128, np.arange(10_001, 20_000, dtype=np.uint64))
+    pyref.hll_merge(a, b)
+    assert a == without_merge
+
+
+def test_reference_hll_accurate_counts():
+    # hyperloglog.rs:4600-4611: HyperLogLog<65_536>, after each of 1000 adds |size - count| <= 10
+    reg = pyref.hll_new(65_536)
+    for counter, item in enumerate(range(1_000), start=1):
+        pyref.hll_add(reg, item)
+        assert abs(pyref.hll_size(reg) - counter) <= 10.0, counter
+
+
+def test_generalised_estimator_agrees_with_the_c_oracle_at_64():
+    rng = np.random.default_rng(11)
+    for regs in graphs.random_registers(rng, 300):
+        assert pyref.hll_size([int(x) for x in regs]) == hbo.hll_size(regs)

@@ -1,0 +1,115 @@
+"""Native webgraph column reader (include/hb_webgraph.h, stract_amd/csrc/hb_webgraph.cpp): SURVEY.md §8(f) rank 1.
+CPU tests: reference-held bytes for the sstable framing and the meta.json shape, then whole fixtures written by
+tests/tantivy_fixture.py (a restatement of the reference serialisers - "format unpinned", see its header)."""
+import ctypes
+import os
+import struct
+import zlib
+
+import numpy as np
+import pytest
+
+from stract_amd import _lib, synth, webgraph
+from tests import tantivy_fixture as tf
+
+
+def _sst(bytes_, mode):
+    lib = _lib.load()
+    buf = np.frombuffer(bytes(bytes_), dtype=np.uint8)
+    keys = np.zeros(4096, dtype=np.uint8)
+    ranges = np.zeros(256, dtype=np.uint64)
+    cnt = ctypes.c_uint64(0)
+    rc = lib.hbw_debug_sstable(buf.ctypes.data, len(buf), mode, keys.ctypes.data, len(keys), ranges.ctypes.data, len(ranges),
+                               ctypes.byref(cnt))
+    assert rc == 0, lib.hbw_last_error(None)
+    out, pos = [], 0
+    for i in range(cnt.value):
+        (kl,) = struct.unpack_from("<I", keys, pos)
+        out.append((bytes(keys[pos + 4:pos + 4 + kl]), (int(ranges[2 * i]), int(ranges[2 * i + 1]))))
+        pos += 4 + kl
+    return out
+
+
+def test_sstable_framing_matches_reference_bytes():
+    # crates/tantivy/src/sstable/mod.rs:373-396 test_simple_sstable: the bytes the reference's writer produces
+    golden = bytes([8, 0, 0, 0, 0, 16, 17, 33, 18, 19, 17, 20, 0, 0, 0, 0,
+                    0, 0, 0, 0, 0, 0, 0, 0, 16, 0, 0, 0, 0, 0, 0, 0, 3, 0, 0, 0, 0, 0, 0, 0, 3, 0, 0, 0])
+    assert [k for k, _ in _sst(golden, 0)] == [bytes([17]), bytes([17, 18, 19]), bytes([17, 20])]
+
+
+def test_fixture_dictionary_round_trip():
+    entries = [(b"from_host_id\0\x06", (0, 40)), (b"from_id\0\x06", (40, 77)), (b"rel_flags\0\x01", (77, 100)),
+               (b"sort_score\0\x01", (100, 3000000000)), (b"x" * 40 + b"\0\x01", (3000000000, 2 ** 40))]
+    assert _sst(tf.sstable_ranges(entries), 1) == entries
+    # the writer restatement reproduces the reference's bytes for its own test case (keys only, no values)
+    assert tf.sst_vint(300) == bytes([0xAC, 0x02]) and tf.sst_vint(127) == bytes([127])
+
+
+def test_crc32_is_ieee():
+    rng = np.random.default_rng(5)
+    for n in (0, 1, 7, 8, 9, 1000, 65537):
+        b = rng.integers(0, 256, n, dtype=np.uint8)
+        assert _lib.load().hbw_debug_crc32(b.ctypes.data if n else None, n) == (zlib.crc32(b.tobytes()) & 0xFFFFFFFF)
+
+
+def test_meta_json_reference_shape(tmp_path):
+    # index_meta.rs:436-440: the JSON the reference's own test expects for an index without segments
+    ref = ('{"index_settings":{"sort_by_field":{"field":"text","order":"Asc"},"docstore_compression":"lz4","docstore_blocksize":16384},'
+           '"segments":[],"schema":[{"name":"text","type":"text","options":{"indexing":{"record":"position","fieldnorms":true,'
+           '"tokenizer":"default"},"stored":false,"columnar":false}}],"opstamp":0}')
+    (tmp_path / "meta.json").write_text(ref)
+    with webgraph.EdgeStoreReader(str(tmp_path)) as r:
+        assert r.num_segments() == 0 and r.total_rows() == 0
+        assert len(r.read()) == 0
+
+
+def test_reads_what_the_fixture_writer_wrote(tmp_path):
+    g = synth.RmatGraph(10, 6000)
+    e = g.edges(salt=1, salt_seed=4)
+    parts = [e[:1000], e[1000:1000], e[1000:4321], e[4321:]]  # an empty segment in between
+    ids = tf.write_edge_store(str(tmp_path / "edges"), parts)
+    with webgraph.EdgeStoreReader(str(tmp_path / "edges"), verify_crc=True) as r:
+        assert r.num_segments() == 4 and r.total_rows() == len(e)
+        assert [r.segment_info(i) for i in range(4)] == [(ids[i], len(parts[i])) for i in range(4)]
+        assert np.array_equal(r.read(), e)                       # stream order = segment order, then doc order
+        assert np.array_equal(r.read(990, 20), e[990:1010])      # a window across a segment boundary
+        assert len(r.read(len(e), 0)) == 0
+        with pytest.raises(_lib.HyperballError):
+            r.read(len(e) - 1, 2)
+
+
+def test_corrupt_stores_are_rejected(tmp_path):
+    g = synth.RmatGraph(8, 500)
+    e = g.edges()
+    d = str(tmp_path / "edges")
+    (uid,) = tf.write_edge_store(d, [e])
+    col = os.path.join(d, uid + ".col")
+    good = open(col, "rb").read()
+
+    def expect_fail(data, what, verify_crc=False):
+        open(col, "wb").write(data)
+        with pytest.raises(_lib.HyperballError) as ei:
+            webgraph.EdgeStoreReader(d, verify_crc=verify_crc)
+        assert what in str(ei.value), str(ei.value)
+
+    expect_fail(good[:-4] + struct.pack("<I", 1336), "magic")
+    flipped = bytearray(good)
+    flipped[100] ^= 0x40
+    expect_fail(bytes(flipped), "CRC", verify_crc=True)
+    # a store whose rel_flags column uses another codec than Raw (the reference snapshot never writes one)
+    body = bytearray(tf.columnar_bytes({"from_host_id": (tf.U128, e["from"]), "to_host_id": (tf.U128, e["to"]),
+                                        "rel_flags": (tf.U64, e["rel_flags"])}, len(e)))
+    off = 2 * (1 + 1 + 4 + 32 + 16 * len(e) + 4) + 1  # codec byte of the third column (columns sorted by name: from, rel?, to)
+    names = sorted(["from_host_id", "rel_flags", "to_host_id"])
+    assert names[1] == "rel_flags"
+    off = (1 + 1 + 4 + 32 + 16 * len(e) + 4) + 1
+    assert body[off] == 3
+    body[off] = 0
+    expect_fail(tf.with_footer(bytes(body)), "codec")
+    # a column missing
+    expect_fail(tf.with_footer(tf.columnar_bytes({"from_host_id": (tf.U128, e["from"]), "rel_flags": (tf.U64, e["rel_flags"])}, len(e))),
+                "to_host_id")
+    open(col, "wb").write(good)
+    os.remove(os.path.join(d, "meta.json"))
+    with pytest.raises(_lib.HyperballError):
+        webgraph.EdgeStoreReader(d)

@@ -1,0 +1,110 @@
+//! ref_golden.rs - run the REFERENCE on small graphs and dump what parity needs.
+//!
+//! Not buildable in this repository's image (no rustc / cargo, ~600 un-vendored crates).  On a machine that builds
+//! StractOrg/stract (snapshot 2024-12-20):
+//!
+//!     cp tools/ref_golden.rs  <stract>/crates/core/examples/ref_golden.rs
+//!     printf '\n[[example]]\nname = "ref_golden"\n' >> <stract>/crates/core/Cargo.toml
+//!     cd <stract> && cargo run --release -p stract --example ref_golden -- /tmp/ref_out
+//!     cp /tmp/ref_out/reference_*.json <this repo>/tests/golden/
+//!     cp -r /tmp/ref_out/store_fixture <this repo>/tests/golden/reference_store      # whole edge store, for the column reader
+//!
+//! and `pytest tests` then pins the oracle, the HIP path and the native column reader to the reference with no
+//! other change (tests/test_reference_golden.py).  Every graph goes through `Webgraph::insert`
+//! (crates/core/src/webgraph/mod.rs:106), is read back through the same `host_edges()` the algorithm uses
+//! (mod.rs:192), and is scored by `HarmonicCentrality::calculate` (centrality/harmonic.rs:292).
+//!
+//! Output, one JSON file per graph:
+//!   { "name": ..., "edges": [[from_hex32, to_hex32, rel_flags_u64], ...]   // host_edges() stream, AFTER its unique_by
+//!     "centrality": [[id_hex32, f64_bits_hex16], ...] }                     // HarmonicCentrality::iter(), ascending id
+use std::fmt::Write as _;
+use std::path::Path;
+
+use stract::webgraph::centrality::harmonic::HarmonicCentrality;
+use stract::webgraph::{Edge, Node, Webgraph};
+use stract::webpage::html::links::RelFlags;
+
+fn build(path: &Path, edges: &[(String, String, RelFlags)], commit_every: usize) -> Webgraph {
+    let mut graph = Webgraph::builder(path, 0u64.into()).open().unwrap();
+    for (i, (from, to, flags)) in edges.iter().enumerate() {
+        graph
+            .insert(Edge {
+                from: Node::from_str_not_validated(from),
+                to: Node::from_str_not_validated(to),
+                rel_flags: *flags,
+                ..Edge::empty()
+            })
+            .unwrap();
+        if (i + 1) % commit_every == 0 {
+            graph.commit().unwrap(); // several segments: exercises the cross-segment first-occurrence rule
+        }
+    }
+    graph.commit().unwrap();
+    graph
+}
+
+fn dump(name: &str, graph: &Webgraph, out_dir: &Path) {
+    let mut s = String::new();
+    write!(s, "{{\"name\":\"{name}\",\"edges\":[").unwrap();
+    for (i, e) in graph.host_edges().enumerate() {
+        if i > 0 {
+            s.push(',');
+        }
+        write!(s, "[\"{:032x}\",\"{:032x}\",{}]", e.from.as_u128(), e.to.as_u128(), e.rel_flags.as_u64()).unwrap();
+    }
+    s.push_str("],\"centrality\":[");
+    let hc = HarmonicCentrality::calculate(graph);
+    for (i, (id, c)) in hc.iter().enumerate() {
+        if i > 0 {
+            s.push(',');
+        }
+        write!(s, "[\"{:032x}\",\"{:016x}\"]", id.as_u128(), c.to_bits()).unwrap();
+    }
+    s.push_str("]}");
+    std::fs::write(out_dir.join(format!("reference_{name}.json")), s).unwrap();
+}
+
+fn main() {
+    let out = std::env::args().nth(1).expect("usage: ref_golden <out dir>");
+    let out = Path::new(&out);
+    std::fs::create_dir_all(out).unwrap();
+    let none = RelFlags::default();
+
+    // 1. the fixture of the reference's own tests (harmonic.rs:323-341)
+    let fixture: Vec<(String, String, RelFlags)> = [("A", "B"), ("B", "C"), ("A", "C"), ("C", "A"), ("D", "C")]
+        .iter()
+        .map(|(a, b)| (format!("{a}.com"), format!("{b}.com"), none))
+        .collect();
+    dump("fixture", &build(&out.join("g_fixture"), &fixture, usize::MAX), out);
+
+    // 2. SURVEY.md Appendix B: n = 200 hosts, 1200 unique non-self edges from a 64-bit LCG, three commits
+    let (mut x, n) = (12345u64, 200u64);
+    let mut lcg = || {
+        x = x.wrapping_mul(6364136223846793005).wrapping_add(1442695040888963407);
+        (x >> 33) % n + 1
+    };
+    let mut seen = std::collections::BTreeSet::new();
+    while seen.len() < 1200 {
+        let (f, t) = (lcg(), lcg());
+        if f != t {
+            seen.insert((f, t));
+        }
+    }
+    let lcg_edges: Vec<_> = seen.iter().map(|(f, t)| (format!("host{f}.com"), format!("host{t}.com"), none)).collect();
+    dump("lcg200", &build(&out.join("g_lcg"), &lcg_edges, 500), out);
+
+    // 3. ingest semantics: flagged first occurrences, later clean copies, duplicates across commits, self links
+    let mut salted = lcg_edges.clone();
+    for (i, e) in lcg_edges.iter().enumerate().take(300) {
+        if i % 3 == 0 {
+            salted.insert(i, (e.0.clone(), e.1.clone(), RelFlags::NOFOLLOW)); // flagged copy BEFORE the clean one: pair is lost
+        } else if i % 3 == 1 {
+            salted.push((e.0.clone(), e.1.clone(), RelFlags::TAG)); // flagged copy AFTER: ignored
+        } else {
+            salted.push((e.0.clone(), e.0.clone(), none)); // self link
+        }
+    }
+    let g = build(&out.join("store_fixture"), &salted, 400);
+    dump("salted", &g, out);
+    // out/store_fixture/edges now holds meta.json + the .col files of this graph: the fixture for the native column reader
+}
