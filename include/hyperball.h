@@ -172,8 +172,11 @@ const char *hb_last_error(const hb_ctx *ctx);
  * (from,to) pair must go to the same rank, in stream order. */
 int hb_load_edges(hb_ctx *ctx, const hb_u128 *node_ids, uint64_t n, const hb_edge *edges,
                   uint64_t m);
-/* Chunked variant for callers that cannot hold all records: append any number of times,
- * then finalize (node_ids as above). */
+/* Streamed variant for callers that cannot (or need not) hold all records: append any number of batches in stream
+ * order, then finalize (node_ids as above).  Every batch is uploaded and unpacked on the device at once (2 x 16-byte
+ * endpoint keys + 1 flag byte per record stay resident there); nothing is buffered on the host, so the caller's
+ * peak memory is one batch.  With HB_FLAG_HOST_INGEST, or if the device runs out of memory mid-stream, the
+ * records are buffered on the host instead (same result). */
 int hb_append_edges(hb_ctx *ctx, const hb_edge *edges, uint64_t m);
 int hb_finalize(hb_ctx *ctx, const hb_u128 *node_ids, uint64_t n);
 

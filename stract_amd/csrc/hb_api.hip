@@ -39,7 +39,12 @@ struct hb_ctx {
     std::string arch;
 
     // host-side graph / plan
-    std::vector<hb_edge> pending;  // hb_append_edges
+    std::vector<hb_edge> pending;  // hb_append_edges, host-ingest mode only
+    // hb_append_edges, default: records are unpacked on the device as they arrive (2 x 16-byte endpoint keys + 1
+    // flag byte each); nothing is buffered on the host
+    void *d_app_end = nullptr;
+    uint8_t *d_app_bad = nullptr;
+    uint64_t app_count = 0, app_cap = 0;
     DenseGraph g;                  // ids kept; row_ptr/src kept only for hb_debug_copy_graph
     Plan plan;
     bool loaded = false, begun = false, finished = false;
@@ -731,6 +736,33 @@ int guarded(hb_ctx *c, F &&f)
     }
 }
 
+// records appended so far live on the device as (from key, to key) pairs + flag bytes: turn them back into hb_edge
+// records on the host (rel_flags collapses to "skipped or not", all the reduction needs) - only when the device
+// ran out of memory in the middle of a stream
+int spill_appended_to_host(hb_ctx *c)
+{
+    const uint64_t k = c->app_count;
+    if (k) {
+        std::vector<hb_u128> keys(2 * k);
+        std::vector<uint8_t> bad(k);
+        HB_HIP(hipMemcpyAsync(keys.data(), c->d_app_end, k * 32, hipMemcpyDeviceToHost, c->stream));
+        HB_HIP(hipMemcpyAsync(bad.data(), c->d_app_bad, k, hipMemcpyDeviceToHost, c->stream));
+        HB_HIP(hipStreamSynchronize(c->stream));
+        c->pending.resize(k);
+        for (uint64_t i = 0; i < k; i++) {
+            c->pending[i].from = keys[2 * i];
+            c->pending[i].to = keys[2 * i + 1];
+            c->pending[i].rel_flags = bad[i] ? HB_SKIPPED_REL_MASK : 0;
+        }
+    }
+    if (c->d_app_end) (void)hipFree(c->d_app_end);
+    if (c->d_app_bad) (void)hipFree(c->d_app_bad);
+    c->d_app_end = nullptr;
+    c->d_app_bad = nullptr;
+    c->app_count = c->app_cap = 0;
+    return HB_OK;
+}
+
 int set_device(hb_ctx *c)
 {
     HB_HIP(hipSetDevice(c->device));
@@ -835,6 +867,8 @@ void hb_destroy(hb_ctx *ctx)
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     if (ctx->comm) (void)ncclCommDestroy(ctx->comm);
+    if (ctx->d_app_end) (void)hipFree(ctx->d_app_end);
+    if (ctx->d_app_bad) (void)hipFree(ctx->d_app_bad);
     free_graph_buffers(ctx);
     if (ctx->h_counters) (void)hipHostFree(ctx->h_counters);
     for (int i = 0; i < 6; i++)
@@ -904,21 +938,86 @@ int hb_load_edges(hb_ctx *c, const hb_u128 *node_ids, uint64_t n, const hb_edge 
 
 int hb_append_edges(hb_ctx *c, const hb_edge *edges, uint64_t m)
 {
-    if (!c || (m && !edges)) return c ? fail(c, HB_ERR_INVALID, "edges == NULL") : HB_ERR_INVALID;
-    try {
+    return guarded(c, [&]() -> int {
+        if (!c || (m && !edges)) return c ? fail(c, HB_ERR_INVALID, "edges == NULL") : HB_ERR_INVALID;
+        if (!m) return HB_OK;
+        int rc = set_device(c);
+        if (rc) return rc;
+        const bool on_host = (c->opt.flags & HB_FLAG_HOST_INGEST) != 0 || !c->pending.empty();
+        if (!on_host) {
+            // grow the device arrays (amortised doubling), then unpack this batch behind what is already there
+            const uint64_t need = c->app_count + m;
+            hipError_t e = hipSuccess;
+            if (need > c->app_cap) {
+                const uint64_t cap = std::max<uint64_t>(need, std::max<uint64_t>(2 * c->app_cap, 1ull << 20));
+                void *n_end = nullptr;
+                uint8_t *n_bad = nullptr;
+                e = hipMalloc(&n_end, cap * 32);
+                if (e == hipSuccess) e = hipMalloc((void **)&n_bad, cap);
+                if (e == hipSuccess && c->app_count) {
+                    e = hipMemcpyAsync(n_end, c->d_app_end, c->app_count * 32, hipMemcpyDeviceToDevice, c->stream);
+                    if (e == hipSuccess) e = hipMemcpyAsync(n_bad, c->d_app_bad, c->app_count, hipMemcpyDeviceToDevice, c->stream);
+                    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+                }
+                if (e == hipSuccess) {
+                    if (c->d_app_end) (void)hipFree(c->d_app_end);
+                    if (c->d_app_bad) (void)hipFree(c->d_app_bad);
+                    c->d_app_end = n_end;
+                    c->d_app_bad = n_bad;
+                    c->app_cap = cap;
+                } else {
+                    if (n_end) (void)hipFree(n_end);
+                    if (n_bad) (void)hipFree(n_bad);
+                    (void)hipGetLastError();
+                }
+            }
+            if (e == hipSuccess) {
+                const std::string err = gpu_ingest_unpack((void *)c->stream, edges, m, c->app_count, c->d_app_end, c->d_app_bad);
+                if (!err.empty()) return fail(c, HB_ERR_HIP, err);
+                c->app_count += m;
+                return HB_OK;
+            }
+            // the device cannot hold the stream: bring back what is there and continue on the host
+            rc = spill_appended_to_host(c);
+            if (rc) return rc;
+        }
         c->pending.insert(c->pending.end(), edges, edges + m);
-    } catch (const std::bad_alloc &) {
-        return fail(c, HB_ERR_NOMEM, "out of host memory buffering edges");
-    }
-    return HB_OK;
+        return HB_OK;
+    });
 }
 
 int hb_finalize(hb_ctx *c, const hb_u128 *node_ids, uint64_t n)
 {
     return guarded(c, [&]() -> int {
         if (!c) return HB_ERR_INVALID;
-        int rc = hb_load_edges(c, node_ids, n, c->pending.data(), c->pending.size());
-        std::vector<hb_edge>().swap(c->pending);
+        int rc = set_device(c);
+        if (rc) return rc;
+        if (!c->d_app_end) { // host mode (or nothing appended)
+            rc = hb_load_edges(c, node_ids, n, c->pending.data(), c->pending.size());
+            std::vector<hb_edge>().swap(c->pending);
+            return rc;
+        }
+        c->stats = hb_stats{};
+        const double t0 = now_ms();
+        void *d_end = c->d_app_end;
+        uint8_t *d_bad = c->d_app_bad;
+        const uint64_t m = c->app_count;
+        c->d_app_end = nullptr;
+        c->d_app_bad = nullptr;
+        c->app_count = c->app_cap = 0;
+        DeviceCsr csr;
+        const bool keep_on_device = device_plan(c);
+        const std::string e = gpu_ingest_reduce((void *)c->stream, node_ids, n, d_end, d_bad, m, &c->g, keep_on_device ? &csr : nullptr);
+        if (!e.empty())
+            return fail(c, e.find("memory") != std::string::npos ? HB_ERR_NOMEM : (e.find("hip") != std::string::npos ? HB_ERR_HIP : HB_ERR_LIMIT), e);
+        if (dest_mode(c)) keep_owned_rows(&c->g, (uint64_t)std::max(c->opt.world_size, 1), (uint64_t)c->opt.rank);
+        const uint64_t nn = c->g.ids.size();
+        const uint64_t m_eff = csr.d_row_ptr ? csr.m : (nn && c->g.row_ptr.size() == nn + 1 ? c->g.row_ptr[nn] : 0);
+        const double ing = now_ms() - t0;
+        rc = plan_and_upload(c, csr.d_row_ptr ? &csr : nullptr, m_eff);
+        if (csr.d_row_ptr) (void)hipFree(csr.d_row_ptr);
+        if (csr.d_src) (void)hipFree(csr.d_src);
+        c->stats.ms_ingest = ing;
         return rc;
     });
 }

@@ -165,18 +165,79 @@ unsigned grid_for(uint64_t count) { return (unsigned)((count + 255) / 256); }
 
 namespace hb {
 
+// Records -> device: endpoint keys (2 per record, stream order) and "flagged" bytes, written at record offset `base`
+// of buffers that hold at least base + m records.  Slab-wise H2D through two staging buffers.
+std::string gpu_ingest_unpack(void *stream_v, const hb_edge *edges, uint64_t m, uint64_t base, void *d_end_v, uint8_t *d_bad)
+{
+    hipStream_t stream = (hipStream_t)stream_v;
+    u128 *d_end = (u128 *)d_end_v;
+    if (!m) return "";
+    DevMem mem;
+    const uint64_t slab = 1ull << 22; // 4 Mi records = 160 MiB per slab, two slabs in flight
+    hb_edge *d_slab[2] = {nullptr, nullptr};
+    IG_HIP(mem.alloc(&d_slab[0], std::min<uint64_t>(slab, m)));
+    IG_HIP(mem.alloc(&d_slab[1], std::min<uint64_t>(slab, m)));
+    struct Events { // destroyed on every exit path
+        hipEvent_t e[2] = {nullptr, nullptr};
+        ~Events()
+        {
+            for (hipEvent_t x : e)
+                if (x) (void)hipEventDestroy(x);
+        }
+    } evs;
+    hipEvent_t *done = evs.e;
+    IG_HIP(hipEventCreateWithFlags(&done[0], hipEventDisableTiming));
+    IG_HIP(hipEventCreateWithFlags(&done[1], hipEventDisableTiming));
+    int b = 0;
+    for (uint64_t off = 0; off < m; off += slab, b ^= 1) {
+        const uint64_t cnt = std::min(slab, m - off);
+        IG_HIP(hipEventSynchronize(done[b])); // the kernel that last read this slab buffer has finished
+        IG_HIP(hipMemcpyAsync(d_slab[b], edges + off, cnt * sizeof(hb_edge), hipMemcpyHostToDevice, stream));
+        hipLaunchKernelGGL(unpack_kernel, dim3(grid_for(cnt)), dim3(256), 0, stream, (const hb_edge *)d_slab[b], cnt, base + off, d_end, d_bad);
+        IG_HIP(hipGetLastError());
+        IG_HIP(hipEventRecord(done[b], stream));
+    }
+    IG_HIP(hipStreamSynchronize(stream));
+    return "";
+}
+
 std::string gpu_ingest_edges(void *stream_v, const hb_u128 *node_ids, uint64_t n_in, const hb_edge *edges, uint64_t m,
                              DenseGraph *out, DeviceCsr *keep)
 {
     if (keep) *keep = DeviceCsr{};
+    if (m && !edges) return "edges == NULL with m > 0";
+    void *d_end = nullptr;
+    uint8_t *d_bad = nullptr;
+    if (hipMalloc(&d_end, std::max<uint64_t>(2 * m * 16, 256)) != hipSuccess) return "hipMalloc(endpoint keys): out of memory";
+    if (hipMalloc((void **)&d_bad, std::max<uint64_t>(m, 256)) != hipSuccess) {
+        (void)hipFree(d_end);
+        return "hipMalloc(flag bytes): out of memory";
+    }
+    std::string e = gpu_ingest_unpack(stream_v, edges, m, 0, d_end, d_bad);
+    if (!e.empty()) {
+        (void)hipFree(d_end);
+        (void)hipFree(d_bad);
+        return e;
+    }
+    return gpu_ingest_reduce(stream_v, node_ids, n_in, d_end, d_bad, m, out, keep);
+}
+
+// The reduction proper, from records that are already on the device (gpu_ingest_unpack); takes ownership of
+// d_end_v / d_bad (hipMalloc'ed) and frees them as soon as they are no longer needed.
+std::string gpu_ingest_reduce(void *stream_v, const hb_u128 *node_ids, uint64_t n_in, void *d_end_v, uint8_t *d_bad, uint64_t m,
+                              DenseGraph *out, DeviceCsr *keep)
+{
     hipStream_t stream = (hipStream_t)stream_v;
+    if (keep) *keep = DeviceCsr{};
     out->ids.clear();
     out->row_ptr.clear();
     out->src.clear();
     out->m_input = m;
     out->m_unique = 0;
-    if (m && !edges) return "edges == NULL with m > 0";
     DevMem mem;
+    mem.ptrs.push_back(d_end_v);
+    mem.ptrs.push_back(d_bad);
+    u128 *d_end = (u128 *)d_end_v; // 2m endpoint keys in stream order
     void *tmp = nullptr;
     size_t tmp_bytes = 0;
     auto need_tmp = [&](size_t bytes) -> hipError_t {
@@ -188,41 +249,6 @@ std::string gpu_ingest_edges(void *stream_v, const hb_u128 *node_ids, uint64_t n
         tmp = p;
         return e;
     };
-
-    // ---- records -> endpoint keys + flagged bytes (slab-wise H2D)
-    u128 *d_end = nullptr; // 2m endpoint keys in stream order
-    uint8_t *d_bad = nullptr;
-    IG_HIP(mem.alloc(&d_end, 2 * m));
-    IG_HIP(mem.alloc(&d_bad, m));
-    {
-        const uint64_t slab = 1ull << 22; // 4 Mi records = 160 MiB per slab, two slabs in flight
-        hb_edge *d_slab[2] = {nullptr, nullptr};
-        IG_HIP(mem.alloc(&d_slab[0], std::min<uint64_t>(slab, std::max<uint64_t>(m, 1))));
-        IG_HIP(mem.alloc(&d_slab[1], std::min<uint64_t>(slab, std::max<uint64_t>(m, 1))));
-        struct Events { // destroyed on every exit path
-            hipEvent_t e[2] = {nullptr, nullptr};
-            ~Events()
-            {
-                for (hipEvent_t x : e)
-                    if (x) (void)hipEventDestroy(x);
-            }
-        } evs;
-        hipEvent_t *done = evs.e;
-        IG_HIP(hipEventCreateWithFlags(&done[0], hipEventDisableTiming));
-        IG_HIP(hipEventCreateWithFlags(&done[1], hipEventDisableTiming));
-        int b = 0;
-        for (uint64_t base = 0; base < m; base += slab, b ^= 1) {
-            const uint64_t cnt = std::min(slab, m - base);
-            IG_HIP(hipEventSynchronize(done[b])); // the kernel that last read this slab buffer has finished
-            IG_HIP(hipMemcpyAsync(d_slab[b], edges + base, cnt * sizeof(hb_edge), hipMemcpyHostToDevice, stream));
-            hipLaunchKernelGGL(unpack_kernel, dim3(grid_for(cnt)), dim3(256), 0, stream, (const hb_edge *)d_slab[b], cnt, base, d_end, d_bad);
-            IG_HIP(hipGetLastError());
-            IG_HIP(hipEventRecord(done[b], stream));
-        }
-        IG_HIP(hipStreamSynchronize(stream));
-        mem.release(d_slab[0]);
-        mem.release(d_slab[1]);
-    }
 
     // ---- node set: sorted unique u128 keys
     const uint64_t cand = (node_ids && n_in) ? n_in : 2 * m;

@@ -151,6 +151,11 @@ void keep_owned_rows(DenseGraph *g, uint64_t world, uint64_t rank);
 std::string gpu_ingest_edges(void *stream, const hb_u128 *node_ids, uint64_t n, const hb_edge *edges, uint64_t m,
                              DenseGraph *out, struct DeviceCsr *keep = nullptr);
 constexpr uint64_t kKeepHostGraph = 1ull << 26;
+// the two halves of gpu_ingest_edges, for streamed input (hb_append_edges): unpack slabs of records into device
+// arrays of 2 x 16-byte endpoint keys + 1 flag byte per record as they arrive, reduce once at hb_finalize
+std::string gpu_ingest_unpack(void *stream, const hb_edge *edges, uint64_t m, uint64_t base, void *d_end, uint8_t *d_bad);
+std::string gpu_ingest_reduce(void *stream, const hb_u128 *node_ids, uint64_t n, void *d_end, uint8_t *d_bad, uint64_t m, DenseGraph *out,
+                              struct DeviceCsr *keep);
 std::string check_dense(const hb_u128 *sorted_ids, uint64_t n, const uint64_t *row_ptr,
                         const uint32_t *src, uint64_t m);
 // out_degree[sid] over the local edges.

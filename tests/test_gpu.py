@@ -220,6 +220,27 @@ def test_salted_edge_records_match_faithful_oracle(gpu_ctx_factory):
     assert np.array_equal(ids2, fids) and np.array_equal(vals2.view(np.uint64), fvals.view(np.uint64))
 
 
+def test_load_webgraph_from_edge_store(gpu_ctx_factory, tmp_path):
+    """hb_load_webgraph: the native column reader (include/hb_webgraph.h) streams an on-disk edge store - three
+    segments written by tests/tantivy_fixture.py - into the library; result = the faithful oracle on the same records."""
+    from stract_amd import webgraph
+    from tests import tantivy_fixture as tf
+    g = synth.RmatGraph(12, 30_000)
+    e = g.edges(salt=1, salt_seed=5)
+    fids, fvals, fst = hbo.faithful_run(e)
+    tf.write_edge_store(str(tmp_path / "edges"), [e[:7000], e[7000:7001], e[7001:]])
+    for flags in (0, _lib.HB_FLAG_HOST_INGEST, _lib.HB_FLAG_HOST_PLAN):
+        with gpu_ctx_factory(flags=flags) as ctx:
+            webgraph.load_webgraph(ctx, str(tmp_path / "edges"), verify_crc=True)
+            st = ctx.run()
+            ids, vals = ctx.results()
+        assert st["n"] == fst["n"] and st["m_unique"] == fst["m_unique"] and st["m_eff"] == fst["m_eff"] and st["passes"] == fst["passes"]
+        assert np.array_equal(ids, fids) and np.array_equal(vals.view(np.uint64), fvals.view(np.uint64))
+    with gpu_ctx_factory() as ctx:
+        with pytest.raises(_lib.HyperballError):
+            webgraph.load_webgraph(ctx, str(tmp_path / "nothing_here"))
+
+
 def test_result_ranks_match_store_harmonic_order(gpu_ctx_factory):
     # centrality/mod.rs:92-103: harmonic_rank = position by (Reverse(total_cmp(centrality)), NodeID)
     g = synth.RmatGraph(13, 60_000)
