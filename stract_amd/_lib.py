@@ -150,6 +150,16 @@ _SIGNATURES += [
     ("hbw_debug_sstable", ctypes.c_int, [_P, _U64, ctypes.c_int, _P, _U64, _P, _U64, ctypes.POINTER(_U64)]),
     ("hbw_debug_crc32", ctypes.c_uint32, [_P, _U64]),
 ]
+# include/hb_ampc.h
+_SIGNATURES += [
+    ("hbu_create", ctypes.c_int, [ctypes.c_int32, _U64, ctypes.POINTER(_P)]),
+    ("hbu_destroy", None, [_P]),
+    ("hbu_last_error", ctypes.c_char_p, [_P]),
+    ("hbu_len", ctypes.c_int, [_P, ctypes.POINTER(_U64)]),
+    ("hbu_batch_set", ctypes.c_int, [_P, _P, _P, _U64]),
+    ("hbu_batch_get", ctypes.c_int, [_P, _P, _U64, _P, _P]),
+    ("hbu_batch_upsert", ctypes.c_int, [_P, _P, _P, _U64, _P]),
+]
 SYMBOLS = [s[0] for s in _SIGNATURES]
 
 _lib = None

@@ -329,6 +329,63 @@ def test_randomized_graphs_and_knobs(gpu_ctx_factory):
                 assert np.array_equal(ctx.registers(), o.registers()), what
 
 
+# ---- AMPC operator ------------------------------------------------------------------------------------
+def test_ampc_counter_table_upsert_semantics(gpu_ctx_factory):
+    """include/hb_ampc.h: batch_set / batch_get / batch_upsert(HyperLogLog64Upsert) on a GPU-resident table shard
+    against a dict that applies the pairs in order exactly like dht/store.rs:159-190 + upsert.rs:67-89."""
+    from stract_amd import ampc
+    rng = np.random.default_rng(23)
+    model = {}
+    keyspace = np.zeros(400, dtype=_lib.U128)
+    keyspace["lo"] = rng.integers(0, 1 << 63, 400, dtype=np.uint64)
+    keyspace["hi"] = rng.integers(0, 1 << 63, 400, dtype=np.uint64)
+    kid = lambda k: (int(k["hi"]) << 64) | int(k["lo"])
+    with ampc.CounterTable(capacity_hint=16) as tab:
+        for step in range(12):
+            n = int(rng.integers(1, 3000))
+            idx = rng.integers(0, len(keyspace), n)  # many repeated keys inside one batch
+            keys = keyspace[idx]
+            vals = graphs.random_registers(rng, n)
+            if step % 4 == 3:  # batch_set: later pairs win
+                tab.batch_set(keys, vals)
+                for k, v in zip(keys, vals):
+                    model[kid(k)] = v.copy()
+                continue
+            acts = tab.batch_upsert(keys, vals)
+            want = []
+            for k, v in zip(keys, vals):
+                old = model.get(kid(k))
+                if old is None:
+                    model[kid(k)] = v.copy()
+                    want.append(ampc.INSERTED)
+                else:
+                    merged = np.maximum(old, v)  # HyperLogLog::merge, hyperloglog.rs:4531-4535
+                    want.append(ampc.MERGED if not np.array_equal(merged, old) else ampc.NO_CHANGE)
+                    model[kid(k)] = merged
+            assert acts.tolist() == want, step
+            assert len(tab) == len(model)
+            got, found = tab.batch_get(keyspace)
+            for k, g_, f in zip(keyspace, got, found):
+                assert f == (kid(k) in model)
+                assert np.array_equal(g_, model.get(kid(k), np.zeros(64, np.uint8)))
+        # one pass of the distributed algorithm's counter update on a small graph == one dense pass of the oracle
+        g = synth.RmatGraph(9, 3000)
+        o = hbo.Dense(g.id_low64(), g.row_ptr, g.src)
+    with ampc.CounterTable() as prev, ampc.CounterTable() as nxt:
+        regs0 = o.registers()
+        prev.batch_set(g.ids, regs0)   # setup_counters, mapper.rs:64-88
+        nxt.batch_set(g.ids, regs0)
+        dst = np.repeat(np.arange(g.n), np.diff(g.row_ptr).astype(np.int64))
+        old, _ = prev.batch_get(g.ids[g.src])                          # get_old_counters
+        acts = nxt.batch_upsert(g.ids[dst], old)                       # update_counters
+        o.step(0)
+        got, _ = nxt.batch_get(g.ids)
+        assert np.array_equal(got, o.registers())
+        changed = np.zeros(g.n, dtype=bool)
+        changed[dst[acts == ampc.MERGED]] = True
+        assert np.array_equal(changed, np.any(o.registers() != regs0, axis=1))
+
+
 # ---- device planner ------------------------------------------------------------------------------
 def test_device_plan_equals_host_plan(gpu_ctx_factory):
     """hb_plan.hip (rocPRIM sorts / scans on the device) must reproduce build_plan() of hb_host.cpp entry for entry:
