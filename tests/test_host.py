@@ -19,7 +19,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def test_header_symbols_all_exported():
     hdr = "".join(open(os.path.join(ROOT, "include", f)).read() for f in sorted(os.listdir(os.path.join(ROOT, "include"))))
     hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
-    declared = set(re.findall(r"\b(hbw?_[a-z0-9_]+)\s*\(", hdr))
+    declared = set(re.findall(r"\b(hb[wu]?_[a-z0-9_]+)\s*\(", hdr))
     assert declared, "no declarations parsed"
     lib = ctypes.CDLL(_lib.LIB_PATH)
     missing = [s for s in sorted(declared) if not hasattr(lib, s)]
