@@ -10,7 +10,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libhyperball.so")
+LIB_PATH = os.environ.get("HB_LIB_PATH") or os.path.join(_HERE, "lib", "libhyperball.so")  # HB_LIB_PATH: experiment builds
 
 HB_OK = 0
 HB_ERR_INVALID, HB_ERR_NO_DEVICE, HB_ERR_HIP, HB_ERR_NOMEM, HB_ERR_RCCL, HB_ERR_LIMIT = -1, -2, -3, -4, -5, -6

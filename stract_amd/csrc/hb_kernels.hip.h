@@ -28,6 +28,37 @@ namespace hbk {
 
 constexpr uint32_t kNone = 0xFFFFFFFFu;
 constexpr int kTableLen = 159;
+
+// Streams that are read or written exactly once per pass (row pointers, source indices, per-row Kahan / size
+// words, the freshly written counters): with HB_STREAM_NT they bypass-hint the caches (nontemporal), leaving the
+// L2 to the gathered counters.  Experiment switch, see profiles/r02*_stream_nt*.
+#ifndef HB_STREAM_NT
+#define HB_STREAM_NT 0
+#endif
+template <class T>
+__device__ __forceinline__ T ld_stream(const T *p)
+{
+#if HB_STREAM_NT
+    return __builtin_nontemporal_load(p);
+#else
+    return *p;
+#endif
+}
+template <class T>
+__device__ __forceinline__ void st_stream(T *p, const T &v)
+{
+    *p = v;
+}
+__device__ __forceinline__ void st_stream(uint4 *p, const uint4 &v)
+{
+#if HB_STREAM_NT
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    u32x4 w = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(w, (u32x4 *)p);
+#else
+    *p = v;
+#endif
+}
 // Per-pass counters are striped: kStripes copies of 4 words, a block adds to stripe blockIdx % kStripes
 // (one same-address atomic stream sustains only ~90 updates/us; 8192 waves finishing together made a
 // 0.1 ms tail).  The host sums the stripes.
@@ -264,9 +295,9 @@ __global__ __launch_bounds__(256) void pass_kernel(const PassParams p)
     {
         const uint64_t r0 = row_lo + (tile0 << 6) + ((uint64_t)wave << 4) + (uint64_t)g;
         if (tile0 < ntiles && r0 < row_hi) {
-            nbeg = p.row_ptr[r0];
-            nend = p.row_ptr[r0 + 1];
-            if (REAL && FUSED) nod = p.outdeg[r0];
+            nbeg = ld_stream(&p.row_ptr[r0]);
+            nend = ld_stream(&p.row_ptr[r0 + 1]);
+            if (REAL && FUSED) nod = ld_stream(&p.outdeg[r0]);
             if (kDenseReal) nself = p.rd[r0 * 4 + q];
         }
     }
@@ -283,9 +314,9 @@ __global__ __launch_bounds__(256) void pass_kernel(const PassParams p)
             nod = 0;
             nself = make_uint4(0, 0, 0, 0);
             if (tile + tstride < ntiles && nrow < row_hi) {
-                nbeg = p.row_ptr[nrow];
-                nend = p.row_ptr[nrow + 1];
-                if (REAL && FUSED) nod = p.outdeg[nrow];
+                nbeg = ld_stream(&p.row_ptr[nrow]);
+                nend = ld_stream(&p.row_ptr[nrow + 1]);
+                if (REAL && FUSED) nod = ld_stream(&p.outdeg[nrow]);
                 if (kDenseReal) nself = p.rd[nrow * 4 + q];
             }
         }
@@ -293,10 +324,10 @@ __global__ __launch_bounds__(256) void pass_kernel(const PassParams p)
         uint64_t pre_sz = 0;
         double pre_ks = 0.0, pre_ke = 0.0;
         if (kDenseReal && FUSED && valid) {
-            pre_sz = p.size[row];
+            pre_sz = ld_stream(&p.size[row]);
             if (q == 0) {
-                pre_ks = p.ksum[row];
-                pre_ke = p.kerr[row];
+                pre_ks = ld_stream(&p.ksum[row]);
+                pre_ke = ld_stream(&p.kerr[row]);
             }
         }
         const uint4 *selfp = REAL ? (p.rd + row * 4 + q) : (p.part + (row - p.n_pad) * 4 + q);
@@ -317,7 +348,7 @@ __global__ __launch_bounds__(256) void pass_kernel(const PassParams p)
 #pragma unroll
                 for (int u = 0; u < UNROLL; u++) {
                     uint64_t ee = e + 4 * u + q;
-                    idx[u] = (ee < end) ? p.src[ee] : kNone;
+                    idx[u] = (ee < end) ? ld_stream(&p.src[ee]) : kNone;
                 }
                 if (FRONTIER) {
 #pragma unroll
@@ -395,9 +426,9 @@ __global__ __launch_bounds__(256) void pass_kernel(const PassParams p)
         if (REAL) {
             // lazy double buffer: wr[row] already holds the right value unless the row changed
             // in this or in the previous pass
-            if (need && (!FRONTIER || changed || self_prev)) p.wr[row * 4 + q] = accv;
+            if (need && (!FRONTIER || changed || self_prev)) st_stream(&p.wr[row * 4 + q], accv);
         } else {
-            if (changed) p.part[(row - p.n_pad) * 4 + q] = accv;
+            if (changed) st_stream(&p.part[(row - p.n_pad) * 4 + q], accv);
         }
         const uint32_t ch16 = pack16(bal);
         if (FUSED || (!REAL && FRONTIER)) {
