@@ -1084,6 +1084,7 @@ int hb_begin(hb_ctx *c)
         int rc = set_device(c);
         if (rc) return rc;
         const Plan &p = c->plan;
+        if (p.n_pad * 4 >= 0xFFFFFFFFull) return fail(c, HB_ERR_LIMIT, "more than 2^30 nodes: init_kernel is one quad per node in one dispatch");
         {
             hipError_t stale = hipGetLastError(); // an unchecked failure of an earlier call on this thread
             if (stale != hipSuccess) return fail(c, HB_ERR_HIP, std::string("stale HIP error before hb_begin: ") + hipGetErrorString(stale));

@@ -237,6 +237,8 @@ std::string gpu_ingest_reduce(void *stream_v, const hb_u128 *node_ids, uint64_t 
     DevMem mem;
     mem.ptrs.push_back(d_end_v);
     mem.ptrs.push_back(d_bad);
+    // one-thread-per-record kernels below: a dispatch holds at most 2^32 - 1 work-items
+    if (m >= 0xFFFFFF00ull) return "too many records for the device ingest (2^32 limit): use HB_FLAG_HOST_INGEST";
     u128 *d_end = (u128 *)d_end_v; // 2m endpoint keys in stream order
     void *tmp = nullptr;
     size_t tmp_bytes = 0;

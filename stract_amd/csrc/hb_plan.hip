@@ -136,7 +136,10 @@ struct DevMem {
     }
 };
 
+// one thread per item; a dispatch is limited to 2^32 - 1 work-items, so callers with more items than that must use
+// grid-stride kernels and grid_strided()
 unsigned grid_for(uint64_t count, unsigned per_block = 256) { return (unsigned)std::max<uint64_t>(1, (count + per_block - 1) / per_block); }
+unsigned grid_strided(uint64_t count) { return (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((count + 255) / 256, 1u << 22)); }
 int bits_for(uint64_t v) // number of bits needed to represent values < v
 {
     int b = 1;
@@ -199,20 +202,20 @@ __global__ __launch_bounds__(256) void row_start_kernel(const uint64_t *row_ptr,
     const uint64_t b = row_ptr[v];
     if (row_ptr[v + 1] > b) rowid[b] = (uint32_t)v;
 }
+// (grid-stride: one dispatch holds at most 2^32 - 1 work-items, graphs here have up to 5.3 G edges)
 __global__ __launch_bounds__(256) void edge_keys_kernel(const uint32_t *rowid, const uint32_t *src, uint64_t m, const uint32_t *dev_of,
                                                         uint64_t slice, uint64_t world, uint64_t *key)
 {
-    const uint64_t e = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-    if (e >= m) return;
-    const uint64_t d = dev_of[rowid[e]];
-    const uint64_t idx = dev_of[src[e]];
-    const uint64_t hr = world == 1 ? idx : (idx % slice) * world + idx / slice; // hotness rank of a device position
-    key[e] = (d << 32) | hr;
+    for (uint64_t e = (uint64_t)blockIdx.x * 256 + threadIdx.x; e < m; e += (uint64_t)gridDim.x * 256) {
+        const uint64_t d = dev_of[rowid[e]];
+        const uint64_t idx = dev_of[src[e]];
+        const uint64_t hr = world == 1 ? idx : (idx % slice) * world + idx / slice; // hotness rank of a device position
+        key[e] = (d << 32) | hr;
+    }
 }
 __global__ __launch_bounds__(256) void low_half_kernel(const uint64_t *key, uint64_t m, uint32_t *out)
 {
-    const uint64_t e = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-    if (e < m) out[e] = (uint32_t)key[e];
+    for (uint64_t e = (uint64_t)blockIdx.x * 256 + threadIdx.x; e < m; e += (uint64_t)gridDim.x * 256) out[e] = (uint32_t)key[e];
 }
 // per device row: in-degree, split flag, out-degree in device order
 __global__ __launch_bounds__(256) void row_info_kernel(const uint32_t *order, uint64_t n_pad, const uint64_t *row_ptr, const uint32_t *outdeg,
@@ -623,7 +626,7 @@ std::string gpu_build_plan(void *stream_v, uint64_t n, const uint64_t *d_row_ptr
         PL_HIP(rocprim::inclusive_scan(tmp, bytes, d_rowid, d_rowid, (size_t)m, rocprim::maximum<uint32_t>(), stream));
         lap("  rows: row id per edge");
         PL_HIP(mem.alloc(&k_in, m));
-        hipLaunchKernelGGL(edge_keys_kernel, dim3(grid_for(m)), dim3(256), 0, stream, (const uint32_t *)d_rowid, d_src_in, m,
+        hipLaunchKernelGGL(edge_keys_kernel, dim3(grid_strided(m)), dim3(256), 0, stream, (const uint32_t *)d_rowid, d_src_in, m,
                            (const uint32_t *)d_dev_of, slice, world, k_in);
         PL_HIP(hipGetLastError());
         PL_HIP(hipStreamSynchronize(stream));
@@ -637,7 +640,7 @@ std::string gpu_build_plan(void *stream_v, uint64_t n, const uint64_t *d_row_ptr
         PL_HIP(need_tmp(bytes));
         PL_HIP(rocprim::radix_sort_keys(tmp, bytes, keys, (size_t)m, 0u, end_bit, stream));
         lap("  rows: 64-bit radix sort");
-        hipLaunchKernelGGL(low_half_kernel, dim3(grid_for(m)), dim3(256), 0, stream, (const uint64_t *)keys.current(), m, d_rs);
+        hipLaunchKernelGGL(low_half_kernel, dim3(grid_strided(m)), dim3(256), 0, stream, (const uint64_t *)keys.current(), m, d_rs);
         PL_HIP(hipGetLastError());
         PL_HIP(hipStreamSynchronize(stream));
         mem.release(k_in);
