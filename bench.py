@@ -56,6 +56,8 @@ def parse():
     ap.add_argument("--partition", default="dest", choices=["dest", "edge"],
                     help="N > 1: destination partition + all-gather per pass (default) or the north-star "
                          "edge partition + all-reduce(max) per pass")
+    ap.add_argument("--changed-only", action="store_true",
+                    help="N > 1, --partition dest: exchange only the counters that changed (HB_FLAG_CHANGED_ONLY)")
     ap.add_argument("--flags", type=int, default=0)
     ap.add_argument("--chunk", type=int, default=0)
     ap.add_argument("--tune", default="", help="comma separated hb_options.tune values")
@@ -111,6 +113,8 @@ def main():
         rccl_id = dist.torch_unique_id(rank, world)
         if a.partition == "dest":
             flags |= _lib.HB_FLAG_DEST_PARTITION
+            if a.changed_only:
+                flags |= _lib.HB_FLAG_CHANGED_ONLY
     tune = tuple(int(x) for x in a.tune.split(",")) if a.tune else ()
     ctx = _lib.Context(device=local_rank, flags=flags, chunk=a.chunk, rank=rank, world_size=world, rccl_id=rccl_id,
                        tune=tune)
@@ -218,7 +222,8 @@ def main():
         n_pad = (n + 63) // 64 * 64
         wire = None
         if world > 1:
-            wire = {"ran": a.partition,
+            wire = {"ran": a.partition + ("+changed-only" if (a.partition == "dest" and a.changed_only) else ""),
+                    "received_bytes_per_gpu_per_run": int(stats["wire_bytes"]),
                     "edge_allreduce_bytes_per_gpu_per_pass": 2.0 * (world - 1) / world * n_pad * 64,
                     "dest_allgather_bytes_per_gpu_per_pass": (world - 1) / world * (n_pad * 64 + n_pad / 8),
                     "ms_collective_per_pass": round(coll_ms / steps / max(passes, 1), 4)}

@@ -27,6 +27,7 @@ HB_FLAG_NO_SPARSE = 0x100
 HB_FLAG_DEST_PARTITION = 0x200
 HB_FLAG_HOST_INGEST = 0x400
 HB_FLAG_HOST_PLAN = 0x800
+HB_FLAG_CHANGED_ONLY = 0x1000
 
 # numpy views of the plain-data structs
 U128 = np.dtype([("lo", "<u8"), ("hi", "<u8")])
@@ -72,6 +73,7 @@ class HbStats(ctypes.Structure):
         ("level1_rows", ctypes.c_uint64),
         ("direct_edges", ctypes.c_uint64),
         ("rows_with_in_edges", ctypes.c_uint64),
+        ("wire_bytes", ctypes.c_uint64),
     ]
 
     def as_dict(self):

@@ -80,6 +80,12 @@ struct hb_ctx {
     uint64_t bits_words = 0;
     uint64_t ksum_len = 0; // entries allocated for ksum (world * slice in RCCL mode)
     uint64_t slice_rows = 0;
+    // changed-only exchange (HB_FLAG_CHANGED_ONLY): packed changed counters, popcounts / prefix of the bitmap words
+    uint4 *d_pack = nullptr;
+    uint32_t *d_wpop = nullptr;
+    uint64_t *d_wprefix = nullptr;
+    std::vector<uint64_t> ex_off; // world + 1: first packed position of every rank's slice
+    uint64_t wire_bytes = 0;      // counter bytes this rank received over the run (changed-only accounting)
 
     // loop state
     uint64_t t = 0;
@@ -158,6 +164,9 @@ void free_graph_buffers(hb_ctx *c)
     c->d_raw = c->d_bias = nullptr;
     c->d_lc = nullptr;
     c->d_out = nullptr;
+    c->d_pack = nullptr;
+    c->d_wpop = nullptr;
+    c->d_wprefix = nullptr;
     c->d_out_ptr = nullptr;
     c->d_out_rows = nullptr;
     c->d_touch = nullptr;
@@ -552,6 +561,60 @@ hbk::PassParams make_params(hb_ctx *c)
     return pp;
 }
 
+bool changed_only(const hb_ctx *c) { return dest_mode(c) && (c->opt.flags & HB_FLAG_CHANGED_ONLY); }
+
+// changed-only exchange, step 1 (the changed bits of ALL slices are in bits_wr): prefix sums over the bitmap words,
+// the packed position where every rank's run starts, and this rank's changed rows packed at their place
+int exchange_pack(hb_ctx *c)
+{
+    const Plan &p = c->plan;
+    const uint64_t words = p.n_pad / 32, S = c->slice_rows;
+    const uint64_t world = (uint64_t)std::max(c->opt.world_size, 1), r = (uint64_t)c->opt.rank;
+    int rc;
+    if (!c->d_pack) {
+        if ((rc = dev_alloc(c, &c->d_pack, p.n_pad * 4))) return rc;
+        if ((rc = dev_alloc(c, &c->d_wpop, words + 1))) return rc;
+        if ((rc = dev_alloc(c, &c->d_wprefix, words + 2))) return rc;
+    }
+    hbk::PassParams pp = make_params(c);
+    if (words) {
+        const unsigned blocks = (unsigned)std::min<uint64_t>((words + 255) / 256, (uint64_t)c->num_cu * 8);
+        hipLaunchKernelGGL(hbk::popcount_words_kernel, dim3(blocks), dim3(256), 0, c->stream, (const uint32_t *)pp.bits_wr, words, c->d_wpop);
+        HB_HIP(hipGetLastError());
+    }
+    const std::string e = device_prefix((void *)c->stream, c->d_wpop, words, c->d_wprefix);
+    if (!e.empty()) return fail(c, HB_ERR_HIP, e);
+    c->ex_off.assign(world + 1, 0);
+    for (uint64_t k = 0; k <= world; k++)
+        HB_HIP(hipMemcpyAsync(&c->ex_off[k], c->d_wprefix + std::min<uint64_t>(k * S, p.n_pad) / 32, sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+    HB_HIP(hipStreamSynchronize(c->stream));
+    const uint64_t lo = r * S, hi = std::min<uint64_t>(lo + S, p.n_pad);
+    if (hi > lo) {
+        hipLaunchKernelGGL(hbk::pack_changed_kernel, dim3((unsigned)(((hi - lo) * 4 + 255) / 256)), dim3(256), 0, c->stream, (const uint4 *)pp.wr,
+                           (const uint32_t *)pp.bits_wr, (const uint64_t *)c->d_wprefix, lo, hi, c->d_pack);
+        HB_HIP(hipGetLastError());
+    }
+    c->wire_bytes += (c->ex_off[world] - (c->ex_off[r + 1] - c->ex_off[r])) * 64 + (p.n_pad - (hi - lo)) / 8;
+    return HB_OK;
+}
+
+// step 3 (the packed runs of all ranks are in d_pack): scatter the foreign ones
+int exchange_unpack(hb_ctx *c)
+{
+    const Plan &p = c->plan;
+    const uint64_t S = c->slice_rows, r = (uint64_t)c->opt.rank;
+    hbk::PassParams pp = make_params(c);
+    const uint64_t lo = r * S, hi = std::min<uint64_t>(lo + S, p.n_pad);
+    const uint64_t ranges[2][2] = {{0, lo}, {hi, p.n_pad}};
+    for (auto &rg : ranges) {
+        if (rg[1] <= rg[0]) continue;
+        hipLaunchKernelGGL(hbk::unpack_changed_kernel, dim3((unsigned)(((rg[1] - rg[0]) * 4 + 255) / 256)), dim3(256), 0, c->stream, pp.wr, pp.rd,
+                           (const uint32_t *)pp.bits_wr, pp.bits_rd, (const uint64_t *)c->d_wprefix, rg[0], rg[1], (const uint4 *)c->d_pack);
+        HB_HIP(hipGetLastError());
+    }
+    return HB_OK;
+}
+
 int step_local(hb_ctx *c)
 {
     if (!c->begun || c->finished) return fail(c, HB_ERR_INVALID, "hb_step*: call hb_begin first");
@@ -671,11 +734,30 @@ int step_finish(hb_ctx *c, int *has_changes)
         // kernel): all-gather the slices in place; sum the counts
         hbk::PassParams pp = make_params(c);
         const uint64_t S = c->slice_rows, r = (uint64_t)c->opt.rank;
-        HB_NCCL(ncclGroupStart());
-        HB_NCCL(ncclAllGather(pp.wr + r * S * 4, pp.wr, S * 64, ncclUint8, c->comm, c->stream));
-        HB_NCCL(ncclAllGather(pp.bits_wr + r * (S / 32), pp.bits_wr, S / 32, ncclUint32, c->comm, c->stream));
-        HB_NCCL(ncclAllReduce(pp.counters, pp.counters, hbk::kCounterWords, ncclUint64, ncclSum, c->comm, c->stream));
-        HB_NCCL(ncclGroupEnd());
+        if (changed_only(c)) {
+            // bits and counts first, then only the counters that changed: one broadcast per rank of its packed run
+            HB_NCCL(ncclGroupStart());
+            HB_NCCL(ncclAllGather(pp.bits_wr + r * (S / 32), pp.bits_wr, S / 32, ncclUint32, c->comm, c->stream));
+            HB_NCCL(ncclAllReduce(pp.counters, pp.counters, hbk::kCounterWords, ncclUint64, ncclSum, c->comm, c->stream));
+            HB_NCCL(ncclGroupEnd());
+            int rc = exchange_pack(c);
+            if (rc) return rc;
+            const int world = std::max(c->opt.world_size, 1);
+            HB_NCCL(ncclGroupStart());
+            for (int k = 0; k < world; k++) {
+                const uint64_t cnt = c->ex_off[k + 1] - c->ex_off[k];
+                if (cnt) HB_NCCL(ncclBroadcast(c->d_pack + c->ex_off[k] * 4, c->d_pack + c->ex_off[k] * 4, cnt * 64, ncclUint8, k, c->comm, c->stream));
+            }
+            HB_NCCL(ncclGroupEnd());
+            if ((rc = exchange_unpack(c))) return rc;
+        } else {
+            HB_NCCL(ncclGroupStart());
+            HB_NCCL(ncclAllGather(pp.wr + r * S * 4, pp.wr, S * 64, ncclUint8, c->comm, c->stream));
+            HB_NCCL(ncclAllGather(pp.bits_wr + r * (S / 32), pp.bits_wr, S / 32, ncclUint32, c->comm, c->stream));
+            HB_NCCL(ncclAllReduce(pp.counters, pp.counters, hbk::kCounterWords, ncclUint64, ncclSum, c->comm, c->stream));
+            HB_NCCL(ncclGroupEnd());
+            c->wire_bytes += (p.n_pad - std::min<uint64_t>(S, p.n_pad)) * 64 + (p.n_pad - std::min<uint64_t>(S, p.n_pad)) / 8;
+        }
         HB_HIP(hipEventRecord(c->ev[3], c->stream));
     }
     hipEvent_t ev_end = c->ev[2];
@@ -1106,6 +1188,7 @@ int hb_begin(hb_ctx *c)
         HB_HIP(hipStreamSynchronize(c->stream));
         c->t = 0;
         c->cur = 0;
+        c->wire_bytes = 0;
         c->has_changes = true; // harmonic.rs:232
         c->last_changed = p.n;
         c->last_active = c->m_global;
@@ -1186,6 +1269,7 @@ int hb_finish(hb_ctx *c)
         for (auto &ps : c->pstats) { g += ps.ms_gpu; coll += ps.ms_collective; }
         c->stats.ms_loop_gpu = g;
         c->stats.ms_collective = coll;
+        c->stats.wire_bytes = c->wire_bytes;
         c->finished = true;
         return HB_OK;
     });
@@ -1535,17 +1619,40 @@ int hb_debug_exchange(hb_ctx **ctxs, int count, int phase)
             HB_HIP(hipStreamSynchronize(c->stream));
             for (int i = 0; i < count; i++)
                 for (size_t k = 0; k < W; k++) total[k] += cnt[(size_t)i * W + k];
+            const bool packed = changed_only(c);
             for (int i = 0; i < count; i++) {
                 hb_ctx *d = ctxs[i];
                 for (int j = 0; j < count; j++) {
                     if (i == j || !S) continue;
                     hb_ctx *o = ctxs[j];
-                    HB_HIP(hipMemcpyAsync(d->d_regs[d->cur ^ 1] + (uint64_t)j * S * 4, o->d_regs[o->cur ^ 1] + (uint64_t)j * S * 4, S * 64,
-                                          hipMemcpyDeviceToDevice, c->stream));
+                    if (!packed)
+                        HB_HIP(hipMemcpyAsync(d->d_regs[d->cur ^ 1] + (uint64_t)j * S * 4, o->d_regs[o->cur ^ 1] + (uint64_t)j * S * 4, S * 64,
+                                              hipMemcpyDeviceToDevice, c->stream));
                     HB_HIP(hipMemcpyAsync(d->d_bits[d->cur ^ 1] + (uint64_t)j * (S / 32), o->d_bits[o->cur ^ 1] + (uint64_t)j * (S / 32), S / 8,
                                           hipMemcpyDeviceToDevice, c->stream));
                 }
                 HB_HIP(hipMemcpyAsync(d->d_counters + W * d->t, total.data(), W * sizeof(unsigned long long), hipMemcpyHostToDevice, c->stream));
+            }
+            if (packed) {
+                // the changed-only protocol with copies in place of the broadcasts: pack everywhere, move the runs, unpack
+                HB_HIP(hipStreamSynchronize(c->stream));
+                for (int i = 0; i < count; i++) {
+                    int rc2 = exchange_pack(ctxs[i]);
+                    if (rc2) return rc2;
+                    HB_HIP(hipStreamSynchronize(ctxs[i]->stream));
+                }
+                for (int i = 0; i < count; i++)
+                    for (int j = 0; j < count; j++) {
+                        if (i == j) continue;
+                        const uint64_t off = ctxs[j]->ex_off[j], cnt = ctxs[j]->ex_off[j + 1] - off;
+                        if (cnt) HB_HIP(hipMemcpyAsync(ctxs[i]->d_pack + off * 4, ctxs[j]->d_pack + off * 4, cnt * 64, hipMemcpyDeviceToDevice, c->stream));
+                    }
+                HB_HIP(hipStreamSynchronize(c->stream));
+                for (int i = 0; i < count; i++) {
+                    int rc2 = exchange_unpack(ctxs[i]);
+                    if (rc2) return rc2;
+                    HB_HIP(hipStreamSynchronize(ctxs[i]->stream));
+                }
             }
         }
         HB_HIP(hipStreamSynchronize(c->stream));

@@ -193,6 +193,8 @@ struct DevicePlan {
 // `out`.  d_outdeg_sid: global out-degree per sid.  Must produce exactly build_plan()'s layout.
 // d_offsets[i] = sum of d_counts[0 .. i), i = 0 .. count; fails unless the total equals `expect`
 std::string device_offsets(void *stream, uint32_t *d_counts, uint64_t count, uint64_t *d_offsets, uint64_t expect);
+// d_offsets[0 .. count]: exclusive prefix sums of d_counts (count + 1 outputs)
+std::string device_prefix(void *stream, const uint32_t *d_counts, uint64_t count, uint64_t *d_offsets);
 std::string gpu_build_plan(void *stream, uint64_t n, const uint64_t *d_row_ptr, const uint32_t *d_src, const uint32_t *d_outdeg_sid,
                            bool reorder, const PlanTune &tune, Plan *plan, DevicePlan *out);
 

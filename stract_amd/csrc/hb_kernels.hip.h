@@ -1110,6 +1110,43 @@ __global__ __launch_bounds__(256) void merge_max_kernel(uint4 *dst, const uint4 
     }
 }
 
+// ---- changed-only exchange (destination partition, HB_FLAG_CHANGED_ONLY) --------------------------------------
+// After the changed bits of all slices are known everywhere, only the counters that changed travel: every rank
+// packs the changed rows of its slice (ascending row order; position = rank of the row's bit among all set bits,
+// from a prefix sum over the bitmap words), the packed runs are broadcast, and the receivers scatter them.
+__global__ __launch_bounds__(256) void popcount_words_kernel(const uint32_t *bits, uint64_t words, uint32_t *out)
+{
+    for (uint64_t w = (uint64_t)blockIdx.x * 256 + threadIdx.x; w < words; w += (uint64_t)gridDim.x * 256) out[w] = __popc(bits[w]);
+}
+// quad per row of [row_lo, row_hi)
+__global__ __launch_bounds__(256) void pack_changed_kernel(const uint4 *wr, const uint32_t *bits, const uint64_t *prefix, uint64_t row_lo,
+                                                           uint64_t row_hi, uint4 *pack)
+{
+    const uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    const uint64_t row = row_lo + (t >> 2);
+    if (row >= row_hi) return;
+    const uint32_t w = bits[row >> 5], b = (uint32_t)(row & 31u);
+    if (!((w >> b) & 1u)) return;
+    const uint64_t pos = prefix[row >> 5] + (uint64_t)__popc(w & ((1u << b) - 1u));
+    pack[pos * 4 + (t & 3)] = wr[row * 4 + (t & 3)];
+}
+// foreign rows [row_lo, row_hi): changed now -> take the packed counter; changed in the previous pass only -> the
+// other buffer is two passes old, carry the current value over (lazy double buffer, see pass_kernel)
+__global__ __launch_bounds__(256) void unpack_changed_kernel(uint4 *wr, const uint4 *rd, const uint32_t *bits_now, const uint32_t *bits_prev,
+                                                             const uint64_t *prefix, uint64_t row_lo, uint64_t row_hi, const uint4 *pack)
+{
+    const uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    const uint64_t row = row_lo + (t >> 2);
+    if (row >= row_hi) return;
+    const uint32_t w = bits_now[row >> 5], b = (uint32_t)(row & 31u);
+    if ((w >> b) & 1u) {
+        const uint64_t pos = prefix[row >> 5] + (uint64_t)__popc(w & ((1u << b) - 1u));
+        wr[row * 4 + (t & 3)] = pack[pos * 4 + (t & 3)];
+    } else if ((bits_prev[row >> 5] >> b) & 1u) {
+        wr[row * 4 + (t & 3)] = rd[row * 4 + (t & 3)];
+    }
+}
+
 // ---- normalize_centralities (harmonic.rs:178-195) -----------------------------------------
 // out[sid] for sid in ascending-NodeID order: f64::from(KahanSum) = sum (kahan_sum.rs:35-39);
 // kept iff > 0.0, then / norm, non-finite -> 0.0; absent nodes are marked -1.0.

@@ -519,6 +519,28 @@ std::string device_offsets(void *stream_v, uint32_t *d_counts /* count + 1 entri
     return "";
 }
 
+// d_offsets[i] = sum of d_counts[0 .. i), i = 0 .. count (no check of the total)
+std::string device_prefix(void *stream_v, const uint32_t *d_counts, uint64_t count, uint64_t *d_offsets)
+{
+    hipStream_t stream = (hipStream_t)stream_v;
+    // count + 1 outputs: the scan runs over count + 1 inputs whose last one is never read as a value that matters
+    auto wide = rocprim::make_transform_iterator(d_counts, Widen32());
+    size_t bytes = 0;
+    void *tmp = nullptr;
+    if (!count) {
+        PL_HIP(hipMemsetAsync(d_offsets, 0, sizeof(uint64_t), stream));
+        return "";
+    }
+    PL_HIP(rocprim::inclusive_scan(nullptr, bytes, wide, d_offsets + 1, (size_t)count, rocprim::plus<uint64_t>(), stream));
+    PL_HIP(hipMalloc(&tmp, std::max<size_t>(bytes, 256)));
+    hipError_t e = hipMemsetAsync(d_offsets, 0, sizeof(uint64_t), stream);
+    if (e == hipSuccess) e = rocprim::inclusive_scan(tmp, bytes, wide, d_offsets + 1, (size_t)count, rocprim::plus<uint64_t>(), stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(stream);
+    (void)hipFree(tmp);
+    if (e != hipSuccess) return std::string("device_prefix: ") + hipGetErrorString(e);
+    return "";
+}
+
 std::string gpu_build_plan(void *stream_v, uint64_t n, const uint64_t *d_row_ptr_in, const uint32_t *d_src_in, const uint32_t *d_outdeg_sid,
                            bool reorder, const PlanTune &tune_in, Plan *p, DevicePlan *out)
 {

@@ -416,15 +416,16 @@ def test_device_plan_equals_host_plan(gpu_ctx_factory):
 
 
 # ---- edge-partition mode ------------------------------------------------------------------------
-@pytest.mark.parametrize("world,mode", [(2, "edge"), (3, "edge"), (2, "dest"), (3, "dest"), (4, "dest")])
+@pytest.mark.parametrize("world,mode", [(2, "edge"), (3, "edge"), (2, "dest"), (3, "dest"), (4, "dest"), (2, "dest_changed"), (4, "dest_changed")])
 def test_logical_ranks_on_one_device(gpu_ctx_factory, world, mode):
     """SURVEY.md §8(e) caveat: R logical ranks on one device, the collective emulated by
     hb_debug_exchange (edge partition: all-reduce(max); destination partition: all-gather of the
     owned slices); every rank must reproduce the single-GPU result bit for bit."""
     g = synth.RmatGraph(12, 40_000)
     o, T, vals, keep, k = _oracle_dense(g.ids, g.row_ptr, g.src)
-    flags = _lib.HB_FLAG_NO_RCCL | (_lib.HB_FLAG_DEST_PARTITION if mode == "dest" else 0)
-    split = dist.partition_dense_by_dest if mode == "dest" else dist.partition_dense
+    flags = _lib.HB_FLAG_NO_RCCL | (_lib.HB_FLAG_DEST_PARTITION if mode.startswith("dest") else 0)
+    flags |= _lib.HB_FLAG_CHANGED_ONLY if mode == "dest_changed" else 0  # packed changed counters instead of whole slices
+    split = dist.partition_dense_by_dest if mode.startswith("dest") else dist.partition_dense
     ctxs = []
     try:
         for r in range(world):
@@ -487,7 +488,7 @@ def test_dest_partition_ignores_foreign_records(gpu_ctx_factory):
             c.close()
 
 
-@pytest.mark.parametrize("dest", [False, True])
+@pytest.mark.parametrize("dest", [False, True, "changed"])
 def test_rccl_call_path_single_rank(gpu_ctx_factory, dest):
     """A 1-rank RCCL communicator: the collectives of both decompositions run for real -
     ncclAllReduce(max, u8) + epilogue (edge partition), grouped ncclAllGather of the counter / changed-bit
@@ -495,7 +496,7 @@ def test_rccl_call_path_single_rank(gpu_ctx_factory, dest):
     g = synth.RmatGraph(12, 40_000)
     o, T, vals, keep, k = _oracle_dense(g.ids, g.row_ptr, g.src)
     uid = _lib.rccl_unique_id()
-    flags = _lib.HB_FLAG_RCCL_SELF | (_lib.HB_FLAG_DEST_PARTITION if dest else 0)
+    flags = _lib.HB_FLAG_RCCL_SELF | (_lib.HB_FLAG_DEST_PARTITION if dest else 0) | (_lib.HB_FLAG_CHANGED_ONLY if dest == "changed" else 0)
     with gpu_ctx_factory(flags=flags, rccl_id=uid) as ctx:
         ctx.load_dense(g.ids, g.row_ptr, g.src)
         st = ctx.run()

@@ -32,7 +32,7 @@ def test_header_symbols_all_exported():
 def test_struct_layouts_match_header():
     assert ctypes.sizeof(_lib.HbOptions) == 4 * 7 + 128 + 32
     assert _lib.EDGE.itemsize == 40 and _lib.U128.itemsize == 16
-    assert ctypes.sizeof(_lib.HbStats) == 22 * 8
+    assert ctypes.sizeof(_lib.HbStats) == 23 * 8
     assert ctypes.sizeof(_lib.HbPassStats) == 4 * 8 + 6 * 4
 
 
