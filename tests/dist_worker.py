@@ -21,14 +21,34 @@ def main():
     td.init_process_group("gloo")
     rank, world = td.get_rank(), td.get_world_size()
     g = synth.RmatGraph(scale, m, threads=1)
-    split = dist.partition_dense_by_dest if mode == "dest" else dist.partition_dense
+    split = dist.partition_dense_by_dest if mode.startswith("dest") else dist.partition_dense
     rp, src = split(g.row_ptr, g.src, rank, world)
     o = hbo.Dense(g.id_low64(), rp, src, threads=1)
     has, passes = True, 0
     while has:
         o.step_local(hbo.FRONTIER)
         pend = torch.from_numpy(o.pending())
-        if mode == "dest":
+        if mode == "dest_changed":
+            # HB_FLAG_CHANGED_ONLY protocol: all-gather the changed bits of the owned rows, then every rank broadcasts
+            # only its changed counters (packed, ascending row order); unchanged foreign rows keep the old value
+            old = torch.from_numpy(o.registers())
+            per = (g.n + world - 1) // world
+            mine_changed = torch.zeros(per, dtype=torch.uint8)
+            own_rows = torch.arange(rank, g.n, world)
+            mine_changed[:len(own_rows)] = (pend[own_rows] != old[own_rows]).any(dim=1).to(torch.uint8)
+            bits = [torch.zeros_like(mine_changed) for _ in range(world)]
+            td.all_gather(bits, mine_changed)
+            for r in range(world):
+                rows_r = torch.arange(r, g.n, world)
+                ch = bits[r][:len(rows_r)].bool()
+                packed = pend[rows_r[ch]].clone() if r == rank else torch.zeros((int(ch.sum()), 64), dtype=torch.uint8)
+                if packed.numel():
+                    td.broadcast(packed, src=r)
+                if r != rank:
+                    pend[rows_r] = old[rows_r]
+                    pend[rows_r[ch]] = packed
+        elif mode == "dest":
+
             # all-gather of the owned rows (rank r owns the rows r, r + world, ...), padded to equal length
             per = (g.n + world - 1) // world
             mine = torch.zeros((per, 64), dtype=torch.uint8)
