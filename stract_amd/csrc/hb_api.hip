@@ -335,6 +335,16 @@ int plan_and_upload(hb_ctx *c, DeviceCsr *csr_in, uint64_t m_eff)
     PlanTune pt = plan_tune(c->opt.chunk, c->opt.tune);
     pt.xcd_map = !(c->opt.flags & HB_FLAG_NO_XCD_MAP);
     if (dest_mode(c)) pt.world = (uint32_t)std::max(c->opt.world_size, 1);
+    // The two counter arrays are what the passes gather from at random: allocate them BEFORE the planner churns
+    // through tens of GB of work memory, while the device heap can still back them with large contiguous
+    // fragments (allocated after it, the same kernels ran 1-2 % slower: more TLB misses on the gathers).
+    {
+        const uint64_t w = pt.world > 1 ? pt.world : 1;
+        const uint64_t n_pad_pre = (((n + w - 1) / w + kRowAlign - 1) / kRowAlign * kRowAlign) * w;
+        int rc0;
+        if ((rc0 = dev_alloc(c, &c->d_regs[0], n_pad_pre * 4))) return rc0;
+        if ((rc0 = dev_alloc(c, &c->d_regs[1], n_pad_pre * 4))) return rc0;
+    }
     std::vector<uint32_t> outdeg; // host planner only
     DevicePlan dp;
     if (on_device) {
@@ -395,8 +405,6 @@ int plan_and_upload(hb_ctx *c, DeviceCsr *csr_in, uint64_t m_eff)
         if ((rc = dev_alloc(c, &c->d_sid_of, p.n_pad))) return rc;
         if ((rc = dev_alloc(c, &c->d_outdeg, p.n_pad))) return rc;
     }
-    if ((rc = dev_alloc(c, &c->d_regs[0], p.n_pad * 4))) return rc;
-    if ((rc = dev_alloc(c, &c->d_regs[1], p.n_pad * 4))) return rc;
     if ((rc = dev_alloc(c, &c->d_part, p.nv * 4))) return rc;
     if ((rc = dev_alloc(c, &c->d_bits[0], c->bits_words))) return rc;
     if ((rc = dev_alloc(c, &c->d_bits[1], c->bits_words))) return rc;

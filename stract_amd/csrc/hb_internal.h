@@ -90,32 +90,40 @@ struct XcdQuota {
         if (key >= 1 && key <= warm_slices) warm[key & 7u] += load_of(len);
         else flex[key == 0 ? 0 : 1] += load_of(len);
     }
+    // Two stages, like dealing the chunks coldest first to the least loaded group: the COLD chunks (every gather a
+    // miss, as slow as the warm ones) level warm + cold; the HOT chunks (L2 hits, cheap) then level the total.
     void finish()
     {
-        uint64_t total = flex[0] + flex[1];
-        for (int x = 0; x < 8; x++) total += warm[x];
-        const uint64_t target = (total + 7) / 8;
-        uint64_t q[8], sq = 0;
-        for (int x = 0; x < 8; x++) {
-            q[x] = target > warm[x] ? target - warm[x] : 0;
-            sq += q[x];
-        }
-        if (sq == 0) {
-            for (int x = 0; x < 8; x++) q[x] = 1;
-            sq = 8;
-        }
-        for (int c = 0; c < 2; c++) {
+        uint64_t load[8];
+        for (int x = 0; x < 8; x++) load[x] = warm[x];
+        for (int c = 1; c >= 0; c--) { // cold (1) first, then hot (0)
+            uint64_t total = flex[c];
+            for (int x = 0; x < 8; x++) total += load[x];
+            const uint64_t target = (total + 7) / 8;
+            uint64_t q[8], sq = 0;
+            for (int x = 0; x < 8; x++) {
+                q[x] = target > load[x] ? target - load[x] : 0;
+                sq += q[x];
+            }
+            if (sq == 0) {
+                for (int x = 0; x < 8; x++) q[x] = 1;
+                sq = 8;
+            }
             uint64_t cum = 0;
             for (int x = 0; x < 8; x++) {
                 bound[c][x] = (uint64_t)(((unsigned __int128)cum * flex[c]) / sq);
                 cum += q[x];
+            }
+            for (int x = 0; x < 8; x++) { // what the class adds to every group (for the next stage)
+                const uint64_t hi = x < 7 ? bound[c][x + 1] : flex[c];
+                load[x] += hi - bound[c][x];
             }
         }
     }
     // The class (in slice / longer-first order) is cut into kStripes stripes of equal load and EVERY stripe is
     // shared out by the quotas, so that each group gets long and short chunks alike (contiguous ranges gave one
     // group all the short chunks, whose per-row overhead is higher than the load model says).
-    static constexpr uint64_t kStripes = 64;
+    static constexpr uint64_t kStripes = 4096;
     uint64_t stripe(int cls) const { return flex[cls] / kStripes ? flex[cls] / kStripes : 1; }
     // group of the flexible chunk whose class-prefix load (exclusive) is `prefix`
     int group_of(int cls, uint64_t prefix) const
