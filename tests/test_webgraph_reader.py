@@ -113,3 +113,33 @@ def test_corrupt_stores_are_rejected(tmp_path):
     os.remove(os.path.join(d, "meta.json"))
     with pytest.raises(_lib.HyperballError):
         webgraph.EdgeStoreReader(d)
+
+
+def test_random_dictionaries_and_segmentations(tmp_path):
+    """Property-style: random column-name sets (long shared prefixes force the vint key headers, delta.rs:90-100) and
+    random segment splits must read back exactly."""
+    rng = np.random.default_rng(99)
+    for case in range(20):
+        names = set()
+        while len(names) < int(rng.integers(1, 12)):
+            base = "x" * int(rng.integers(0, 30)) + "".join(chr(int(c)) for c in rng.integers(97, 123, int(rng.integers(1, 25))))
+            names.add(base.encode() + b"\0" + bytes([int(rng.choice([1, 6]))]))
+        entries, off = [], 0
+        for k in sorted(names):
+            ln = int(rng.integers(0, 1 << int(rng.integers(1, 40))))
+            entries.append((k, (off, off + ln)))
+            off += ln
+        assert _sst(tf.sstable_ranges(entries), 1) == entries
+    g = synth.RmatGraph(9, 2500)
+    e = g.edges(salt=1, salt_seed=8)
+    for case in range(5):
+        cuts = sorted(int(c) for c in rng.integers(0, len(e) + 1, int(rng.integers(0, 6))))
+        parts = [e[a:b] for a, b in zip([0] + cuts, cuts + [len(e)])]
+        d = str(tmp_path / ("edges%d" % case))
+        tf.write_edge_store(d, parts, extra_columns=bool(case % 2))
+        with webgraph.EdgeStoreReader(d, verify_crc=True) as r:
+            assert r.num_segments() == len(parts)
+            assert np.array_equal(r.read(), e)
+            a = int(rng.integers(0, len(e)))
+            b = int(rng.integers(a, len(e) + 1))
+            assert np.array_equal(r.read(a, b - a), e[a:b])
