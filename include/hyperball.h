@@ -85,6 +85,14 @@ typedef struct hb_edge {
                                          changed in the pass travel (one ncclBroadcast of its packed run per rank) instead of
                                          the all-gather of whole slices: ~18 % fewer bytes in the dense passes of the R-MAT
                                          configs, ~100 % fewer in the tail; same results */
+#define HB_FLAG_REFERENCE_TAIL 0x2000u /* reproduce the reference's changed-node machinery AS WRITTEN instead of its host-level
+                                          meaning: the bloom filter of changed nodes with its false
+                                          positives (harmonic.rs:221-225,133; bloom/src/lib.rs:85-123), the exact-counting
+                                          switch (:277-279) and, once 0 < |changed| <= round(sqrt(n)), update_changed_counters
+                                          (:75-114), which follows the PAGE-level records a ForwardlinksQuery on the host id
+                                          returns (query/forwardlink.rs:95-101,153-173) - give them with hb_load_tail_edges.
+                                          On a graph whose pages are hosts this equals the default; on a real crawl it is
+                                          what `stract centrality harmonic` prints.  Single rank only; passes run unfused. */
 #define HB_FLAG_RCCL_SELF     0x80u /* world_size == 1 but still create a 1-rank communicator and run
                                        the collectives (exercises the RCCL call path on one GPU)   */
 
@@ -147,7 +155,8 @@ typedef struct hb_pass_stats {
     uint64_t touched;       /* frontier / sparse passes: node rows with >= 1 gathered source (<= V_t: a split
                                row counts only when one of its partials changed); dense passes: 0   */
     uint32_t mode;          /* 0 = dense (no frontier test), 1 = frontier bitmap, 2 = sweep (touch bitmap of the rows
-                               that read a changed node; only those rows run)                                */
+                               that read a changed node; only those rows run), 3 = reference tail
+                               (HB_FLAG_REFERENCE_TAIL: update_changed_counters over the page-level records)  */
     float    ms_gpu;        /* GPU time of the pass (all its launches + collective)         */
     float    ms_main;       /* GPU time of the dominant launch (real rows)                  */
     float    ms_collective;
@@ -185,6 +194,15 @@ int hb_load_edges(hb_ctx *ctx, const hb_u128 *node_ids, uint64_t n, const hb_edg
  * records are buffered on the host instead (same result). */
 int hb_append_edges(hb_ctx *ctx, const hb_edge *edges, uint64_t m);
 int hb_finalize(hb_ctx *ctx, const hb_u128 *node_ids, uint64_t n);
+
+/* HB_FLAG_REFERENCE_TAIL only; after the graph is loaded, before hb_begin / hb_run.  records = the page-level
+ * (from_id, to_id, rel_flags) documents whose from_id is a host node id, i.e. the union over all hosts h of what
+ * `graph.search(ForwardlinksQuery::new(h).with_limit(Unlimited))` returns (harmonic.rs:82-87; the query de-duplicates
+ * by to_id and drops self links itself).  Any superset may be passed: records whose ends are not both host nodes fall
+ * out at the counter lookup (harmonic.rs:91-92), records with a SKIPPED_REL flag at the filter (:87); duplicates and
+ * self links are harmless (max is idempotent).  Replaces the records of an earlier call; count == 0 = "the query
+ * finds nothing" (also the state before the first call). */
+int hb_load_tail_edges(hb_ctx *ctx, const hb_edge *records, uint64_t count);
 
 /* Pre-reduced input (bench / large synthetic graphs): sorted_ids strictly ascending;
  * in-edges of node v (the v-th smallest id) are src[row_ptr[v] .. row_ptr[v+1]), already

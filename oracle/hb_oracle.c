@@ -573,6 +573,18 @@ static inline int regs_any_greater(const uint8_t *from, const uint8_t *to)
 uint64_t hbo_faithful_run(const hbo_edge *edges, uint64_t m, hbo_u128 *out_ids, double *out_vals,
                           uint64_t cap, hbo_faithful_stats *stats)
 {
+    return hbo_faithful_run_pages(edges, m, NULL, 0, out_ids, out_vals, cap, stats);
+}
+
+/* pages != NULL: update_changed_counters follows PAGE-level records like the reference does:
+ * ForwardlinksQuery::new(host id) matches documents whose page-level from_id equals the host id and yields their
+ * page-level to_id (query/forwardlink.rs:95-101,153-173); harmonic.rs:91-92 then looks both ends up in the
+ * host-keyed maps.  `pages` = those (from_id, to_id, rel_flags) records (any superset of them: records whose
+ * ends are not host nodes fall out at the map lookup).  pages == NULL: host-level semantics (the forward index of
+ * the de-duplicated host edges). */
+uint64_t hbo_faithful_run_pages(const hbo_edge *edges, uint64_t m, const hbo_edge *pages, uint64_t mp,
+                                hbo_u128 *out_ids, double *out_vals, uint64_t cap, hbo_faithful_stats *stats)
+{
     hbo_faithful_stats st;
     memset(&st, 0, sizeof(st));
     /* ---- host_nodes(): every endpoint of every doc, no flag filtering (store.rs:338-357) */
@@ -629,12 +641,26 @@ uint64_t hbo_faithful_run(const hbo_edge *edges, uint64_t m, hbo_u128 *out_ids, 
         fwd[m_eff].to = (uint32_t)node_find(ids, n, tt);
         m_eff++;
     }
-    qsort(fwd, m_eff, sizeof(iedge_t), cmp_iedge_from);
-    uint64_t *fwd_ptr = (uint64_t *)calloc(n + 2, 8);
-    for (uint64_t i = 0; i < m_eff; i++) fwd_ptr[fwd[i].from + 1]++;
-    for (uint64_t v = 0; v < n; v++) fwd_ptr[v + 1] += fwd_ptr[v];
     st.m_unique = m_unique;
     st.m_eff = m_eff;
+    uint64_t fwd_len = m_eff;
+    if (pages) { /* the tail follows the page-level records instead (harmonic.rs:82-87: rel filter on the result) */
+        free(fwd);
+        fwd = (iedge_t *)malloc((mp + 1) * sizeof(iedge_t));
+        fwd_len = 0;
+        for (uint64_t i = 0; i < mp; i++) {
+            if (pages[i].rel_flags & HBO_SKIPPED_REL_MASK) continue;
+            int64_t ui = node_find(ids, n, to_u128(pages[i].from)), vi = node_find(ids, n, to_u128(pages[i].to));
+            if (ui < 0 || vi < 0) continue; /* harmonic.rs:91-92: both lookups must hit */
+            fwd[fwd_len].from = (uint32_t)ui;
+            fwd[fwd_len].to = (uint32_t)vi;
+            fwd_len++;
+        }
+    }
+    qsort(fwd, fwd_len, sizeof(iedge_t), cmp_iedge_from);
+    uint64_t *fwd_ptr = (uint64_t *)calloc(n + 2, 8);
+    for (uint64_t i = 0; i < fwd_len; i++) fwd_ptr[fwd[i].from + 1]++;
+    for (uint64_t v = 0; v < n; v++) fwd_ptr[v + 1] += fwd_ptr[v];
 
     double t0 = now_s();
     for (;;) { /* harmonic.rs:237 */

@@ -136,6 +136,12 @@ typedef struct {
 uint64_t hbo_faithful_run(const hbo_edge *edges, uint64_t m, hbo_u128 *out_ids,
                           double *out_vals, uint64_t cap, hbo_faithful_stats *stats);
 
+/* Same, but the sqrt(n) tail (update_changed_counters, harmonic.rs:75-114) follows the given PAGE-level records
+ * (from_id, to_id, rel_flags) like the reference's ForwardlinksQuery does instead of the
+ * host-level edges.  pages == NULL = hbo_faithful_run. */
+uint64_t hbo_faithful_run_pages(const hbo_edge *edges, uint64_t m, const hbo_edge *pages, uint64_t mp,
+                                hbo_u128 *out_ids, double *out_vals, uint64_t cap, hbo_faithful_stats *stats);
+
 /* U64BloomFilter pieces exposed for tests (bloom/src/lib.rs:36-41,108-123). */
 uint64_t hbo_bloom_num_bits(uint64_t estimated_items, double fp);
 uint64_t hbo_bloom_estimate_card(uint64_t num_bits, uint64_t num_ones);

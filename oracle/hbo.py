@@ -74,6 +74,8 @@ def load():
     L.hbo_dense_state_hash.argtypes = [P, P]
     L.hbo_faithful_run.restype = U64
     L.hbo_faithful_run.argtypes = [P, U64, P, P, U64, P]
+    L.hbo_faithful_run_pages.restype = U64
+    L.hbo_faithful_run_pages.argtypes = [P, U64, P, U64, P, P, U64, P]
     L.hbo_bloom_num_bits.restype = U64
     L.hbo_bloom_num_bits.argtypes = [U64, ctypes.c_double]
     L.hbo_bloom_estimate_card.restype = U64
@@ -201,8 +203,9 @@ class Dense:
             pass
 
 
-def faithful_run(edges):
-    """Structure-faithful single-thread path on raw SmallEdge records.
+def faithful_run(edges, pages=None):
+    """Structure-faithful single-thread path on raw SmallEdge records.  pages (EDGE records, may be empty): the
+    sqrt(n) tail follows these page-level records like the reference; None = host-level.
     Returns (ids[U128], vals[f64], stats dict)."""
     L = load()
     edges = np.ascontiguousarray(edges, dtype=EDGE)
@@ -210,7 +213,14 @@ def faithful_run(edges):
     ids = np.zeros(cap, dtype=U128)
     vals = np.zeros(cap, dtype=np.float64)
     st = FaithfulStats()
-    k = L.hbo_faithful_run(edges.ctypes.data if len(edges) else None, len(edges), ids.ctypes.data, vals.ctypes.data, cap,
-                           ctypes.byref(st))
+    if pages is None:
+        k = L.hbo_faithful_run(edges.ctypes.data if len(edges) else None, len(edges), ids.ctypes.data, vals.ctypes.data,
+                               cap, ctypes.byref(st))
+    else:
+        pages = np.ascontiguousarray(pages, dtype=EDGE)
+        keep = np.zeros(1, dtype=EDGE)  # non-NULL even when there are no page records: "page-level, nothing found"
+        k = L.hbo_faithful_run_pages(edges.ctypes.data if len(edges) else None, len(edges),
+                                     pages.ctypes.data if len(pages) else keep.ctypes.data, len(pages), ids.ctypes.data,
+                                     vals.ctypes.data, cap, ctypes.byref(st))
     assert k != 0xFFFFFFFFFFFFFFFF
     return ids[:k].copy(), vals[:k].copy(), {f: getattr(st, f) for f, _ in st._fields_}

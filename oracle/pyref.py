@@ -278,3 +278,124 @@ def harmonic_centrality(edges):
                 c = c / norm
                 out[v] = c if math.isfinite(c) else 0.0
     return out, t
+
+
+# ---- the reference's loop with its changed-set machinery spelled out (bloom + sqrt(n) exact tail) --------------------
+LARGE_PRIME = 11400714819323198549  # bloom/src/lib.rs:36
+
+
+def bloom_num_bits(estimated_items, fp=0.05):
+    """bloom/src/lib.rs:38-41."""
+    return int(math.ceil(float(estimated_items) * math.log(fp) / (-8.0 * math.log(2.0) ** 2)))
+
+
+class Bloom:
+    """U64BloomFilter (bloom/src/lib.rs:60-123): one multiplicative hash of the LOW 64 bits of the id."""
+
+    def __init__(self, estimated_items):
+        self.num_bits = bloom_num_bits(estimated_items)
+        self.bits = set()
+
+    def _slot(self, item):
+        return (((item & MASK64) * LARGE_PRIME) & MASK64) % self.num_bits  # :85-93 (usize = u64)
+
+    def insert(self, item):
+        self.bits.add(self._slot(item))
+
+    def contains(self, item):
+        return self._slot(item) in self.bits
+
+    def estimate_card(self):
+        """:108-123 - the logarithm is cast to i64 BEFORE the multiplication (truncation toward zero)."""
+        ones = len(self.bits)
+        if ones == 0 or self.num_bits == 0:
+            return 0
+        if ones == self.num_bits:
+            return (1 << 64) - 1
+        v = -self.num_bits * int(math.log(1.0 - float(ones) / float(self.num_bits)))
+        return v if 0 <= v < (1 << 64) else 0  # try_into::<u64>().unwrap_or_default()
+
+
+def harmonic_centrality_reference(edges, pages=None):
+    """calculate_centrality (harmonic.rs:215-287) with the bloom filter, the exact-counting switch and the
+    sqrt(n) tail as written.  pages: the page-level (from_id, to_id, rel_flags) records ForwardlinksQuery matches
+    in the tail; None = host-level edges (then the result equals harmonic_centrality()).
+    Returns (dict, passes, passes that took update_changed_counters)."""
+    nodes = sorted({x for e in edges for x in (e[0], e[1])})
+    n = len(nodes)
+    if n == 0:
+        return {}, 0, 0
+    seen, kept = set(), []
+    for e in edges:
+        k = (e[0], e[1])
+        if k in seen:
+            continue
+        seen.add(k)
+        if (e[2] if len(e) > 2 else 0) & SKIPPED_REL:
+            continue
+        kept.append(k)
+    node_set = set(nodes)
+    fwd = {}
+    tail_src = kept if pages is None else [(e[0], e[1]) for e in pages if not ((e[2] if len(e) > 2 else 0) & SKIPPED_REL)]
+    for (f, to) in tail_src:
+        if f in node_set and to in node_set:  # harmonic.rs:91-92
+            fwd.setdefault(f, []).append(to)
+    old = {}
+    for v in nodes:
+        c = hll_new()
+        hll_add(c, v)
+        old[v] = c
+    new = {v: list(c) for v, c in old.items()}
+    cent = {v: Kahan() for v in nodes}
+    changed = Bloom(n)  # :221-225
+    for v in nodes:
+        changed.insert(v)
+    threshold = int(round(max(math.sqrt(float(n)), 0.0)))  # :228 (f64::round: half away from zero; sqrt is never x.5)
+    exact_counting, has_changes, t, tail_passes = False, True, 0, 0
+    exact_changed = set()
+    while has_changes:
+        new_changed = Bloom(n)
+        has_changes = False
+        if exact_changed and len(exact_changed) <= threshold:  # :244-252 update_changed_counters
+            tail_passes += 1
+            nxt = set()
+            for u in sorted(exact_changed):
+                for to in fwd.get(u, ()):
+                    fc, tc = old[u], new[to]
+                    if any(a > b for a, b in zip(fc, tc)):
+                        hll_merge(tc, fc)
+                        new_changed.insert(to)
+                        nxt.add(to)
+                        has_changes = True
+            exact_changed = nxt
+        else:  # update_all_counters, :116-157
+            track = exact_counting
+            if track:
+                exact_changed = set()
+            for (f, to) in kept:
+                if not changed.contains(f):
+                    continue
+                fc, tc = old[f], new[to]
+                if any(a > b for a, b in zip(fc, tc)):
+                    hll_merge(tc, fc)
+                    new_changed.insert(to)
+                    if track:
+                        exact_changed.add(to)
+                    has_changes = True
+        for v in nodes:
+            sn, so = hll_size(new[v]), hll_size(old[v])
+            cent[v].add(float(sn - so if sn >= so else 0) / float(t + 1))
+        old = {v: list(c) for v, c in new.items()}
+        changed = new_changed
+        t += 1
+        if changed.estimate_card() <= threshold:  # :277-279
+            exact_counting = True
+    out = {}
+    if n >= 2:
+        norm = float(n - 1)
+        for v in nodes:
+            c = cent[v].sum
+            if c > 0.0:
+                c = c / norm
+                out[v] = c if math.isfinite(c) else 0.0
+    return out, t, tail_passes

@@ -28,6 +28,7 @@ HB_FLAG_DEST_PARTITION = 0x200
 HB_FLAG_HOST_INGEST = 0x400
 HB_FLAG_HOST_PLAN = 0x800
 HB_FLAG_CHANGED_ONLY = 0x1000
+HB_FLAG_REFERENCE_TAIL = 0x2000
 
 # numpy views of the plain-data structs
 U128 = np.dtype([("lo", "<u8"), ("hi", "<u8")])
@@ -111,6 +112,7 @@ _SIGNATURES = [
     ("hb_load_edges", ctypes.c_int, [_P, _P, _U64, _P, _U64]),
     ("hb_append_edges", ctypes.c_int, [_P, _P, _U64]),
     ("hb_finalize", ctypes.c_int, [_P, _P, _U64]),
+    ("hb_load_tail_edges", ctypes.c_int, [_P, _P, _U64]),
     ("hb_load_dense", ctypes.c_int, [_P, _P, _U64, _P, _P, _U64]),
     ("hb_run", ctypes.c_int, [_P, ctypes.POINTER(HbStats)]),
     ("hb_begin", ctypes.c_int, [_P]),
@@ -259,6 +261,11 @@ class Context:
     def append_edges(self, edges):
         edges = np.ascontiguousarray(edges, dtype=EDGE)
         self._check(self.lib.hb_append_edges(self.h, _ptr(edges), len(edges)))
+
+    def load_tail_edges(self, records):
+        """HB_FLAG_REFERENCE_TAIL: the page-level records update_changed_counters follows (harmonic.rs:82-92)."""
+        records = np.ascontiguousarray(records, dtype=EDGE)
+        self._check(self.lib.hb_load_tail_edges(self.h, _ptr(records) if len(records) else None, len(records)))
 
     def finalize(self, node_ids=None):
         n = 0

@@ -86,6 +86,19 @@ struct hb_ctx {
     uint64_t *d_wprefix = nullptr;
     std::vector<uint64_t> ex_off; // world + 1: first packed position of every rank's slice
     uint64_t wire_bytes = 0;      // counter bytes this rank received over the run (changed-only accounting)
+    // reference-tail mode (HB_FLAG_REFERENCE_TAIL): the reference's changed-node machinery as written
+    uint64_t *d_tail_ptr = nullptr; // page-level records by source device row (hb_load_tail_edges), n_pad + 1
+    uint32_t *d_tail_to = nullptr;
+    uint64_t tail_count = 0;
+    uint32_t *d_bloom = nullptr;    // new_changed_nodes of the last pass (U64BloomFilter), bloom_bits bits
+    uint64_t bloom_bits = 0;
+    unsigned long long *d_bloom_ones = nullptr; // [0] count_ones, [1] (low word) length of d_list
+    uint32_t *d_list = nullptr;     // exact_changed_nodes as device rows, <= ref_threshold entries
+    uint64_t ref_threshold = 0;     // exact_counting_threshold (harmonic.rs:228)
+    bool exact_counting = false;    // harmonic.rs:231,277-279
+    bool exact_valid = false;       // the previous pass filled exact_changed_nodes (ran with Some(..) or was a tail pass)
+    bool stale = false;             // a tail pass has run: host-level edges may have been skipped, the bloom filter's
+                                    // false positives are no longer results-inert
 
     // loop state
     uint64_t t = 0;
@@ -173,6 +186,12 @@ void free_graph_buffers(hb_ctx *c)
     c->d_seeds = c->d_heavy = nullptr;
     c->d_sparse_counts = nullptr;
     c->sparse_ok = false;
+    c->d_tail_ptr = nullptr;
+    c->d_tail_to = nullptr;
+    c->tail_count = 0;
+    c->d_bloom = nullptr;
+    c->d_bloom_ones = nullptr;
+    c->d_list = nullptr;
     if (c->h_out) (void)hipHostFree(c->h_out);
     c->h_out = nullptr;
     c->h_out_len = 0;
@@ -202,9 +221,10 @@ bool dest_mode(const hb_ctx *c)
 }
 // edge partition: every rank holds some in-edges of every row; one all-reduce(max) of all counters per pass
 bool edge_partitioned(const hb_ctx *c) { return multi_rank(c) && !dest_mode(c); }
+bool ref_tail(const hb_ctx *c) { return (c->opt.flags & HB_FLAG_REFERENCE_TAIL) != 0; }
 bool unfused(const hb_ctx *c)
 {
-    return edge_partitioned(c) || (c->comm && !dest_mode(c)) || (c->opt.flags & HB_FLAG_UNFUSED);
+    return edge_partitioned(c) || (c->comm && !dest_mode(c)) || (c->opt.flags & HB_FLAG_UNFUSED) || ref_tail(c);
 }
 
 // Transposed work-row graph (who reads each node / virtual row), touch bitmap and seed lists for the
@@ -623,6 +643,76 @@ int exchange_unpack(hb_ctx *c)
     return HB_OK;
 }
 
+// ---- reference-tail mode ---------------------------------------------------------------------------------
+// bloom/src/lib.rs:38-41
+uint64_t bloom_num_bits(uint64_t estimated_items, double fp)
+{
+    const double ln2 = std::log(2.0);
+    return (uint64_t)std::ceil((double)estimated_items * std::log(fp) / (-8.0 * (ln2 * ln2)));
+}
+// bloom/src/lib.rs:108-123: the logarithm is cast to i64 BEFORE the multiplication; a negative product -> 0
+uint64_t bloom_estimate_card(uint64_t num_bits, uint64_t num_ones)
+{
+    if (num_ones == 0 || num_bits == 0) return 0;
+    if (num_ones == num_bits) return ~0ull;
+    const int64_t l = (int64_t)std::log(1.0 - (double)num_ones / (double)num_bits);
+    const int64_t v = -(int64_t)num_bits * l;
+    return v < 0 ? 0 : (uint64_t)v;
+}
+
+// update_changed_counters (harmonic.rs:75-114): counters.new starts as the clone of counters.old (Counters::step),
+// the changed nodes push their OLD counter along the page-level records; everything else (changed bits, sizes,
+// Kahan) is the unfused epilogue of step_finish, like after any other pass
+int tail_pass(hb_ctx *c, const hbk::PassParams &pp)
+{
+    const Plan &p = c->plan;
+    c->cur_mode = 3;
+    c->stale = true;
+    unsigned int *d_len = (unsigned int *)(c->d_bloom_ones + 1);
+    HB_HIP(hipMemcpyAsync(pp.wr, pp.rd, p.n_pad * 64, hipMemcpyDeviceToDevice, c->stream));
+    HB_HIP(hipMemsetAsync(d_len, 0, sizeof(unsigned int), c->stream));
+    const unsigned blocks = (unsigned)std::min<uint64_t>(std::max<uint64_t>(p.n_pad / 256, 1), (uint64_t)c->num_cu * 8);
+    hipLaunchKernelGGL(hbk::changed_list_kernel, dim3(blocks), dim3(256), 0, c->stream, pp.bits_rd, p.n_pad, c->d_list, d_len,
+                       (uint32_t)(c->ref_threshold + 1));
+    HB_HIP(hipEventRecord(c->ev[5], c->stream));
+    HB_HIP(hipEventRecord(c->ev[1], c->stream));
+    const unsigned tblocks = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((c->last_changed + 3) / 4, (uint64_t)c->num_cu * 8));
+    hipLaunchKernelGGL(hbk::tail_merge_kernel, dim3(tblocks), dim3(256), 0, c->stream, (const uint32_t *)c->d_list, (const unsigned int *)d_len,
+                       (const uint64_t *)c->d_tail_ptr, (const uint32_t *)c->d_tail_to, (const uint32_t *)pp.rd, (uint32_t *)pp.wr);
+    HB_HIP(hipEventRecord(c->ev[2], c->stream));
+    HB_HIP(hipGetLastError());
+    c->pending_local = true;
+    return HB_OK;
+}
+
+// after a pass: new_changed_nodes as the reference builds it, and the exact-counting switch (harmonic.rs:273-279)
+int reference_changed_state(hb_ctx *c, const uint32_t *bits_changed, uint64_t changed)
+{
+    const Plan &p = c->plan;
+    const bool tracked = c->cur_mode == 3 || c->exact_counting; // this pass ran with Some(&mut exact_changed_nodes)
+    if (!c->exact_counting || c->stale) {
+        const uint64_t words = (c->bloom_bits + 31) / 32;
+        HB_HIP(hipMemsetAsync(c->d_bloom, 0, (words + 1) * 4, c->stream));
+        HB_HIP(hipMemsetAsync(c->d_bloom_ones, 0, sizeof(unsigned long long), c->stream));
+        unsigned long long ones = 0;
+        if (changed && c->bloom_bits) {
+            const unsigned blocks = (unsigned)std::min<uint64_t>(std::max<uint64_t>(p.n_pad / 256, 1), (uint64_t)c->num_cu * 8);
+            hipLaunchKernelGGL(hbk::bloom_insert_kernel, dim3(blocks), dim3(256), 0, c->stream, bits_changed, (const uint64_t *)c->d_idlow, p.n_pad,
+                               c->bloom_bits, c->d_bloom);
+            if (!c->exact_counting) {
+                const unsigned cblocks = (unsigned)std::min<uint64_t>(std::max<uint64_t>(words / 256, 1), (uint64_t)c->num_cu * 8);
+                hipLaunchKernelGGL(hbk::bloom_count_kernel, dim3(cblocks), dim3(256), 0, c->stream, (const uint32_t *)c->d_bloom, words, c->d_bloom_ones);
+                HB_HIP(hipMemcpyAsync(&ones, c->d_bloom_ones, sizeof(ones), hipMemcpyDeviceToHost, c->stream));
+                HB_HIP(hipStreamSynchronize(c->stream));
+            }
+            HB_HIP(hipGetLastError());
+        }
+        if (!c->exact_counting && bloom_estimate_card(c->bloom_bits, ones) <= c->ref_threshold) c->exact_counting = true;
+    }
+    c->exact_valid = tracked;
+    return HB_OK;
+}
+
 int step_local(hb_ctx *c)
 {
     if (!c->begun || c->finished) return fail(c, HB_ERR_INVALID, "hb_step*: call hb_begin first");
@@ -636,8 +726,8 @@ int step_local(hb_ctx *c)
     // bit-tested, only active sources are gathered (pays while A_t < ~half of the edges); sparse: only the
     // work rows that read a changed node are visited at all.
     const uint32_t thr = c->opt.tune[2] ? c->opt.tune[2] : 50; // frontier when A_t < thr % of the edges
-    const bool frontier = !(c->opt.flags & HB_FLAG_NO_FRONTIER) && c->t > 0 &&
-                          (c->last_active * 100ull < (uint64_t)thr * c->m_global || thr > 100);
+    bool frontier = !(c->opt.flags & HB_FLAG_NO_FRONTIER) && c->t > 0 &&
+                    (c->last_active * 100ull < (uint64_t)thr * c->m_global || thr > 100);
     // sweep mode when A_t * div < edges: measured crossover with the bitmap pass at A_t = 10-12 % of the edges
     // (profiles/r02c_sweep_*: 7.4 % -> 1.25 ms vs 2.15 ms, 16 % -> 4.1 ms vs 2.1 ms on the C3-sized graphs)
     const uint64_t sparse_div = c->opt.tune[6] ? c->opt.tune[6] : 10;
@@ -646,6 +736,20 @@ int step_local(hb_ctx *c)
     const bool fused = !unfused(c);
     hbk::PassParams pp = make_params(c);
     HB_HIP(hipEventRecord(c->ev[0], c->stream));
+    if (ref_tail(c)) {
+        // harmonic.rs:244-246: `!exact_changed_nodes.is_empty() && exact_changed_nodes.len() <= threshold`
+        if (c->exact_valid && c->last_changed != 0 && c->last_changed <= c->ref_threshold) return tail_pass(c, pp);
+        if (c->stale && c->t > 0) {
+            // update_all_counters after a tail pass: sources pass `changed_nodes.contains_u128` (harmonic.rs:133) - the
+            // bloom filter of the previous pass' changed nodes INCLUDING its false positives (they may hold updates a
+            // tail pass did not deliver); never a dense pass (it would deliver all of them)
+            frontier = true;
+            c->cur_mode = 1;
+            hipLaunchKernelGGL(hbk::bloom_frontier_kernel, dim3((unsigned)(p.n_pad / 256 + 1)), dim3(256), 0, c->stream, (const uint32_t *)c->d_bloom,
+                               (const uint64_t *)c->d_idlow, (const uint32_t *)c->d_sid_of, p.n_pad, c->bloom_bits, c->d_bits[c->cur]);
+            HB_HIP(hipGetLastError());
+        }
+    }
     if (sparse) {
         // sweep mode: changed nodes -> touch bits of their readers; then the levels, then the node rows
         hbk::SweepParams sp{};
@@ -794,12 +898,16 @@ int step_finish(hb_ctx *c, int *has_changes)
     ps.ms_gpu = ms_all;
     ps.ms_main = ms_main;
     ps.ms_collective = c->comm ? ms_coll : 0.f;
-    if (c->cur_mode != 2 && p.level_begin.size() > 1) {
+    if (c->cur_mode < 2 && p.level_begin.size() > 1) {
         float ms_l1 = 0.f;
         HB_HIP(hipEventElapsedTime(&ms_l1, c->ev[0], c->ev[5]));
         ps.ms_level1 = ms_l1;
     }
     c->pstats.push_back(ps);
+    if (ref_tail(c)) {
+        int rc = reference_changed_state(c, (const uint32_t *)c->d_bits[c->cur ^ 1], ps.changed);
+        if (rc) return rc;
+    }
     // counters.step(); changed_nodes = new_changed_nodes; t += 1 (harmonic.rs:273-275)
     c->last_changed = ps.changed;
     c->last_active = c->h_counters[3];
@@ -916,6 +1024,8 @@ int hb_create(const hb_options *opt, hb_ctx **out)
         if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
             return fail(c, HB_ERR_NO_DEVICE, std::string("device is ") + prop.gcnArchName + ", kernels are built for gfx950 only");
         if (o.world_size > 1 && (o.rank < 0 || o.rank >= o.world_size)) return fail(c, HB_ERR_INVALID, "rank out of range");
+        if ((o.flags & HB_FLAG_REFERENCE_TAIL) && (o.world_size > 1 || (o.flags & (HB_FLAG_RCCL_SELF | HB_FLAG_DEST_PARTITION))))
+            return fail(c, HB_ERR_INVALID, "HB_FLAG_REFERENCE_TAIL is a single-rank mode (no partition / RCCL flags)");
         hb_ctx *ctx = new (std::nothrow) hb_ctx();
         if (!ctx) return fail(c, HB_ERR_NOMEM, "out of host memory");
         ctx->opt = o;
@@ -1112,6 +1222,43 @@ int hb_finalize(hb_ctx *c, const hb_u128 *node_ids, uint64_t n)
     });
 }
 
+int hb_load_tail_edges(hb_ctx *c, const hb_edge *records, uint64_t count)
+{
+    return guarded(c, [&]() -> int {
+        if (!c) return HB_ERR_INVALID;
+        if (!ref_tail(c)) return fail(c, HB_ERR_INVALID, "hb_load_tail_edges: create the context with HB_FLAG_REFERENCE_TAIL");
+        if (!c->loaded) return fail(c, HB_ERR_INVALID, "hb_load_tail_edges: load the graph first");
+        if (count && !records) return fail(c, HB_ERR_INVALID, "records == NULL with count > 0");
+        int rc = set_device(c);
+        if (rc) return rc;
+        if ((rc = need_host_dev_of(c))) return rc;
+        const Plan &p = c->plan;
+        std::vector<uint64_t> ptr;
+        std::vector<uint32_t> to;
+        const std::string e = map_tail_records(c->g.ids.data(), c->g.ids.size(), p.dev_of.data(), p.n_pad, records, count, &ptr, &to);
+        if (!e.empty()) return fail(c, HB_ERR_NOMEM, e);
+        for (void *old : {(void *)c->d_tail_ptr, (void *)c->d_tail_to}) { // replace the records of an earlier call
+            if (!old) continue;
+            for (size_t i = 0; i < c->allocs.size(); i++)
+                if (c->allocs[i].p == old) {
+                    c->stats.device_bytes -= c->allocs[i].bytes;
+                    (void)hipFree(old);
+                    c->allocs.erase(c->allocs.begin() + (long)i);
+                    break;
+                }
+        }
+        c->d_tail_ptr = nullptr;
+        c->d_tail_to = nullptr;
+        if ((rc = dev_alloc(c, &c->d_tail_ptr, p.n_pad + 1))) return rc;
+        if ((rc = dev_alloc(c, &c->d_tail_to, to.size() + 1))) return rc;
+        HB_HIP(hipMemcpyAsync(c->d_tail_ptr, ptr.data(), (p.n_pad + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
+        if (!to.empty()) HB_HIP(hipMemcpyAsync(c->d_tail_to, to.data(), to.size() * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+        HB_HIP(hipStreamSynchronize(c->stream));
+        c->tail_count = to.size();
+        return HB_OK;
+    });
+}
+
 int hb_load_dense(hb_ctx *c, const hb_u128 *sorted_ids, uint64_t n, const uint64_t *row_ptr, const uint32_t *src,
                   uint64_t m_eff)
 {
@@ -1192,6 +1339,22 @@ int hb_begin(hb_ctx *c)
                                c->d_regs[0], c->d_regs[1], c->d_ksum, c->d_kerr, c->d_size, c->d_bits[0], c->d_kdirty,
                                c->d_raw, c->d_bias, c->d_lc);
             HB_HIP(hipGetLastError());
+        }
+        if (ref_tail(c)) {
+            // harmonic.rs:221,228: U64BloomFilter::new(num_nodes, 0.05); threshold = sqrt(num_nodes).max(0).round()
+            c->bloom_bits = bloom_num_bits(p.n, 0.05);
+            c->ref_threshold = (uint64_t)std::round(std::max(std::sqrt((double)p.n), 0.0));
+            if (!c->d_bloom) {
+                if ((rc = dev_alloc(c, &c->d_bloom, (c->bloom_bits + 31) / 32 + 2))) return rc;
+                if ((rc = dev_alloc(c, &c->d_bloom_ones, 2))) return rc;
+                if ((rc = dev_alloc(c, &c->d_list, c->ref_threshold + 2))) return rc;
+            }
+            if (!c->d_tail_ptr) { // no hb_load_tail_edges: the forward-links query finds nothing
+                if ((rc = dev_alloc(c, &c->d_tail_ptr, p.n_pad + 1))) return rc;
+                if ((rc = dev_alloc(c, &c->d_tail_to, 1))) return rc;
+                HB_HIP(hipMemsetAsync(c->d_tail_ptr, 0, (p.n_pad + 1) * sizeof(uint64_t), c->stream));
+            }
+            c->exact_counting = c->exact_valid = c->stale = false;
         }
         HB_HIP(hipStreamSynchronize(c->stream));
         c->t = 0;

@@ -1147,6 +1147,93 @@ __global__ __launch_bounds__(256) void unpack_changed_kernel(uint4 *wr, const ui
     }
 }
 
+// ---- reference-tail mode (HB_FLAG_REFERENCE_TAIL): the changed-node machinery of the reference as written -----------
+// U64BloomFilter::insert_u128 (bloom/src/lib.rs:85-98): slot = (low 64 bits of the id * LARGE_PRIME) % num_bits.
+constexpr unsigned long long kBloomPrime = 11400714819323198549ull;
+__device__ __forceinline__ uint64_t bloom_slot(uint64_t id_low, uint64_t num_bits) { return (id_low * kBloomPrime) % num_bits; }
+
+// new_changed_nodes of one pass: a bit per slot of every changed node (harmonic.rs:145,103)
+__global__ __launch_bounds__(256) void bloom_insert_kernel(const uint32_t *bits, const uint64_t *id_low, uint64_t n_pad, uint64_t num_bits,
+                                                           uint32_t *bloom)
+{
+    for (uint64_t row = (uint64_t)blockIdx.x * 256 + threadIdx.x; row < n_pad; row += (uint64_t)gridDim.x * 256) {
+        if (!((bits[row >> 5] >> (row & 31u)) & 1u)) continue;
+        const uint64_t s = bloom_slot(id_low[row], num_bits);
+        atomicOr(&bloom[s >> 5], 1u << (s & 31u));
+    }
+}
+// bit_vec.count_ones() (bloom/src/lib.rs:109)
+__global__ __launch_bounds__(256) void bloom_count_kernel(const uint32_t *bloom, uint64_t words, unsigned long long *out)
+{
+    unsigned long long c = 0;
+    for (uint64_t w = (uint64_t)blockIdx.x * 256 + threadIdx.x; w < words; w += (uint64_t)gridDim.x * 256) c += __popc(bloom[w]);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off);
+    if ((threadIdx.x & 63) == 0 && c) atomicAdd(out, c);
+}
+// changed_nodes.contains_u128(edge.from) (harmonic.rs:133) for every node: the frontier WITH the filter's false
+// positives - they are results-inert only as long as no tail pass has skipped host-level edges (hb_api.hip)
+__global__ __launch_bounds__(256) void bloom_frontier_kernel(const uint32_t *bloom, const uint64_t *id_low, const uint32_t *sid_of,
+                                                             uint64_t n_pad, uint64_t num_bits, uint32_t *bits)
+{
+    const uint64_t row = (uint64_t)blockIdx.x * 256 + threadIdx.x; // n_pad is a multiple of 64: whole waves
+    if (row >= n_pad) return;
+    bool in = false;
+    if (sid_of[row] != kNone) {
+        const uint64_t s = bloom_slot(id_low[row], num_bits);
+        in = (bloom[s >> 5] >> (s & 31u)) & 1u;
+    }
+    const uint64_t bal = __ballot(in);
+    if ((threadIdx.x & 63) == 0) {
+        bits[row >> 5] = (uint32_t)bal;
+        bits[(row >> 5) + 1] = (uint32_t)(bal >> 32);
+    }
+}
+// exact_changed_nodes (harmonic.rs:146-148,105) as a list of device rows; order is irrelevant (max is commutative)
+__global__ __launch_bounds__(256) void changed_list_kernel(const uint32_t *bits, uint64_t n_pad, uint32_t *list, unsigned int *count, uint32_t cap)
+{
+    for (uint64_t row = (uint64_t)blockIdx.x * 256 + threadIdx.x; row < n_pad; row += (uint64_t)gridDim.x * 256) {
+        if (!((bits[row >> 5] >> (row & 31u)) & 1u)) continue;
+        const unsigned int k = atomicAdd(count, 1u);
+        if (k < cap) list[k] = (uint32_t)row;
+    }
+}
+__device__ __forceinline__ uint32_t bytes_max(uint32_t a, uint32_t b)
+{
+    uint32_t r = 0;
+#pragma unroll
+    for (int k = 0; k < 32; k += 8) {
+        const uint32_t x = (a >> k) & 0xFFu, y = (b >> k) & 0xFFu;
+        r |= (x > y ? x : y) << k;
+    }
+    return r;
+}
+// update_changed_counters (harmonic.rs:75-114): for every changed node u and every record (u -> v) the forward-links
+// query returns: counters.new[v] = max(counters.new[v], counters.old[u]) register-wise.  One wave per changed node,
+// 4 records x 16 words at a time; targets are shared between nodes, hence the compare-and-swap.  wr = copy of rd.
+__global__ __launch_bounds__(256) void tail_merge_kernel(const uint32_t *list, const unsigned int *count, const uint64_t *tail_ptr,
+                                                         const uint32_t *tail_to, const uint32_t *rd, uint32_t *wr)
+{
+    const uint32_t lane = threadIdx.x & 63u, k = lane >> 4, w = lane & 15u;
+    const uint32_t total = *count;
+    for (uint32_t i = blockIdx.x * 4 + (threadIdx.x >> 6); i < total; i += gridDim.x * 4) {
+        const uint64_t u = list[i];
+        const uint32_t from = rd[u * 16 + w];
+        const uint64_t e = tail_ptr[u + 1];
+        for (uint64_t j = tail_ptr[u] + k; j < e; j += 4) {
+            uint32_t *dst = &wr[(uint64_t)tail_to[j] * 16 + w];
+            uint32_t old = __hip_atomic_load(dst, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (;;) {
+                const uint32_t nw = bytes_max(old, from);
+                if (nw == old) break;
+                const uint32_t prev = atomicCAS(dst, old, nw);
+                if (prev == old) break;
+                old = prev;
+            }
+        }
+    }
+}
+
 // ---- normalize_centralities (harmonic.rs:178-195) -----------------------------------------
 // out[sid] for sid in ascending-NodeID order: f64::from(KahanSum) = sum (kahan_sum.rs:35-39);
 // kept iff > 0.0, then / norm, non-finite -> 0.0; absent nodes are marked -1.0.

@@ -109,3 +109,20 @@ def random_graph(rng, kind=None):
         for _ in range(4 * n):
             edges.add((int(rng.integers(1, half + 1)), int(rng.integers(half + 1, n + 2))))
     return kind, sorted(edges)
+
+
+def tailed_graph(core=300, core_edges=1500, chain=120, seed=7, branch=3):
+    """A graph that reaches the reference's sqrt(n) tail (harmonic.rs:244-252): an LCG core whose node 1 feeds a
+    chain of `chain` hosts with a few side branches.  Ids are salted so that bloom slots are not trivially distinct.
+    Returns host-level tuples (from, to, 0)."""
+    salt = 0x9E3779B97F4A7C15
+    def nid(k):
+        return ((k * salt) & 0xFFFFFFFFFFFFFFFF) | (k << 64)
+    e = [(nid(f), nid(t), 0) for f, t in lcg_graph(core, core_edges, seed)]
+    first = core + 1
+    e.append((nid(1), nid(first), 0))
+    for k in range(chain - 1):
+        e.append((nid(first + k), nid(first + k + 1), 0))
+        if branch and k % branch == 0:
+            e.append((nid(first + k), nid(first + chain + k), 0))  # a leaf hanging off the chain
+    return e

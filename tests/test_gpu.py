@@ -535,3 +535,62 @@ def test_c2_config_bit_exact_and_properties(gpu_ctx_factory):
             _check_final(ctx, g.ids, T, vals, keep, st2)
             outs.append(regs)
     assert np.array_equal(outs[0], outs[1])
+
+
+@pytest.mark.gpu
+def test_reference_tail_mode(gpu_ctx_factory):
+    """HB_FLAG_REFERENCE_TAIL: the reference's changed-node machinery as written (bloom filter with its false
+    positives, exact-counting switch, sqrt(n) tail over page-level forward links) - against the
+    faithful oracle given the same page-level records: ids, values (bits), pass count and the number of tail passes."""
+    host = graphs.tailed_graph()
+    foreign = [(0xDEAD0000 + k, host[k][1], 0) for k in range(5)] + [(host[k][0], 0xBEEF0000 + k, 0) for k in range(5)]
+    flagged = [(f, t, graphs.NOFOLLOW) for f, t, _ in host[-40:]]
+    e = graphs.EdgeListGraph.from_tuples(host).host_edges()
+    to_edges = lambda tuples: graphs.EdgeListGraph.from_tuples(tuples).host_edges() if tuples else np.zeros(0, dtype=_lib.EDGE)
+    cases = {"all_host_edges_as_pages": list(host), "no_call": None, "no_root_links": [], "every_other": host[::2] + foreign,
+             "chain_links_flagged": host[:-40] + flagged}
+    base_ids, base_vals, base_st = hbo.faithful_run(e)
+    differs = 0
+    for name, pages in cases.items():
+        recs = None if pages is None else to_edges(pages)
+        fids, fvals, fst = hbo.faithful_run(e, recs if recs is not None else np.zeros(0, dtype=hbo.EDGE))
+        for extra in (0, _lib.HB_FLAG_HOST_PLAN):
+            with gpu_ctx_factory(flags=_lib.HB_FLAG_REFERENCE_TAIL | extra) as ctx:
+                ctx.load_edges(e)
+                if recs is not None:
+                    ctx.load_tail_edges(recs[::-1])   # order of the records is irrelevant
+                    ctx.load_tail_edges(recs)         # a second call replaces the first
+                st = ctx.run()
+                ids, vals = ctx.results()
+                modes = [ps["mode"] for ps in ctx.pass_stats()]
+            assert st["passes"] == fst["passes"], (name, modes)
+            assert modes.count(3) == fst["passes_exact"], (name, modes)
+            assert np.array_equal(ids, fids), name
+            assert np.array_equal(vals.view(np.uint64), fvals.view(np.uint64)), name
+        if name == "all_host_edges_as_pages":   # pages are hosts: same list as the default mode
+            assert np.array_equal(ids, base_ids) and np.array_equal(vals.view(np.uint64), base_vals.view(np.uint64))
+            assert fst["passes_exact"] > 10
+        else:
+            differs += int(len(vals) != len(base_vals) or not np.array_equal(vals.view(np.uint64), base_vals.view(np.uint64)))
+    assert differs >= 3
+    # a graph that falls back from the tail to update_all_counters with a stale bloom frontier: a wide levelled tail
+    g = synth.RmatGraph(11, 9_000, tail=(600, 900, 3))
+    e = g.edges(salt=1, salt_seed=5)
+    rng = np.random.default_rng(3)
+    recs = e[rng.random(len(e)) < 0.7]
+    fids, fvals, fst = hbo.faithful_run(e, recs)
+    with gpu_ctx_factory(flags=_lib.HB_FLAG_REFERENCE_TAIL) as ctx:
+        ctx.load_edges(e)
+        ctx.load_tail_edges(recs)
+        st = ctx.run()
+        ids, vals = ctx.results()
+        modes = [ps["mode"] for ps in ctx.pass_stats()]
+    assert st["passes"] == fst["passes"] and modes.count(3) == fst["passes_exact"], (modes, fst)
+    assert np.array_equal(ids, fids) and np.array_equal(vals.view(np.uint64), fvals.view(np.uint64))
+    # the mode is single-rank, and the records need the flag
+    with pytest.raises(Exception):
+        gpu_ctx_factory(flags=_lib.HB_FLAG_REFERENCE_TAIL | _lib.HB_FLAG_NO_RCCL, rank=0, world_size=2)
+    with gpu_ctx_factory() as ctx:
+        ctx.load_edges(e)
+        with pytest.raises(Exception):
+            ctx.load_tail_edges(recs)

@@ -418,3 +418,59 @@ def test_generalised_estimator_agrees_with_the_c_oracle_at_64():
     rng = np.random.default_rng(11)
     for regs in graphs.random_registers(rng, 300):
         assert pyref.hll_size([int(x) for x in regs]) == hbo.hll_size(regs)
+
+
+def _tuples_to_edges(tuples):
+    return graphs.EdgeListGraph.from_tuples(tuples).host_edges() if tuples else np.zeros(0, dtype=hbo.EDGE)
+
+
+def _faithful_dict(edges, pages):
+    ids, vals, st = hbo.faithful_run(edges, pages)
+    return {(int(h) << 64) | int(l): float(v) for l, h, v in zip(ids["lo"], ids["hi"], vals)}, st
+
+
+def test_reference_tail_two_restatements_agree():
+    """The reference's loop AS WRITTEN (bloom filter with false positives, exact-counting switch, sqrt(n) tail over
+    page-level forward links - SURVEY.md App. C-5): the Python restatement against the C oracle, bit for bit."""
+    from oracle import pyref
+
+    host = graphs.tailed_graph()
+    foreign = [(0xDEAD0000 + k, host[k][1], 0) for k in range(5)] + [(host[k][0], 0xBEEF0000 + k, 0) for k in range(5)]
+    flagged = [(f, t, graphs.NOFOLLOW) for f, t, _ in host[-40:]]
+    cases = {
+        "host_level": None,                          # pages are hosts: the default semantics
+        "all_host_edges_as_pages": list(host),       # same thing said through the page-level interface
+        "no_root_links": [],                         # the query finds nothing: the tail stops at once
+        "every_other": host[::2] + foreign,          # some links exist at page level; unknown ids fall out (harmonic.rs:91-92)
+        "chain_links_flagged": host[:-40] + flagged, # rel filter on the query result (harmonic.rs:87)
+    }
+    e = _tuples_to_edges(host)
+    base, base_passes = pyref.harmonic_centrality(host)
+    seen = {}
+    for name, pages in cases.items():
+        py, passes, tail_passes = pyref.harmonic_centrality_reference(host, pages)
+        got, st = _faithful_dict(e, None if pages is None else _tuples_to_edges(pages))
+        assert (st["passes"], st["passes_exact"]) == (passes, tail_passes), name
+        assert list(got.keys()) == list(py.keys()), name
+        assert [np.float64(v).view(np.uint64) for v in got.values()] == [np.float64(v).view(np.uint64) for v in py.values()], name
+        seen[name] = (py, passes, tail_passes)
+    # host-level pages: the machinery is results-inert (App. C-1) - same list as the plain iteration
+    for name in ("host_level", "all_host_edges_as_pages"):
+        assert seen[name][0] == base and seen[name][1] == base_passes and seen[name][2] > 0
+    # page-level tail: the run ends early and the end of the chain keeps smaller values (documented in DESIGN.md §5)
+    py, passes, tail_passes = seen["no_root_links"]
+    assert passes < base_passes and tail_passes == 1
+    diff = [k for k in base if base[k] != py.get(k)]
+    assert 0 < len(diff) < 60 and all(py.get(k, 0.0) < base[k] for k in diff)
+
+
+def test_pyref_bloom_matches_c_pieces():
+    from oracle import pyref
+
+    L = hbo.load()
+    for n in (1, 2, 7, 100, 1000, 12345, 10 ** 6):
+        assert pyref.bloom_num_bits(n) == L.hbo_bloom_num_bits(n, 0.05)
+    b = pyref.Bloom(1000)
+    for ones in (0, 1, 300, 492, 493, 600, 700, 779):
+        b.bits = set(range(ones))
+        assert b.estimate_card() == L.hbo_bloom_estimate_card(b.num_bits, ones), ones
