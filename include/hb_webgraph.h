@@ -28,7 +28,7 @@
  * FORMAT STATUS: "format unpinned" for whole files - no file written by the reference is available in this
  * image (no Rust toolchain).  Pinned against reference-held bytes: the sstable block framing
  * (sstable/mod.rs:373-396 test_simple_sstable) and the meta.json shape (index_meta.rs:436-440).  tests/ build
- * fixtures with a Python writer that follows the serialisers cited above line by line; tools/ref_fixture.rs
+ * fixtures with a Python writer that follows the serialisers cited above line by line; tools/ref_golden.rs
  * is the program that writes the same fixture with the reference itself.
  *
  * All functions: extern "C", never unwind, 0 = ok, negative = HB_ERR_* of hyperball.h.  Host only (no GPU).
@@ -47,6 +47,8 @@ extern "C" {
 typedef struct hbw_reader hbw_reader;
 
 #define HBW_VERIFY_CRC 0x1u /* check every .col file's CRC-32 against its footer (reads the whole file once) */
+#define HBW_PAGE_IDS   0x2u /* also locate the page-level `from_id` / `to_id` columns (webgraph/schema.rs:132-180): the records
+                               the reference's tail mode queries (harmonic.rs:82-87), see HB_FLAG_REFERENCE_TAIL */
 
 /* Opens `<webgraph>/edges` (the directory holding meta.json).  Maps every segment's .col file and locates the three
  * columns; fails if a column is missing, has another codec than Raw, or row counts disagree with meta.json. */
@@ -65,9 +67,13 @@ int hbw_total_rows(const hbw_reader *r, uint64_t *rows);
  * SmallSegmentEdgesIter order) into out[]: {from_host_id, to_host_id, rel_flags} = SmallEdge (edge.rs:31-35). */
 int hbw_read_host_edges(const hbw_reader *r, uint64_t first, uint64_t count, hb_edge *out);
 
+/* Same positions, page-level ids: {from_id, to_id, rel_flags} (reader opened with HBW_PAGE_IDS). */
+int hbw_read_page_edges(const hbw_reader *r, uint64_t first, uint64_t count, hb_edge *out);
+
 /* Replaces `HarmonicCentrality::calculate(&Webgraph)`'s input side end to end (harmonic.rs:292, :58-72, :116-131):
  * streams the store's records into ctx in slabs (hb_append_edges) and finalizes with the node set derived from all
- * endpoints (= host_nodes()).  Then hb_run() as usual. */
+ * endpoints (= host_nodes()).  Then hb_run() as usual.  With HBW_PAGE_IDS (ctx created with HB_FLAG_REFERENCE_TAIL) the
+ * page-level records follow through hb_append_tail_edges, so the run is `stract centrality harmonic` as written. */
 int hb_load_webgraph(hb_ctx *ctx, const char *edges_dir, uint32_t flags);
 
 /* ---- test exports ------------------------------------------------------------------------------------------- */

@@ -203,6 +203,10 @@ int hb_finalize(hb_ctx *ctx, const hb_u128 *node_ids, uint64_t n);
  * self links are harmless (max is idempotent).  Replaces the records of an earlier call; count == 0 = "the query
  * finds nothing" (also the state before the first call). */
 int hb_load_tail_edges(hb_ctx *ctx, const hb_edge *records, uint64_t count);
+/* The same in batches (a crawl's page-level documents do not fit one array): every batch is filtered and mapped at
+ * once, 8 bytes per surviving record stay on the host; batches add up (hb_load_tail_edges = forget all + append).
+ * The index is built and uploaded by the next hb_begin / hb_run. */
+int hb_append_tail_edges(hb_ctx *ctx, const hb_edge *records, uint64_t count);
 
 /* Pre-reduced input (bench / large synthetic graphs): sorted_ids strictly ascending;
  * in-edges of node v (the v-th smallest id) are src[row_ptr[v] .. row_ptr[v+1]), already

@@ -113,6 +113,7 @@ _SIGNATURES = [
     ("hb_append_edges", ctypes.c_int, [_P, _P, _U64]),
     ("hb_finalize", ctypes.c_int, [_P, _P, _U64]),
     ("hb_load_tail_edges", ctypes.c_int, [_P, _P, _U64]),
+    ("hb_append_tail_edges", ctypes.c_int, [_P, _P, _U64]),
     ("hb_load_dense", ctypes.c_int, [_P, _P, _U64, _P, _P, _U64]),
     ("hb_run", ctypes.c_int, [_P, ctypes.POINTER(HbStats)]),
     ("hb_begin", ctypes.c_int, [_P]),
@@ -150,6 +151,7 @@ _SIGNATURES += [
     ("hbw_segment_info", ctypes.c_int, [_P, _U64, ctypes.c_char_p, ctypes.POINTER(_U64)]),
     ("hbw_total_rows", ctypes.c_int, [_P, ctypes.POINTER(_U64)]),
     ("hbw_read_host_edges", ctypes.c_int, [_P, _U64, _U64, _P]),
+    ("hbw_read_page_edges", ctypes.c_int, [_P, _U64, _U64, _P]),
     ("hb_load_webgraph", ctypes.c_int, [_P, ctypes.c_char_p, ctypes.c_uint32]),
     ("hbw_debug_sstable", ctypes.c_int, [_P, _U64, ctypes.c_int, _P, _U64, _P, _U64, ctypes.POINTER(_U64)]),
     ("hbw_debug_crc32", ctypes.c_uint32, [_P, _U64]),
@@ -266,6 +268,10 @@ class Context:
         """HB_FLAG_REFERENCE_TAIL: the page-level records update_changed_counters follows (harmonic.rs:82-92)."""
         records = np.ascontiguousarray(records, dtype=EDGE)
         self._check(self.lib.hb_load_tail_edges(self.h, _ptr(records) if len(records) else None, len(records)))
+
+    def append_tail_edges(self, records):
+        records = np.ascontiguousarray(records, dtype=EDGE)
+        self._check(self.lib.hb_append_tail_edges(self.h, _ptr(records) if len(records) else None, len(records)))
 
     def finalize(self, node_ids=None):
         n = 0

@@ -90,6 +90,8 @@ struct hb_ctx {
     uint64_t *d_tail_ptr = nullptr; // page-level records by source device row (hb_load_tail_edges), n_pad + 1
     uint32_t *d_tail_to = nullptr;
     uint64_t tail_count = 0;
+    std::vector<uint64_t> tail_keys; // records appended so far, mapped (hb_host.cpp map_tail_records)
+    bool tail_dirty = false;         // tail_keys differ from what d_tail_* hold: rebuilt by hb_begin
     uint32_t *d_bloom = nullptr;    // new_changed_nodes of the last pass (U64BloomFilter), bloom_bits bits
     uint64_t bloom_bits = 0;
     unsigned long long *d_bloom_ones = nullptr; // [0] count_ones, [1] (low word) length of d_list
@@ -189,6 +191,8 @@ void free_graph_buffers(hb_ctx *c)
     c->d_tail_ptr = nullptr;
     c->d_tail_to = nullptr;
     c->tail_count = 0;
+    std::vector<uint64_t>().swap(c->tail_keys);
+    c->tail_dirty = false;
     c->d_bloom = nullptr;
     c->d_bloom_ones = nullptr;
     c->d_list = nullptr;
@@ -713,6 +717,37 @@ int reference_changed_state(hb_ctx *c, const uint32_t *bits_changed, uint64_t ch
     return HB_OK;
 }
 
+// tail_keys -> d_tail_ptr / d_tail_to (hb_begin, when records were given since the last upload)
+int upload_tail_index(hb_ctx *c)
+{
+    const Plan &p = c->plan;
+    std::vector<uint64_t> ptr;
+    std::vector<uint32_t> to;
+    const std::string e = build_tail_csr(&c->tail_keys, p.n_pad, &ptr, &to);
+    if (!e.empty()) return fail(c, HB_ERR_NOMEM, e);
+    for (void *old : {(void *)c->d_tail_ptr, (void *)c->d_tail_to}) {
+        if (!old) continue;
+        for (size_t i = 0; i < c->allocs.size(); i++)
+            if (c->allocs[i].p == old) {
+                c->stats.device_bytes -= c->allocs[i].bytes;
+                (void)hipFree(old);
+                c->allocs.erase(c->allocs.begin() + (long)i);
+                break;
+            }
+    }
+    c->d_tail_ptr = nullptr;
+    c->d_tail_to = nullptr;
+    int rc;
+    if ((rc = dev_alloc(c, &c->d_tail_ptr, p.n_pad + 1))) return rc;
+    if ((rc = dev_alloc(c, &c->d_tail_to, to.size() + 1))) return rc;
+    HB_HIP(hipMemcpyAsync(c->d_tail_ptr, ptr.data(), (p.n_pad + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
+    if (!to.empty()) HB_HIP(hipMemcpyAsync(c->d_tail_to, to.data(), to.size() * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+    HB_HIP(hipStreamSynchronize(c->stream));
+    c->tail_count = to.size();
+    c->tail_dirty = false;
+    return HB_OK;
+}
+
 int step_local(hb_ctx *c)
 {
     if (!c->begun || c->finished) return fail(c, HB_ERR_INVALID, "hb_step*: call hb_begin first");
@@ -1222,41 +1257,30 @@ int hb_finalize(hb_ctx *c, const hb_u128 *node_ids, uint64_t n)
     });
 }
 
-int hb_load_tail_edges(hb_ctx *c, const hb_edge *records, uint64_t count)
+int hb_append_tail_edges(hb_ctx *c, const hb_edge *records, uint64_t count)
 {
     return guarded(c, [&]() -> int {
         if (!c) return HB_ERR_INVALID;
-        if (!ref_tail(c)) return fail(c, HB_ERR_INVALID, "hb_load_tail_edges: create the context with HB_FLAG_REFERENCE_TAIL");
-        if (!c->loaded) return fail(c, HB_ERR_INVALID, "hb_load_tail_edges: load the graph first");
+        if (!ref_tail(c)) return fail(c, HB_ERR_INVALID, "tail records: create the context with HB_FLAG_REFERENCE_TAIL");
+        if (!c->loaded) return fail(c, HB_ERR_INVALID, "tail records: load the graph first");
         if (count && !records) return fail(c, HB_ERR_INVALID, "records == NULL with count > 0");
         int rc = set_device(c);
         if (rc) return rc;
         if ((rc = need_host_dev_of(c))) return rc;
-        const Plan &p = c->plan;
-        std::vector<uint64_t> ptr;
-        std::vector<uint32_t> to;
-        const std::string e = map_tail_records(c->g.ids.data(), c->g.ids.size(), p.dev_of.data(), p.n_pad, records, count, &ptr, &to);
+        const std::string e = map_tail_records(c->g.ids.data(), c->g.ids.size(), c->plan.dev_of.data(), records, count, &c->tail_keys);
         if (!e.empty()) return fail(c, HB_ERR_NOMEM, e);
-        for (void *old : {(void *)c->d_tail_ptr, (void *)c->d_tail_to}) { // replace the records of an earlier call
-            if (!old) continue;
-            for (size_t i = 0; i < c->allocs.size(); i++)
-                if (c->allocs[i].p == old) {
-                    c->stats.device_bytes -= c->allocs[i].bytes;
-                    (void)hipFree(old);
-                    c->allocs.erase(c->allocs.begin() + (long)i);
-                    break;
-                }
-        }
-        c->d_tail_ptr = nullptr;
-        c->d_tail_to = nullptr;
-        if ((rc = dev_alloc(c, &c->d_tail_ptr, p.n_pad + 1))) return rc;
-        if ((rc = dev_alloc(c, &c->d_tail_to, to.size() + 1))) return rc;
-        HB_HIP(hipMemcpyAsync(c->d_tail_ptr, ptr.data(), (p.n_pad + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
-        if (!to.empty()) HB_HIP(hipMemcpyAsync(c->d_tail_to, to.data(), to.size() * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
-        HB_HIP(hipStreamSynchronize(c->stream));
-        c->tail_count = to.size();
+        c->tail_dirty = true;
         return HB_OK;
     });
+}
+
+int hb_load_tail_edges(hb_ctx *c, const hb_edge *records, uint64_t count)
+{
+    if (c && ref_tail(c) && c->loaded) {
+        c->tail_keys.clear();
+        c->tail_dirty = true;
+    }
+    return hb_append_tail_edges(c, records, count);
 }
 
 int hb_load_dense(hb_ctx *c, const hb_u128 *sorted_ids, uint64_t n, const uint64_t *row_ptr, const uint32_t *src,
@@ -1349,11 +1373,8 @@ int hb_begin(hb_ctx *c)
                 if ((rc = dev_alloc(c, &c->d_bloom_ones, 2))) return rc;
                 if ((rc = dev_alloc(c, &c->d_list, c->ref_threshold + 2))) return rc;
             }
-            if (!c->d_tail_ptr) { // no hb_load_tail_edges: the forward-links query finds nothing
-                if ((rc = dev_alloc(c, &c->d_tail_ptr, p.n_pad + 1))) return rc;
-                if ((rc = dev_alloc(c, &c->d_tail_to, 1))) return rc;
-                HB_HIP(hipMemsetAsync(c->d_tail_ptr, 0, (p.n_pad + 1) * sizeof(uint64_t), c->stream));
-            }
+            // no records given: the forward-links query finds nothing (an empty index)
+            if ((c->tail_dirty || !c->d_tail_ptr) && (rc = upload_tail_index(c))) return rc;
             c->exact_counting = c->exact_valid = c->stale = false;
         }
         HB_HIP(hipStreamSynchronize(c->stream));

@@ -225,19 +225,18 @@ std::string ingest_edges(const hb_u128 *node_ids, uint64_t n_in, const hb_edge *
     return "";
 }
 
-// HB_FLAG_REFERENCE_TAIL: the page-level records update_changed_counters follows (harmonic.rs:82-92), as a CSR by
-// SOURCE in device-row numbering: the rel filter (:87) and the two counter lookups (:91-92) are applied here.
-std::string map_tail_records(const hb_u128 *ids, uint64_t n, const uint32_t *dev_of, uint64_t n_pad, const hb_edge *recs,
-                             uint64_t count, std::vector<uint64_t> *ptr, std::vector<uint32_t> *to)
+// HB_FLAG_REFERENCE_TAIL: the page-level records update_changed_counters follows (harmonic.rs:82-92).  A batch of
+// records -> keys (source device row << 32 | target device row), appended to *keys: the rel filter (:87) and the two
+// counter lookups (:91-92) are applied here, so only records between two host nodes stay (8 bytes each).
+std::string map_tail_records(const hb_u128 *ids, uint64_t n, const uint32_t *dev_of, const hb_edge *recs, uint64_t count,
+                             std::vector<uint64_t> *keys)
 {
+    if (n == 0 || count == 0) return "";
     ThreadScope threads(count);
     try {
-        ptr->assign(n_pad + 1, 0);
-        to->clear();
-        if (n == 0 || count == 0) return "";
         IdIndex index;
         index.build(ids, n);
-        std::vector<uint64_t> keys(count);
+        std::vector<uint64_t> mapped(count);
 #pragma omp parallel for schedule(static)
         for (int64_t i = 0; i < (int64_t)count; i++) {
             uint64_t key = ~0ull;
@@ -245,19 +244,31 @@ std::string map_tail_records(const hb_u128 *ids, uint64_t n, const uint32_t *dev
                 const int64_t f = index.find(recs[i].from), t = index.find(recs[i].to);
                 if (f >= 0 && t >= 0) key = ((uint64_t)dev_of[f] << 32) | (uint64_t)dev_of[t];
             }
-            keys[i] = key;
+            mapped[i] = key;
         }
-        HB_SORT(keys.begin(), keys.end());
-        keys.erase(std::unique(keys.begin(), keys.end()), keys.end());
-        while (!keys.empty() && keys.back() == ~0ull) keys.pop_back();
-        to->resize(keys.size());
-        for (uint64_t i = 0; i < keys.size(); i++) {
-            (*to)[i] = (uint32_t)keys[i];
-            (*ptr)[(keys[i] >> 32) + 1]++;
+        for (uint64_t k : mapped)
+            if (k != ~0ull) keys->push_back(k);
+    } catch (const std::bad_alloc &) {
+        return "out of host memory mapping the tail records";
+    }
+    return "";
+}
+// all keys -> CSR by source device row (duplicates dropped: max is idempotent)
+std::string build_tail_csr(std::vector<uint64_t> *keys, uint64_t n_pad, std::vector<uint64_t> *ptr, std::vector<uint32_t> *to)
+{
+    ThreadScope threads(keys->size());
+    try {
+        ptr->assign(n_pad + 1, 0);
+        HB_SORT(keys->begin(), keys->end());
+        keys->erase(std::unique(keys->begin(), keys->end()), keys->end());
+        to->resize(keys->size());
+        for (uint64_t i = 0; i < keys->size(); i++) {
+            (*to)[i] = (uint32_t)(*keys)[i];
+            (*ptr)[((*keys)[i] >> 32) + 1]++;
         }
         for (uint64_t v = 0; v < n_pad; v++) (*ptr)[v + 1] += (*ptr)[v];
     } catch (const std::bad_alloc &) {
-        return "out of host memory mapping the tail records";
+        return "out of host memory building the tail index";
     }
     return "";
 }

@@ -153,9 +153,11 @@ struct PlanTune {
 std::string ingest_edges(const hb_u128 *node_ids, uint64_t n, const hb_edge *edges, uint64_t m,
                          DenseGraph *out);
 void keep_owned_rows(DenseGraph *g, uint64_t world, uint64_t rank);
-// HB_FLAG_REFERENCE_TAIL: page-level records -> CSR by source in device rows (rel filter + both lookups applied)
-std::string map_tail_records(const hb_u128 *ids, uint64_t n, const uint32_t *dev_of, uint64_t n_pad, const hb_edge *recs,
-                             uint64_t count, std::vector<uint64_t> *ptr, std::vector<uint32_t> *to);
+// HB_FLAG_REFERENCE_TAIL: page-level records -> keys (source device row << 32 | target device row) of the records
+// between two host nodes that pass the rel filter; all keys -> CSR by source
+std::string map_tail_records(const hb_u128 *ids, uint64_t n, const uint32_t *dev_of, const hb_edge *recs, uint64_t count,
+                             std::vector<uint64_t> *keys);
+std::string build_tail_csr(std::vector<uint64_t> *keys, uint64_t n_pad, std::vector<uint64_t> *ptr, std::vector<uint32_t> *to);
 // --- hb_ingest.hip: the same reduction on the GPU (stream = hipStream_t); identical output
 // keep != NULL: the CSR stays on the device (returned in *keep, owned by the caller) and out->row_ptr / out->src
 // are only filled for small graphs (m_eff <= kKeepHostGraph, for hb_debug_copy_graph)

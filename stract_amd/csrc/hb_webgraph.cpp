@@ -350,6 +350,7 @@ struct Segment {
     void *map = nullptr;
     uint64_t map_len = 0;
     const uint8_t *from = nullptr, *to = nullptr, *flags = nullptr; // raw little-endian values, num_rows each
+    const uint8_t *page_from = nullptr, *page_to = nullptr;         // `from_id` / `to_id` (HBW_PAGE_IDS)
     uint64_t num_rows = 0;
     uint64_t first = 0; // stream position of its first document
 };
@@ -427,8 +428,11 @@ std::string open_segment(const std::string &dir, uint32_t flags, Segment *s)
         int value_bytes;
         uint8_t codec;     // Raw: 0 among the u128 codecs, 3 among the u64 codecs
         const uint8_t **dst;
-    } wants[3] = {{"from_host_id", 6, 16, 0, &s->from}, {"to_host_id", 6, 16, 0, &s->to}, {"rel_flags", 1, 8, 3, &s->flags}};
-    for (const Want &w : wants) {
+    } wants[5] = {{"from_host_id", 6, 16, 0, &s->from}, {"to_host_id", 6, 16, 0, &s->to}, {"rel_flags", 1, 8, 3, &s->flags},
+                  {"from_id", 6, 16, 0, &s->page_from}, {"to_id", 6, 16, 0, &s->page_to}}; // schema.rs:132-180: page node ids
+    const int nwants = (flags & HBW_PAGE_IDS) ? 5 : 3;
+    for (int wi = 0; wi < nwants; wi++) {
+        const Want &w = wants[wi];
         std::string key(w.name);
         key.push_back('\0');
         key.push_back((char)w.type_code);
@@ -544,7 +548,7 @@ int hbw_total_rows(const hbw_reader *r, uint64_t *rows)
     return HB_OK;
 }
 
-int hbw_read_host_edges(const hbw_reader *r, uint64_t first, uint64_t count, hb_edge *out)
+static int read_records(const hbw_reader *r, bool page_level, uint64_t first, uint64_t count, hb_edge *out)
 {
     if (!r || (count && !out)) return HB_ERR_INVALID;
     if (first > r->total || count > r->total - first) return HB_ERR_INVALID;
@@ -553,18 +557,24 @@ int hbw_read_host_edges(const hbw_reader *r, uint64_t first, uint64_t count, hb_
         if (done == count) break;
         const uint64_t pos = first + done;
         if (pos >= s.first + s.num_rows) continue;
+        const uint8_t *from = page_level ? s.page_from : s.from, *to = page_level ? s.page_to : s.to;
+        if (!from || !to) return HB_ERR_INVALID; // page-level ids: the reader was opened without HBW_PAGE_IDS
         const uint64_t b = pos - s.first, n = std::min<uint64_t>(count - done, s.num_rows - b);
         hb_edge *dst = out + done;
 #pragma omp parallel for schedule(static) if (n > 65536)
         for (int64_t i = 0; i < (int64_t)n; i++) {
-            std::memcpy(&dst[i].from, s.from + 16 * (b + (uint64_t)i), 16); // u128 little-endian = {lo, hi}
-            std::memcpy(&dst[i].to, s.to + 16 * (b + (uint64_t)i), 16);
+            std::memcpy(&dst[i].from, from + 16 * (b + (uint64_t)i), 16); // u128 little-endian = {lo, hi}
+            std::memcpy(&dst[i].to, to + 16 * (b + (uint64_t)i), 16);
             std::memcpy(&dst[i].rel_flags, s.flags + 8 * (b + (uint64_t)i), 8);
         }
         done += n;
     }
     return HB_OK;
 }
+
+int hbw_read_host_edges(const hbw_reader *r, uint64_t first, uint64_t count, hb_edge *out) { return read_records(r, false, first, count, out); }
+
+int hbw_read_page_edges(const hbw_reader *r, uint64_t first, uint64_t count, hb_edge *out) { return read_records(r, true, first, count, out); }
 
 int hb_load_webgraph(hb_ctx *ctx, const char *edges_dir, uint32_t flags)
 {
@@ -582,6 +592,16 @@ int hb_load_webgraph(hb_ctx *ctx, const char *edges_dir, uint32_t flags)
             if (rc2 == HB_OK) rc2 = hb_append_edges(ctx, buf.data(), n);
         }
         if (rc2 == HB_OK) rc2 = hb_finalize(ctx, nullptr, 0); // node set = all endpoints = host_nodes() (store.rs:338-357)
+        if (rc2 == HB_OK && (flags & HBW_PAGE_IDS)) {
+            // HB_FLAG_REFERENCE_TAIL: every document's page-level (from_id, to_id, rel_flags); the library keeps those
+            // between two host nodes = what ForwardlinksQuery::new(host id) can return (harmonic.rs:82-92)
+            rc2 = hb_load_tail_edges(ctx, nullptr, 0);
+            for (uint64_t at = 0; at < r->total && rc2 == HB_OK; at += slab) {
+                const uint64_t n = std::min(slab, r->total - at);
+                rc2 = hbw_read_page_edges(r, at, n, buf.data());
+                if (rc2 == HB_OK) rc2 = hb_append_tail_edges(ctx, buf.data(), n);
+            }
+        }
         hbw_close(r);
         return rc2;
     });

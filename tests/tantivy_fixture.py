@@ -11,7 +11,7 @@ serialisers, each function citing what it follows (paths under /root/reference/c
   meta.json       index/index_meta.rs:215-225,325-342,436-440
 
 "Format unpinned": nothing here was checked against a file written by the reference (no Rust toolchain in this
-image); tools/ref_fixture.rs writes the same fixture with the reference itself."""
+image); tools/ref_golden.rs writes a whole store (`store_fixture`) with the reference itself."""
 import json
 import os
 import struct
@@ -131,8 +131,10 @@ def with_footer(body):
     return body + js + struct.pack("<II", len(js), 1337)
 
 
-def write_edge_store(path, segments, extra_columns=True):
-    """segments: list of EDGE record arrays (stract_amd._lib.EDGE), one tantivy segment each.  Returns the uuids."""
+def write_edge_store(path, segments, extra_columns=True, page_segments=None):
+    """segments: list of EDGE record arrays (stract_amd._lib.EDGE), one tantivy segment each.  Returns the uuids.
+    page_segments: per segment, EDGE arrays whose from / to are the documents' page-level `from_id` / `to_id`
+    (webgraph/schema.rs:132-180); default: decoy values, so that a reader picking the wrong column is caught."""
     os.makedirs(path, exist_ok=True)
     metas, ids = [], []
     for i, edges in enumerate(segments):
@@ -140,8 +142,8 @@ def write_edge_store(path, segments, extra_columns=True):
         n = len(edges)
         cols = {"from_host_id": (U128, edges["from"]), "to_host_id": (U128, edges["to"]), "rel_flags": (U64, edges["rel_flags"])}
         if extra_columns:  # other columnar fields of the webgraph schema (webgraph/schema.rs), ignored by the reader
-            cols["from_id"] = (U128, edges["to"])
-            cols["to_id"] = (U128, edges["from"])
+            cols["from_id"] = (U128, page_segments[i]["from"] if page_segments else edges["to"])
+            cols["to_id"] = (U128, page_segments[i]["to"] if page_segments else edges["from"])
             cols["sort_score"] = (U64, np.arange(n, dtype=np.uint64))
         with open(os.path.join(path, sid.hex + ".col"), "wb") as f:
             f.write(with_footer(columnar_bytes(cols, n)))

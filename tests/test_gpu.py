@@ -537,8 +537,20 @@ def test_c2_config_bit_exact_and_properties(gpu_ctx_factory):
     assert np.array_equal(outs[0], outs[1])
 
 
+def _mixed_page_host_documents(host_tuples, seed=11):
+    """A page-level webgraph over the hosts of `host_tuples`: one document per host edge; the linking / linked page is
+    the host's root page (page id == host id, webgraph/node.rs:140-156) or one of its sub-pages (another id)."""
+    rng = np.random.default_rng(seed)
+    host = graphs.EdgeListGraph.from_tuples(host_tuples).host_edges()
+    page = host.copy()
+    sub_from, sub_to = rng.random(len(host)) < 0.5, rng.random(len(host)) < 0.4
+    page["from"]["lo"][sub_from] ^= rng.integers(1, 1 << 62, size=int(sub_from.sum()), dtype=np.uint64)
+    page["to"]["lo"][sub_to] ^= rng.integers(1, 1 << 62, size=int(sub_to.sum()), dtype=np.uint64)
+    return host, page
+
+
 @pytest.mark.gpu
-def test_reference_tail_mode(gpu_ctx_factory):
+def test_reference_tail_mode(gpu_ctx_factory, tmp_path):
     """HB_FLAG_REFERENCE_TAIL: the reference's changed-node machinery as written (bloom filter with its false
     positives, exact-counting switch, sqrt(n) tail over page-level forward links) - against the
     faithful oracle given the same page-level records: ids, values (bits), pass count and the number of tail passes."""
@@ -587,6 +599,30 @@ def test_reference_tail_mode(gpu_ctx_factory):
         modes = [ps["mode"] for ps in ctx.pass_stats()]
     assert st["passes"] == fst["passes"] and modes.count(3) == fst["passes_exact"], (modes, fst)
     assert np.array_equal(ids, fids) and np.array_equal(vals.view(np.uint64), fvals.view(np.uint64))
+    # end to end from an on-disk store with page-level and host-level id columns (hb_load_webgraph + HBW_PAGE_IDS),
+    # and the same records handed over in batches
+    from stract_amd import webgraph
+    from tests import tantivy_fixture as tf
+    host_docs, page_docs = _mixed_page_host_documents(graphs.tailed_graph(chain=90))
+    cut = [0, 500, 501, len(host_docs)]
+    tf.write_edge_store(str(tmp_path / "edges"), [host_docs[a:b] for a, b in zip(cut, cut[1:])],
+                        page_segments=[page_docs[a:b] for a, b in zip(cut, cut[1:])])
+    fids, fvals, fst = hbo.faithful_run(host_docs, page_docs)
+    hids, hvals, hst = hbo.faithful_run(host_docs)
+    assert fst["passes"] < hst["passes"] and fst["passes_exact"] >= 1   # the page-level tail ends the run early here
+    for how in ("store", "batches"):
+        with gpu_ctx_factory(flags=_lib.HB_FLAG_REFERENCE_TAIL) as ctx:
+            if how == "store":
+                webgraph.load_webgraph(ctx, str(tmp_path / "edges"), verify_crc=True, page_ids=True)
+            else:
+                ctx.load_edges(host_docs)
+                for part in np.array_split(page_docs, 5):
+                    ctx.append_tail_edges(part)
+            st = ctx.run()
+            ids, vals = ctx.results()
+            modes = [ps["mode"] for ps in ctx.pass_stats()]
+        assert st["passes"] == fst["passes"] and modes.count(3) == fst["passes_exact"], (how, modes, fst)
+        assert np.array_equal(ids, fids) and np.array_equal(vals.view(np.uint64), fvals.view(np.uint64)), how
     # the mode is single-rank, and the records need the flag
     with pytest.raises(Exception):
         gpu_ctx_factory(flags=_lib.HB_FLAG_REFERENCE_TAIL | _lib.HB_FLAG_NO_RCCL, rank=0, world_size=2)

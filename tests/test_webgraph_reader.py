@@ -143,3 +143,27 @@ def test_random_dictionaries_and_segmentations(tmp_path):
             a = int(rng.integers(0, len(e)))
             b = int(rng.integers(a, len(e) + 1))
             assert np.array_equal(r.read(a, b - a), e[a:b])
+
+
+def test_page_level_id_columns(tmp_path):
+    """HBW_PAGE_IDS: the documents' page-level `from_id` / `to_id` (webgraph/schema.rs:132-180) next to the host-level
+    ids - what the reference's tail mode queries (harmonic.rs:82-87)."""
+    g = synth.RmatGraph(10, 4_000)
+    host = g.edges(salt=1, salt_seed=2)
+    page = host.copy()
+    page["from"]["hi"] ^= np.uint64(0x55)
+    page["to"]["lo"] += np.uint64(3)
+    cut = [0, 1000, len(host)]
+    tf.write_edge_store(str(tmp_path / "e"), [host[a:b] for a, b in zip(cut, cut[1:])], page_segments=[page[a:b] for a, b in zip(cut, cut[1:])])
+    with webgraph.EdgeStoreReader(str(tmp_path / "e"), verify_crc=True, page_ids=True) as r:
+        assert np.array_equal(r.read(), host)
+        assert np.array_equal(r.read(page_level=True), page)
+        assert np.array_equal(r.read(990, 20, page_level=True), page[990:1010])   # across the segment boundary
+    with webgraph.EdgeStoreReader(str(tmp_path / "e")) as r:   # not opened: the page-level read refuses
+        with pytest.raises(_lib.HyperballError):
+            r.read(page_level=True)
+    tf.write_edge_store(str(tmp_path / "bare"), [host], extra_columns=False)
+    with pytest.raises(_lib.HyperballError):
+        webgraph.EdgeStoreReader(str(tmp_path / "bare"), page_ids=True)       # the store has no such columns
+    with webgraph.EdgeStoreReader(str(tmp_path / "bare")) as r:
+        assert np.array_equal(r.read(), host)
