@@ -16,7 +16,8 @@
 //!
 //! Output, one JSON file per graph:
 //!   { "name": ..., "edges": [[from_hex32, to_hex32, rel_flags_u64], ...]   // host_edges() stream, AFTER its unique_by
-//!     "centrality": [[id_hex32, f64_bits_hex16], ...] }                     // HarmonicCentrality::iter(), ascending id
+//!     "centrality": [[id_hex32, f64_bits_hex16], ...]                       // HarmonicCentrality::iter(), ascending id
+//!     "pages": [[from_id_hex32, to_id_hex32, rel_flags_u64], ...] }         // page_edges(): only for the mixed graph (4)
 use std::fmt::Write as _;
 use std::path::Path;
 
@@ -44,6 +45,10 @@ fn build(path: &Path, edges: &[(String, String, RelFlags)], commit_every: usize)
 }
 
 fn dump(name: &str, graph: &Webgraph, out_dir: &Path) {
+    dump_with_pages(name, graph, out_dir, false)
+}
+
+fn dump_with_pages(name: &str, graph: &Webgraph, out_dir: &Path, pages: bool) {
     let mut s = String::new();
     write!(s, "{{\"name\":\"{name}\",\"edges\":[").unwrap();
     for (i, e) in graph.host_edges().enumerate() {
@@ -60,7 +65,19 @@ fn dump(name: &str, graph: &Webgraph, out_dir: &Path) {
         }
         write!(s, "[\"{:032x}\",\"{:016x}\"]", id.as_u128(), c.to_bits()).unwrap();
     }
-    s.push_str("]}");
+    s.push(']');
+    if pages {
+        // the page-level records update_changed_counters queries in the tail (harmonic.rs:82-87, mod.rs:183)
+        s.push_str(",\"pages\":[");
+        for (i, e) in graph.page_edges().enumerate() {
+            if i > 0 {
+                s.push(',');
+            }
+            write!(s, "[\"{:032x}\",\"{:032x}\",{}]", e.from.as_u128(), e.to.as_u128(), e.rel_flags.as_u64()).unwrap();
+        }
+        s.push(']');
+    }
+    s.push('}');
     std::fs::write(out_dir.join(format!("reference_{name}.json")), s).unwrap();
 }
 
@@ -107,4 +124,16 @@ fn main() {
     let g = build(&out.join("store_fixture"), &salted, 400);
     dump("salted", &g, out);
     // out/store_fixture/edges now holds meta.json + the .col files of this graph: the fixture for the native column reader
+
+    // 4. pages AND hosts: the sqrt(n) tail follows page-level links whose source page id equals
+    //    a host id (root pages); a chain of hosts linked alternately from root pages and from sub-pages makes the run
+    //    end earlier than the host-level iteration would.  Consumed with HB_FLAG_REFERENCE_TAIL.
+    let mut mixed: Vec<(String, String, RelFlags)> = lcg_edges.clone();
+    mixed.push(("host1.com".to_string(), "tail0.com".to_string(), none));
+    for k in 0..60 {
+        let from = if k % 2 == 0 { format!("tail{k}.com") } else { format!("tail{k}.com/links.html") };
+        let to = if k % 3 == 0 { format!("tail{}.com/about", k + 1) } else { format!("tail{}.com", k + 1) };
+        mixed.push((from, to, none));
+    }
+    dump_with_pages("mixed_pages", &build(&out.join("g_mixed"), &mixed, 700), out, true);
 }
