@@ -245,6 +245,13 @@ int hb_result_copy(hb_ctx *ctx, hb_u128 *ids, double *vals, uint64_t cap);
  * cap must be >= hb_result_count. */
 int hb_result_ranks(hb_ctx *ctx, uint64_t *ranks, uint64_t cap);
 
+/* top_nodes(&store, TopNodes::Top(k)) (centrality/mod.rs:33-52), which build_harmonic calls with k = 1_000_000 for
+ * harmonic.csv (entrypoint/centrality.rs:55-68): the min(k, count) results with the largest centrality, descending
+ * (f64::total_cmp); ties in ascending NodeID = the first k of the harmonic_rank order.  (The reference's sorted_k is an
+ * unstable sort keyed by the centrality alone: the order of ties, and which of them make the cut, are unspecified
+ * there.)  ids or vals may be NULL; *written = number of entries. */
+int hb_result_top(hb_ctx *ctx, uint64_t k, hb_u128 *ids, double *vals, uint64_t *written);
+
 /* ---- multi-GPU (one process per GPU, RCCL over xGMI) -------------------------------------- */
 /* Rank 0 calls this and distributes the 128 bytes (e.g. torch.distributed broadcast);
  * every rank puts them in hb_options.rccl_id. */

@@ -124,6 +124,7 @@ _SIGNATURES = [
     ("hb_result_count", ctypes.c_int, [_P, ctypes.POINTER(_U64)]),
     ("hb_result_copy", ctypes.c_int, [_P, _P, _P, _U64]),
     ("hb_result_ranks", ctypes.c_int, [_P, _P, _U64]),
+    ("hb_result_top", ctypes.c_int, [_P, _U64, _P, _P, ctypes.POINTER(ctypes.c_uint64)]),
     ("hb_rccl_unique_id", ctypes.c_int, [_P]),
     ("hb_device_count", ctypes.c_int, [ctypes.POINTER(ctypes.c_int)]),
     ("hb_device_name", ctypes.c_int, [_P, ctypes.c_char_p, _U64]),
@@ -358,6 +359,17 @@ class Context:
         out = np.zeros(k.value, dtype=np.uint64)
         self._check(self.lib.hb_result_ranks(self.h, _ptr(out), k.value))
         return out
+
+    def top(self, k):
+        """top_nodes(TopNodes::Top(k)) (centrality/mod.rs:33-52): (ids, vals), largest centrality first."""
+        cnt = ctypes.c_uint64(0)
+        self._check(self.lib.hb_result_count(self.h, ctypes.byref(cnt)))
+        k = min(int(k), cnt.value)
+        ids = np.zeros(k, dtype=U128)
+        vals = np.zeros(k, dtype=np.float64)
+        w = ctypes.c_uint64(0)
+        self._check(self.lib.hb_result_top(self.h, k, _ptr(ids), _ptr(vals), ctypes.byref(w)))
+        return ids[:w.value], vals[:w.value]
 
     # -- debug exports
     def n(self):

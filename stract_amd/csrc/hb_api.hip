@@ -1545,6 +1545,34 @@ int hb_result_ranks(hb_ctx *c, uint64_t *ranks, uint64_t cap)
     });
 }
 
+int hb_result_top(hb_ctx *c, uint64_t k, hb_u128 *ids, double *vals, uint64_t *written)
+{
+    return guarded(c, [&]() -> int {
+        if (!c) return HB_ERR_INVALID;
+        if (!c->finished) return fail(c, HB_ERR_INVALID, "no results: hb_run / hb_finish not called");
+        int rc = set_device(c);
+        if (rc) return rc;
+        const uint64_t top = std::min<uint64_t>(k, c->res_count);
+        if (written) *written = top;
+        if (!top || (!ids && !vals)) return HB_OK;
+        std::vector<uint64_t> order(top);
+        std::string e = gpu_rank_results((void *)c->stream, c->d_out, c->plan.n, c->res_count, nullptr, order.data(), top);
+        if (!e.empty()) return fail(c, HB_ERR_HIP, e);
+        // result index (ascending NodeID among the kept ones) -> sid
+        std::vector<uint32_t> kept;
+        kept.reserve(c->res_count);
+        for (uint64_t sid = 0; sid < c->plan.n; sid++)
+            if (c->h_out[sid] >= 0.0) kept.push_back((uint32_t)sid);
+        if (kept.size() != c->res_count) return fail(c, HB_ERR_INVALID, "hb_result_top: result buffer changed since hb_finish");
+        for (uint64_t i = 0; i < top; i++) {
+            const uint32_t sid = kept[order[i]];
+            if (ids) ids[i] = c->g.ids[sid];
+            if (vals) vals[i] = c->h_out[sid];
+        }
+        return HB_OK;
+    });
+}
+
 // ---- debug exports ------------------------------------------------------------------------
 int hb_debug_copy_registers(hb_ctx *c, uint8_t *out)
 {

@@ -398,7 +398,9 @@ std::string gpu_ingest_reduce(void *stream_v, const hb_u128 *node_ids, uint64_t 
 }
 
 // ranks[j] for the j-th kept result (ascending NodeID): its position in the store_harmonic order.
-std::string gpu_rank_results(void *stream_v, const double *d_vals, uint64_t n, uint64_t expect, uint64_t *ranks_out)
+// order_out (optional): the result indices of the first `top` positions of that order (top_nodes, centrality/mod.rs:33-52).
+std::string gpu_rank_results(void *stream_v, const double *d_vals, uint64_t n, uint64_t expect, uint64_t *ranks_out, uint64_t *order_out,
+                             uint64_t top)
 {
     hipStream_t stream = (hipStream_t)stream_v;
     if (n == 0 || expect == 0) return "";
@@ -438,9 +440,12 @@ std::string gpu_rank_results(void *stream_v, const double *d_vals, uint64_t n, u
     IG_HIP(rocprim::radix_sort_pairs(nullptr, bytes, d_kkey, d_kkey_s, iota, d_idx_s, (size_t)k, 0, 64, stream));
     IG_HIP(need(bytes));
     IG_HIP(rocprim::radix_sort_pairs(tmp, bytes, d_kkey, d_kkey_s, iota, d_idx_s, (size_t)k, 0, 64, stream));
-    hipLaunchKernelGGL(rank_scatter_kernel, dim3(grid_for(k)), dim3(256), 0, stream, (const uint64_t *)d_idx_s, k, d_rank);
-    IG_HIP(hipGetLastError());
-    IG_HIP(hipMemcpyAsync(ranks_out, d_rank, k * sizeof(uint64_t), hipMemcpyDeviceToHost, stream));
+    if (ranks_out) {
+        hipLaunchKernelGGL(rank_scatter_kernel, dim3(grid_for(k)), dim3(256), 0, stream, (const uint64_t *)d_idx_s, k, d_rank);
+        IG_HIP(hipGetLastError());
+        IG_HIP(hipMemcpyAsync(ranks_out, d_rank, k * sizeof(uint64_t), hipMemcpyDeviceToHost, stream));
+    }
+    if (order_out && top) IG_HIP(hipMemcpyAsync(order_out, d_idx_s, std::min(top, k) * sizeof(uint64_t), hipMemcpyDeviceToHost, stream));
     IG_HIP(hipStreamSynchronize(stream));
     return "";
 }

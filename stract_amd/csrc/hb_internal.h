@@ -174,7 +174,8 @@ std::string check_dense(const hb_u128 *sorted_ids, uint64_t n, const uint64_t *r
 // out_degree[sid] over the local edges.
 void count_out_degree(const uint64_t *row_ptr, const uint32_t *src, uint64_t n, std::vector<uint32_t> *deg);
 // ranks of the kept results in store_harmonic's order (hb_ingest.hip); d_vals = per-node f64, < 0 = absent
-std::string gpu_rank_results(void *stream, const double *d_vals, uint64_t n, uint64_t expect, uint64_t *ranks_out);
+std::string gpu_rank_results(void *stream, const double *d_vals, uint64_t n, uint64_t expect, uint64_t *ranks_out, uint64_t *order_out = nullptr,
+                             uint64_t top = 0);
 // Builds the device layout.  global_out_degree: per sid (already summed over ranks).
 std::string build_plan(uint64_t n, const uint64_t *row_ptr, const uint32_t *src,
                        const std::vector<uint32_t> &global_out_degree, bool reorder, const PlanTune &tune,

@@ -251,6 +251,16 @@ def test_result_ranks_match_store_harmonic_order(gpu_ctx_factory):
     assert len(ranks) == len(vals) and sorted(ranks.tolist()) == list(range(len(vals)))
     assert np.array_equal(ranks, hbo.rank_results(vals))
     assert len(np.unique(vals)) < len(vals)  # ties exist: the NodeID tie-break is exercised
+    # top_nodes(TopNodes::Top(k)) (centrality/mod.rs:33-52) = the first k of that order
+    by_rank = np.argsort(ranks, kind="stable")
+    with gpu_ctx_factory() as ctx:
+        ctx.load_dense(g.ids, g.row_ptr, g.src)
+        ctx.run()
+        for k in (0, 1, 1000, len(vals), len(vals) + 5):
+            tids, tvals = ctx.top(k)
+            kk = min(k, len(vals))
+            assert len(tvals) == kk and np.array_equal(tids, ids[by_rank[:kk]]) and np.array_equal(tvals, vals[by_rank[:kk]])
+        assert np.all(np.diff(ctx.top(1000)[1]) <= 0)
     hc = HarmonicCentrality.calculate(graphs.fixture_graph())
     with gpu_ctx_factory() as ctx:
         ctx.load_edges(graphs.fixture_graph().host_edges())
