@@ -542,7 +542,13 @@ void launch_pass(hb_ctx *c, const hbk::PassParams &pp, bool real, bool frontier,
     if (unroll != 1 && unroll != 2 && unroll != 4) unroll = real ? 2 : 4;
     const uint64_t ntiles = (pp.row_hi - pp.row_lo + 63) / 64;
     if (ntiles == 0) return;
-    uint32_t bpc = c->opt.tune[0] ? c->opt.tune[0] : 8;
+    // workgroups per CU: low byte of tune[0] = node rows, second byte = hub chunks (0 = default).  Measured
+    // (profiles/r02s_sweep_bpc_*): the hub-chunk gather loop is fastest with only 2 workgroups (8 waves) per CU - each
+    // quad already keeps 16 gathers in flight, more waves only add contention (dense pass -12 % at C3, -16 % at C4);
+    // the bitmap pass has a dependent bit test in front of every gather and wants 4.  Node rows: many small
+    // workgroups, the hardware scheduler levels the uneven tiles (1.13 -> 1.05 ms at C3).
+    uint32_t bpc = real ? (c->opt.tune[0] & 0xFFu) : ((c->opt.tune[0] >> 8) & 0xFFu);
+    if (!bpc) bpc = real ? (frontier ? 16u : 64u) : (frontier ? 4u : 2u);
     uint64_t blocks = std::min<uint64_t>(ntiles, (uint64_t)c->num_cu * bpc);
     if (pp.xcd_map) blocks = std::max<uint64_t>((blocks + 7) / 8 * 8, 8); // 8 queues, equal shares of the grid
     dim3 grid((unsigned)blocks);
@@ -828,6 +834,7 @@ int step_local(hb_ctx *c)
                 pp.xcd_lo[x] = p.xcd_begin[x];
                 pp.xcd_hi[x] = p.xcd_begin[x + 1];
             }
+
             const uint32_t lds_tile = std::min<uint32_t>(c->opt.tune[7], 2048u); // experiment, see hub_lds_tile_kernel
             if (l == 0 && !frontier && lds_tile && !(c->opt.flags & HB_FLAG_PASS_STATS) && !multi_rank(c)) {
                 const uint64_t ntiles = (pp.row_hi - pp.row_lo + 63) / 64;
@@ -870,7 +877,7 @@ int step_finish(hb_ctx *c, int *has_changes)
         HB_HIP(hipEventRecord(c->ev[3], c->stream));
         const uint64_t ntiles = p.n_pad / 64;
         if (ntiles) {
-            uint32_t bpc = c->opt.tune[0] ? c->opt.tune[0] : 8;
+            uint32_t bpc = (c->opt.tune[0] & 0xFFu) ? (c->opt.tune[0] & 0xFFu) : 8;
             uint64_t blocks = std::min<uint64_t>(ntiles, (uint64_t)c->num_cu * bpc);
             hipLaunchKernelGGL(hbk::epilogue_kernel, dim3((unsigned)blocks), dim3(256), 0, c->stream, pp);
         }
