@@ -8,7 +8,7 @@
 //
 // build:  g++ -O2 -fopenmp -std=c++17 -Iinclude -Istract_amd/csrc tools/l2sim.cpp stract_amd/csrc/hb_host.cpp \
 //             stract_amd/csrc/hb_synth.cpp -o tools/l2sim.bin
-// usage:  tools/l2sim.bin <scale> <m_target> [band_w_log2] [minc] [direct_max] [chunk] [blocks_per_cu]
+// usage:  tools/l2sim.bin <scale> <m_target> [band_w_log2] [minc] [direct_max] [chunk] [hub blocks/CU] [node blocks/CU] [streams bypass L2]
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
@@ -39,7 +39,7 @@ struct Cache {
     uint32_t clock = 0;
     explicit Cache(uint64_t bytes) : sets((uint32_t)(bytes / 128 / kWays)), tag((size_t)sets * kWays, 0), stamp((size_t)sets * kWays, 0) {}
     // returns true on hit
-    bool access(uint64_t line)
+    bool access(uint64_t line, bool allocate = true)
     {
         uint64_t h = line * 0x9E3779B97F4A7C15ull;
         const uint32_t s = (uint32_t)((h >> 32) % sets);
@@ -54,6 +54,7 @@ struct Cache {
             }
             if (st[w] < st[victim]) victim = w;
         }
+        if (!allocate) return false;
         t[victim] = line + 1;
         st[victim] = clock;
         return false;
@@ -91,7 +92,9 @@ int main(int argc, char **argv)
     if (argc > 4 && std::atoi(argv[4]) > 0) pt.minc = (uint32_t)std::atoi(argv[4]);
     if (argc > 5 && std::atoi(argv[5]) > 0) pt.direct_max = (uint32_t)std::atoi(argv[5]);
     if (argc > 6 && std::atoi(argv[6]) > 0) pt.chunk = (uint32_t)std::atoi(argv[6]);
-    const int bpc = argc > 7 ? std::atoi(argv[7]) : 8;
+    const int bpc = argc > 7 ? std::atoi(argv[7]) : 2;
+    const int node_bpc = argc > 8 ? std::atoi(argv[8]) : 64;
+    const bool stream_bypass = argc > 9 && std::atoi(argv[9]) != 0; // model: index / state / write streams do not allocate in L2
     hbs_graph *g = hbs_rmat(scale, m_target, 0x5712AC7ull, 0);
     if (!g) return 1;
     const uint64_t n = hbs_num_nodes(g);
@@ -128,7 +131,7 @@ int main(int argc, char **argv)
         const uint64_t hi = p.xcd_groups == 8 ? p.xcd_begin[x + 1] : (x == 7 ? p.level_begin[1] : p.level_begin[0] + (p.level_begin[1] - p.level_begin[0]) * (x + 1) / 8 / 64 * 64);
         const uint64_t ntiles = (hi - lo + 63) / 64;
         auto touch = [&](uint64_t addr, int cls) {
-            if (c.access(addr >> 7)) t.hit[cls]++;
+            if (c.access(addr >> 7, !(stream_bypass && cls >= 5))) t.hit[cls]++;
             else t.miss[cls]++;
         };
         for (uint64_t step = 0; step * kBlocksPerXcd < ntiles; step++) {
@@ -151,13 +154,13 @@ int main(int argc, char **argv)
     }
     // ---------------- node-row launch: plain grid stride, block b on XCD b % 8
     {
-        const uint64_t ntiles = p.n_pad / 64, G = (uint64_t)kBlocksPerXcd * 8;
+        const uint64_t ntiles = p.n_pad / 64, G = (uint64_t)std::min(32 * node_bpc, 32 * 4) * 8; // resident: 4 workgroups per CU
 #pragma omp parallel for schedule(dynamic, 1)
         for (int x = 0; x < 8; x++) {
             Cache c(4ull << 20);
             Tally &t = tn[x];
             auto touch = [&](uint64_t addr, int cls) {
-                if (c.access(addr >> 7)) t.hit[cls]++;
+                if (c.access(addr >> 7, !(stream_bypass && cls >= 5))) t.hit[cls]++;
                 else t.miss[cls]++;
             };
             for (uint64_t step = 0; step * G < ntiles; step++) {
