@@ -106,7 +106,7 @@ typedef struct hb_options {
     int32_t  world_size;    /* ... of world_size (<= 1: single GPU, no collective)         */
     uint8_t  rccl_id[128];  /* ncclUniqueId from hb_rccl_unique_id() of rank 0             */
     uint32_t tune[8];       /* tuning knobs, 0 = default:
-                             *  [0] workgroups per CU of the pass launches: low byte = node rows (dense 64, bitmap 16),
+                             *  [0] workgroups per CU of the pass launches: low byte = node rows (dense 64, bitmap 32),
                              *      second byte = hub chunks (dense 2, bitmap 4)
                              *  [1] gather unroll 1|2|4 (hub chunks 4, node rows 2)
                              *  [2] frontier mode when A_t < tune[2] % of the edges (50; > 100 = always)

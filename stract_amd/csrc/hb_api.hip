@@ -548,7 +548,7 @@ void launch_pass(hb_ctx *c, const hbk::PassParams &pp, bool real, bool frontier,
     // the bitmap pass has a dependent bit test in front of every gather and wants 4.  Node rows: many small
     // workgroups, the hardware scheduler levels the uneven tiles (1.13 -> 1.05 ms at C3).
     uint32_t bpc = real ? (c->opt.tune[0] & 0xFFu) : ((c->opt.tune[0] >> 8) & 0xFFu);
-    if (!bpc) bpc = real ? (frontier ? 16u : 64u) : (frontier ? 4u : 2u);
+    if (!bpc) bpc = real ? (frontier ? 32u : 64u) : (frontier ? 4u : 2u);
     uint64_t blocks = std::min<uint64_t>(ntiles, (uint64_t)c->num_cu * bpc);
     if (pp.xcd_map) blocks = std::max<uint64_t>((blocks + 7) / 8 * 8, 8); // 8 queues, equal shares of the grid
     dim3 grid((unsigned)blocks);
