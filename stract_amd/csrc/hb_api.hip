@@ -92,6 +92,7 @@ struct hb_ctx {
     uint64_t tail_count = 0;
     std::vector<uint64_t> tail_keys; // records appended so far, mapped (hb_host.cpp map_tail_records)
     bool tail_dirty = false;         // tail_keys differ from what d_tail_* hold: rebuilt by hb_begin
+    TailIndex *tail_index = nullptr; // id -> sid index for the batches of tail records (built at the first batch)
     uint32_t *d_bloom = nullptr;    // new_changed_nodes of the last pass (U64BloomFilter), bloom_bits bits
     uint64_t bloom_bits = 0;
     unsigned long long *d_bloom_ones = nullptr; // [0] count_ones, [1] (low word) length of d_list
@@ -193,6 +194,8 @@ void free_graph_buffers(hb_ctx *c)
     c->tail_count = 0;
     std::vector<uint64_t>().swap(c->tail_keys);
     c->tail_dirty = false;
+    tail_index_free(c->tail_index);
+    c->tail_index = nullptr;
     c->d_bloom = nullptr;
     c->d_bloom_ones = nullptr;
     c->d_list = nullptr;
@@ -1274,7 +1277,8 @@ int hb_append_tail_edges(hb_ctx *c, const hb_edge *records, uint64_t count)
         int rc = set_device(c);
         if (rc) return rc;
         if ((rc = need_host_dev_of(c))) return rc;
-        const std::string e = map_tail_records(c->g.ids.data(), c->g.ids.size(), c->plan.dev_of.data(), records, count, &c->tail_keys);
+        if (!c->tail_index && count) c->tail_index = tail_index_build(c->g.ids.data(), c->g.ids.size());
+        const std::string e = map_tail_records(c->tail_index, c->g.ids.size(), c->plan.dev_of.data(), records, count, &c->tail_keys);
         if (!e.empty()) return fail(c, HB_ERR_NOMEM, e);
         c->tail_dirty = true;
         return HB_OK;

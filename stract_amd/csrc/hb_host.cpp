@@ -228,14 +228,31 @@ std::string ingest_edges(const hb_u128 *node_ids, uint64_t n_in, const hb_edge *
 // HB_FLAG_REFERENCE_TAIL: the page-level records update_changed_counters follows (harmonic.rs:82-92).  A batch of
 // records -> keys (source device row << 32 | target device row), appended to *keys: the rel filter (:87) and the two
 // counter lookups (:91-92) are applied here, so only records between two host nodes stay (8 bytes each).
-std::string map_tail_records(const hb_u128 *ids, uint64_t n, const uint32_t *dev_of, const hb_edge *recs, uint64_t count,
+struct TailIndex {
+    IdIndex index;
+};
+TailIndex *tail_index_build(const hb_u128 *ids, uint64_t n)
+{
+    TailIndex *t = new (std::nothrow) TailIndex();
+    if (!t) return nullptr;
+    try {
+        t->index.build(ids, n); // ids must stay alive and unchanged (hb_ctx::g.ids) for the lifetime of the index
+    } catch (const std::bad_alloc &) {
+        delete t;
+        return nullptr;
+    }
+    return t;
+}
+void tail_index_free(TailIndex *t) { delete t; }
+
+std::string map_tail_records(const TailIndex *tix, uint64_t n, const uint32_t *dev_of, const hb_edge *recs, uint64_t count,
                              std::vector<uint64_t> *keys)
 {
     if (n == 0 || count == 0) return "";
+    if (!tix) return "out of host memory indexing the node ids";
     ThreadScope threads(count);
     try {
-        IdIndex index;
-        index.build(ids, n);
+        const IdIndex &index = tix->index;
         std::vector<uint64_t> mapped(count);
 #pragma omp parallel for schedule(static)
         for (int64_t i = 0; i < (int64_t)count; i++) {

@@ -155,7 +155,10 @@ std::string ingest_edges(const hb_u128 *node_ids, uint64_t n, const hb_edge *edg
 void keep_owned_rows(DenseGraph *g, uint64_t world, uint64_t rank);
 // HB_FLAG_REFERENCE_TAIL: page-level records -> keys (source device row << 32 | target device row) of the records
 // between two host nodes that pass the rel filter; all keys -> CSR by source
-std::string map_tail_records(const hb_u128 *ids, uint64_t n, const uint32_t *dev_of, const hb_edge *recs, uint64_t count,
+struct TailIndex; // id -> sid hash index over the (sorted, caller-owned) id array, built once per graph
+TailIndex *tail_index_build(const hb_u128 *ids, uint64_t n);
+void tail_index_free(TailIndex *t);
+std::string map_tail_records(const TailIndex *tix, uint64_t n, const uint32_t *dev_of, const hb_edge *recs, uint64_t count,
                              std::vector<uint64_t> *keys);
 std::string build_tail_csr(std::vector<uint64_t> *keys, uint64_t n_pad, std::vector<uint64_t> *ptr, std::vector<uint32_t> *to);
 // --- hb_ingest.hip: the same reduction on the GPU (stream = hipStream_t); identical output
