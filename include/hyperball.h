@@ -318,6 +318,11 @@ int hb_host_ingest(const hb_u128 *node_ids, uint64_t n, const hb_edge *edges, ui
 int hb_host_plan(uint64_t n, const uint64_t *row_ptr, const uint32_t *src, uint32_t flags,
                  uint32_t chunk, const uint32_t *tune /* hb_options.tune or NULL */, uint64_t sizes[4],
                  uint32_t *order, uint64_t *plan_row_ptr, uint32_t *plan_src, uint64_t *level_begin);
+/* Host only (no GPU): the index hb_load_tail_edges / hb_append_tail_edges build from page-level records - CSR by SOURCE
+ * device row (dev_of[sid]) over the records that pass the rel filter and whose two ids are nodes (harmonic.rs:87,91-92),
+ * duplicates dropped.  ptr_out: n_pad + 1 offsets; to_out: target device rows (first to_cap), *to_len = their number. */
+int hb_debug_tail_index(uint64_t n, const hb_u128 *sorted_ids, const uint32_t *dev_of, uint64_t n_pad, const hb_edge *records,
+                        uint64_t count, uint64_t *ptr_out, uint32_t *to_out, uint64_t to_cap, uint64_t *to_len);
 
 #ifdef __cplusplus
 }

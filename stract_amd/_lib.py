@@ -114,6 +114,7 @@ _SIGNATURES = [
     ("hb_finalize", ctypes.c_int, [_P, _P, _U64]),
     ("hb_load_tail_edges", ctypes.c_int, [_P, _P, _U64]),
     ("hb_append_tail_edges", ctypes.c_int, [_P, _P, _U64]),
+    ("hb_debug_tail_index", ctypes.c_int, [_U64, _P, _P, _U64, _P, _U64, _P, _P, _U64, ctypes.POINTER(ctypes.c_uint64)]),
     ("hb_load_dense", ctypes.c_int, [_P, _P, _U64, _P, _P, _U64]),
     ("hb_run", ctypes.c_int, [_P, ctypes.POINTER(HbStats)]),
     ("hb_begin", ctypes.c_int, [_P]),

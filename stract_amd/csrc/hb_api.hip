@@ -1798,6 +1798,26 @@ int hb_host_plan(uint64_t n, const uint64_t *row_ptr, const uint32_t *src, uint3
     });
 }
 
+int hb_debug_tail_index(uint64_t n, const hb_u128 *sorted_ids, const uint32_t *dev_of, uint64_t n_pad, const hb_edge *records,
+                        uint64_t count, uint64_t *ptr_out, uint32_t *to_out, uint64_t to_cap, uint64_t *to_len)
+{
+    return guarded(nullptr, [&]() -> int {
+        hb_ctx *c = nullptr;
+        if ((n && (!sorted_ids || !dev_of)) || (count && !records) || !ptr_out || !to_len) return fail(c, HB_ERR_INVALID, "NULL argument");
+        TailIndex *tix = n ? tail_index_build(sorted_ids, n) : nullptr;
+        std::vector<uint64_t> keys, ptr;
+        std::vector<uint32_t> to;
+        std::string e = map_tail_records(tix, n, dev_of, records, count, &keys);
+        tail_index_free(tix);
+        if (e.empty()) e = build_tail_csr(&keys, n_pad, &ptr, &to);
+        if (!e.empty()) return fail(c, HB_ERR_NOMEM, e);
+        std::memcpy(ptr_out, ptr.data(), (n_pad + 1) * sizeof(uint64_t));
+        *to_len = to.size();
+        if (to_out && !to.empty()) std::memcpy(to_out, to.data(), std::min<uint64_t>(to.size(), to_cap) * sizeof(uint32_t));
+        return HB_OK;
+    });
+}
+
 int hb_debug_exchange(hb_ctx **ctxs, int count, int phase)
 {
     return guarded(nullptr, [&]() -> int {

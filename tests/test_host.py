@@ -280,3 +280,49 @@ def test_host_stages_under_sanitizers(tmp_path):
     env.pop("LD_PRELOAD", None)
     r = subprocess.run([exe], capture_output=True, text=True, timeout=900, env=env)
     assert r.returncode == 0 and "asan_host_check: ok" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
+
+
+def test_tail_index_filter_and_mapping():
+    """hb_debug_tail_index (host only): the index behind hb_load_tail_edges - records that pass the rel filter and whose
+    two ids are host nodes (harmonic.rs:87,91-92), as a CSR by source device row, duplicates dropped."""
+    import ctypes
+    from tests import graphs
+    lib = _lib.load()
+    rng = np.random.default_rng(4)
+    n, n_pad = 300, 320
+    vals = sorted(int(x) for x in rng.choice(1 << 40, size=n, replace=False))
+    ids = np.zeros(n, dtype=_lib.U128)
+    ids["lo"] = np.array(vals, dtype=np.uint64)
+    ids["hi"] = np.arange(n, dtype=np.uint64) % 3           # ascending (hi, lo) order is required
+    order = np.lexsort((ids["lo"], ids["hi"]))
+    ids = ids[order]
+    dev_of = rng.permutation(n_pad)[:n].astype(np.uint32)
+    m = 4000
+    recs = np.zeros(m, dtype=_lib.EDGE)
+    f, t = rng.integers(0, n, m), rng.integers(0, n, m)
+    recs["from"], recs["to"] = ids[f], ids[t]
+    foreign = rng.random(m) < 0.1
+    recs["from"]["lo"][foreign] ^= np.uint64(1 << 50)      # not a host id: falls out at the lookup
+    flagged = rng.random(m) < 0.2
+    recs["rel_flags"][flagged] = graphs.NOFOLLOW
+    recs["rel_flags"][~flagged & (rng.random(m) < 0.3)] = 1  # a flag outside SKIPPED_REL: kept
+    recs[:50] = recs[50:100]                                # duplicates
+    key = {(int(r["hi"]) << 64) | int(r["lo"]): i for i, r in enumerate(ids)}
+    want = set()
+    for r in recs:
+        if int(r["rel_flags"]) & 0x6FED00:
+            continue
+        a = key.get((int(r["from"]["hi"]) << 64) | int(r["from"]["lo"]))
+        b = key.get((int(r["to"]["hi"]) << 64) | int(r["to"]["lo"]))
+        if a is not None and b is not None:
+            want.add((int(dev_of[a]), int(dev_of[b])))
+    ptr = np.zeros(n_pad + 1, dtype=np.uint64)
+    to = np.zeros(m, dtype=np.uint32)
+    k = ctypes.c_uint64(0)
+    rc = lib.hb_debug_tail_index(n, ids.ctypes.data, dev_of.ctypes.data, n_pad, recs.ctypes.data, m, ptr.ctypes.data, to.ctypes.data, m,
+                                 ctypes.byref(k))
+    assert rc == 0 and k.value == len(want) and int(ptr[-1]) == len(want) and 0 < len(want) < m
+    got = [(row, int(x)) for row in range(n_pad) for x in to[int(ptr[row]):int(ptr[row + 1])]]
+    assert got == sorted(want)
+    rc = lib.hb_debug_tail_index(n, ids.ctypes.data, dev_of.ctypes.data, n_pad, None, 0, ptr.ctypes.data, to.ctypes.data, m, ctypes.byref(k))
+    assert rc == 0 and k.value == 0 and not ptr.any()
