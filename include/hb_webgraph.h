@@ -26,8 +26,9 @@
  *                                   u64_based/raw.rs, u64_based/mod.rs:27-32 (the fork writes nothing else: serialize.rs:23,53)
  *
  * FORMAT STATUS: "format unpinned" for whole files - no file written by the reference is available in this
- * image (no Rust toolchain).  Pinned against reference-held bytes: the sstable block framing
- * (sstable/mod.rs:373-396 test_simple_sstable) and the meta.json shape (index_meta.rs:436-440).  tests/ build
+ * image (no Rust toolchain).  Pinned against reference-held bytes / cases: the sstable block framing
+ * (sstable/mod.rs:373-396 test_simple_sstable), the meta.json shape (index_meta.rs:436-440), the directory-footer
+ * refusals (directory/footer.rs:169-235) and the vint lengths (sstable/vint.rs:47-60).  tests/ build
  * fixtures with a Python writer that follows the serialisers cited above line by line; tools/ref_golden.rs
  * is the program that writes the same fixture with the reference itself.
  *

@@ -167,3 +167,37 @@ def test_page_level_id_columns(tmp_path):
         webgraph.EdgeStoreReader(str(tmp_path / "bare"), page_ids=True)       # the store has no such columns
     with webgraph.EdgeStoreReader(str(tmp_path / "bare")) as r:
         assert np.array_equal(r.read(), host)
+
+
+def test_directory_footer_cases_of_the_reference(tmp_path):
+    """crates/tantivy/src/directory/footer.rs:169-235 - the reference's own footer tests, replayed on the reader: a file
+    that ends in [footer_len u32][magic u32] with a wrong magic, a footer longer than the file, or longer than
+    FOOTER_MAX_LEN = 50 000 must be refused."""
+    g = synth.RmatGraph(6, 100)
+    d = str(tmp_path / "edges")
+    (uid,) = tf.write_edge_store(d, [g.edges()])
+    col = os.path.join(d, uid + ".col")
+    for data, what in ((struct.pack("<II", 0, 5555), "magic"),                      # test_deserialize_footer_missing_magic_byte
+                       (struct.pack("<II", 100, 1337), "footer length"),            # test_deserialize_footer_wrong_filesize
+                       (b"\0" * 60000 + struct.pack("<II", 50001, 1337), "footer length")):   # test_deserialize_too_large_footer
+        open(col, "wb").write(data)
+        with pytest.raises(_lib.HyperballError) as ei:
+            webgraph.EdgeStoreReader(d)
+        assert what in str(ei.value), str(ei.value)
+
+
+def test_vint_lengths_of_the_reference_and_long_keys():
+    """crates/tantivy/src/sstable/vint.rs:47-60 (test_vint): encoded lengths; then keys longer than 15 bytes, whose
+    keep/add lengths are written as 0x01 + two vints (sstable/mod.rs:293-316), through the native dictionary reader."""
+    for val, length in ((0, 1), (17, 1), (127, 1), (128, 2), (123423418, 4)):
+        assert len(tf.sst_vint(val)) == length
+    for i in range(1, 63):
+        assert len(tf.sst_vint(1 << i)) == i // 7 + 1 and len(tf.sst_vint((1 << i) + 1)) == i // 7 + 1
+    keys = [b"k" * 40 + bytes([c]) + b"\0\x06" for c in range(1, 30)]        # add >= 16 on the first, keep >= 16 after
+    keys += [b"z" * 200 + b"tail" + bytes([c]) for c in range(1, 5)]          # two-byte vints
+    entries, at = [], 0
+    for i, k in enumerate(keys):                                              # RangeSSTable: ranges are contiguous
+        entries.append((k, (at, at + 7 + 300 * i)))
+        at += 7 + 300 * i
+    got = _sst(tf.sstable_ranges(entries), 1)
+    assert got == entries
