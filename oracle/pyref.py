@@ -292,8 +292,8 @@ def bloom_num_bits(estimated_items, fp=0.05):
 class Bloom:
     """U64BloomFilter (bloom/src/lib.rs:60-123): one multiplicative hash of the LOW 64 bits of the id."""
 
-    def __init__(self, estimated_items):
-        self.num_bits = bloom_num_bits(estimated_items)
+    def __init__(self, estimated_items, fp=0.05):
+        self.num_bits = bloom_num_bits(estimated_items, fp)
         self.bits = set()
 
     def _slot(self, item):

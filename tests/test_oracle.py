@@ -474,3 +474,16 @@ def test_pyref_bloom_matches_c_pieces():
     for ones in (0, 1, 300, 492, 493, 600, 700, 779):
         b.bits = set(range(ones))
         assert b.estimate_card() == L.hbo_bloom_estimate_card(b.num_bits, ones), ones
+
+
+def test_reference_bloom_filter_test():
+    """crates/bloom/src/lib.rs:199-216 (test_bloom_filter) on the restated U64BloomFilter: U64BloomFilter::new(100, 0.01),
+    1..5 inserted -> contained, 6..10 not.  Holds only with the reference's bit count and multiplicative hash."""
+    from oracle import pyref
+
+    bf = pyref.Bloom(100, 0.01)
+    assert bf.num_bits == hbo.load().hbo_bloom_num_bits(100, 0.01) == 120
+    for v in (1, 2, 3, 4, 5):
+        bf.insert(v)
+    assert all(bf.contains(v) for v in (1, 2, 3, 4, 5))
+    assert not any(bf.contains(v) for v in (6, 7, 8, 9, 10))
