@@ -640,3 +640,36 @@ def test_reference_tail_mode(gpu_ctx_factory, tmp_path):
         ctx.load_edges(e)
         with pytest.raises(Exception):
             ctx.load_tail_edges(recs)
+
+
+@pytest.mark.gpu
+def test_reference_two_shard_fixture(gpu_ctx_factory):
+    """entrypoint/ampc/harmonic_centrality/mod.rs:90-184 (test_simple_graph): the fixture's edges dealt i % 2 over two
+    shards, the distributed result compared with HarmonicCentrality::calculate on the combined graph (there: 1e-4; here
+    bit for bit).  Edge partition over two logical ranks, raw records, the all-reduce emulated on one device."""
+    edges = graphs.fixture_graph().host_edges()
+    want = HarmonicCentrality.calculate(graphs.fixture_graph())
+    ids = np.unique(np.concatenate([edges["from"], edges["to"]]))
+    ids = ids[np.lexsort((ids["lo"], ids["hi"]))]
+    ctxs = []
+    try:
+        for r in range(2):
+            c = gpu_ctx_factory(rank=r, world_size=2, flags=_lib.HB_FLAG_NO_RCCL)
+            c.load_edges(edges[r::2], ids)          # every shard knows all nodes, holds its own edges
+            c.begin()
+            ctxs.append(c)
+        has = True
+        while has:
+            for c in ctxs:
+                c.step_local()
+            _lib.Context.exchange(ctxs, 0)
+            has = [c.step_finish() for c in ctxs][0]
+        _lib.Context.exchange(ctxs, 1)
+        for c in ctxs:
+            c.finish()
+            got_ids, got_vals = c.results()
+            assert np.array_equal(got_ids, want.arrays()[0])
+            assert np.array_equal(got_vals.view(np.uint64), want.arrays()[1].view(np.uint64))
+    finally:
+        for c in ctxs:
+            c.close()
