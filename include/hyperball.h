@@ -93,6 +93,9 @@ typedef struct hb_edge {
                                           returns (query/forwardlink.rs:95-101,153-173) - give them with hb_load_tail_edges.
                                           On a graph whose pages are hosts this equals the default; on a real crawl it is
                                           what `stract centrality harmonic` prints.  Single rank only; passes run unfused. */
+#define HB_FLAG_NO_INIT_PASS  0x4000u /* pass 0 like every other dense pass (64-byte gathers) instead of streaming the sources'
+                                         single initial register with the edge list (2 bytes per edge, written at load time);
+                                         same results, measurement switch */
 #define HB_FLAG_RCCL_SELF     0x80u /* world_size == 1 but still create a 1-rank communicator and run
                                        the collectives (exercises the RCCL call path on one GPU)   */
 

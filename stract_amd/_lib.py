@@ -29,6 +29,7 @@ HB_FLAG_HOST_INGEST = 0x400
 HB_FLAG_HOST_PLAN = 0x800
 HB_FLAG_CHANGED_ONLY = 0x1000
 HB_FLAG_REFERENCE_TAIL = 0x2000
+HB_FLAG_NO_INIT_PASS = 0x4000
 
 # numpy views of the plain-data structs
 U128 = np.dtype([("lo", "<u8"), ("hi", "<u8")])

@@ -53,6 +53,7 @@ struct hb_ctx {
     std::vector<DevBuf> allocs;
     uint64_t *d_row_ptr = nullptr;
     uint32_t *d_src = nullptr;
+    uint16_t *d_src_jp = nullptr; // parallel to d_src: the sources' initial register (pass 0 streams it, hb_kernels.hip.h)
     uint4 *d_regs[2] = {nullptr, nullptr};
     uint4 *d_part = nullptr;
     uint32_t *d_bits[2] = {nullptr, nullptr};
@@ -166,6 +167,7 @@ void free_graph_buffers(hb_ctx *c)
     c->stats.device_bytes = 0;
     c->d_row_ptr = nullptr;
     c->d_src = nullptr;
+    c->d_src_jp = nullptr;
     c->d_regs[0] = c->d_regs[1] = nullptr;
     c->d_part = nullptr;
     c->d_bits[0] = c->d_bits[1] = nullptr;
@@ -496,6 +498,14 @@ int plan_and_upload(hb_ctx *c, DeviceCsr *csr_in, uint64_t m_eff)
         HB_HIP(hipGetLastError());
         HB_HIP(hipStreamSynchronize(c->stream));
     }
+    if (src_len && !(c->opt.flags & HB_FLAG_NO_INIT_PASS)) {
+        if ((rc = dev_alloc(c, &c->d_src_jp, src_len + 4))) return rc;
+        const unsigned blocks = (unsigned)std::min<uint64_t>((src_len + 255) / 256, (uint64_t)c->num_cu * 16);
+        hipLaunchKernelGGL(hbk::src_jp_kernel, dim3(blocks), dim3(256), 0, c->stream, (const uint32_t *)c->d_src, src_len, (const uint64_t *)c->d_idlow,
+                           (const uint32_t *)c->d_sid_of, p.n_pad, c->d_src_jp);
+        HB_HIP(hipGetLastError());
+        HB_HIP(hipStreamSynchronize(c->stream));
+    }
     if ((rc = build_sparse_support(c))) return rc;
     // the plan's big host arrays are no longer needed
     decltype(c->plan.row_ptr)().swap(c->plan.row_ptr);
@@ -520,9 +530,16 @@ int need_host_dev_of(hb_ctx *c)
 
 // ---- kernel dispatch ----------------------------------------------------------------------
 template <bool REAL, bool FRONTIER, bool FUSED>
-void launch_pass_u(hb_ctx *c, const hbk::PassParams &pp, bool stats, int unroll, dim3 grid)
+void launch_pass_u(hb_ctx *c, const hbk::PassParams &pp, bool stats, int unroll, dim3 grid, bool init = false)
 {
     hipStream_t s = c->stream;
+    if constexpr (!FRONTIER) {
+        if (init && !stats) { // pass 0: the sources' initial registers stream in with the edge list (hb_kernels.hip.h)
+            if (unroll == 2) hipLaunchKernelGGL((hbk::pass_kernel<REAL, false, FUSED, false, 2, true>), grid, dim3(256), 0, s, pp);
+            else hipLaunchKernelGGL((hbk::pass_kernel<REAL, false, FUSED, false, 4, true>), grid, dim3(256), 0, s, pp);
+            return;
+        }
+    }
 #define HB_LAUNCH(ST, UN) hipLaunchKernelGGL((hbk::pass_kernel<REAL, FRONTIER, FUSED, ST, UN>), grid, dim3(256), 0, s, pp)
     if (stats) {
         if (unroll == 1) HB_LAUNCH(true, 1);
@@ -554,18 +571,24 @@ void launch_pass(hb_ctx *c, const hbk::PassParams &pp, bool real, bool frontier,
     if (!bpc) bpc = real ? (frontier ? 32u : 64u) : (frontier ? 4u : 2u);
     uint64_t blocks = std::min<uint64_t>(ntiles, (uint64_t)c->num_cu * bpc);
     if (pp.xcd_map) blocks = std::max<uint64_t>((blocks + 7) / 8 * 8, 8); // 8 queues, equal shares of the grid
+    const bool init = c->t == 0 && !frontier && pp.src_jp != nullptr && !(c->opt.flags & HB_FLAG_NO_INIT_PASS) && unroll != 1;
+    if (init && !real && !((c->opt.tune[0] >> 8) & 0xFFu)) {
+        // pass 0 streams its sources: no L2 window to protect, the register rebuild wants every wave the CU can hold
+        blocks = std::min<uint64_t>(ntiles, (uint64_t)c->num_cu * 8);
+        if (pp.xcd_map) blocks = std::max<uint64_t>((blocks + 7) / 8 * 8, 8);
+    }
     dim3 grid((unsigned)blocks);
     if (real) {
         if (frontier) {
             if (fused) launch_pass_u<true, true, true>(c, pp, stats, unroll, grid);
             else launch_pass_u<true, true, false>(c, pp, stats, unroll, grid);
         } else {
-            if (fused) launch_pass_u<true, false, true>(c, pp, stats, unroll, grid);
-            else launch_pass_u<true, false, false>(c, pp, stats, unroll, grid);
+            if (fused) launch_pass_u<true, false, true>(c, pp, stats, unroll, grid, init);
+            else launch_pass_u<true, false, false>(c, pp, stats, unroll, grid, init);
         }
     } else {
         if (frontier) launch_pass_u<false, true, false>(c, pp, stats, unroll, grid);
-        else launch_pass_u<false, false, false>(c, pp, stats, unroll, grid);
+        else launch_pass_u<false, false, false>(c, pp, stats, unroll, grid, init);
     }
 }
 
@@ -575,6 +598,7 @@ hbk::PassParams make_params(hb_ctx *c)
     hbk::PassParams pp{};
     pp.row_ptr = c->d_row_ptr;
     pp.src = c->d_src;
+    pp.src_jp = c->d_src_jp;
     pp.rd = c->d_regs[c->cur];
     pp.wr = c->d_regs[c->cur ^ 1];
     pp.part = c->d_part;

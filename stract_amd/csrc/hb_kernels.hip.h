@@ -86,6 +86,7 @@ __device__ __forceinline__ void block_add_counters(unsigned long long *counters,
 struct PassParams {
     const uint64_t *row_ptr;
     const uint32_t *src;
+    const uint16_t *src_jp;   // pass 0 only, parallel to src: register index | value << 8 of the source's INITIAL counter
     const uint4 *rd;          // counters of the previous pass ("old"), n_pad rows
     uint4 *wr;                // counters being produced ("new")
     uint4 *part;              // virtual (hub-chunk) rows, indexed by vid - n_pad
@@ -253,7 +254,11 @@ __device__ __forceinline__ bool kahan_update(double &sum, double &err, uint64_t 
 //           skip rows nothing happened to; else every source is gathered, every row written
 // FUSED     REAL only: estimator + Kahan in the same kernel (single GPU)
 // STATS     count active edges / processed rows
-template <bool REAL, bool FRONTIER, bool FUSED, bool STATS, int UNROLL>
+// INIT      pass 0, dense only: every real source's counter is still HyperLogLog::default() + add(id) - ONE register
+//           set (harmonic.rs:60-62) - so instead of gathering 64 bytes at random the row streams 2 bytes per edge
+//           (src_jp, written once at load time) and rebuilds the block in registers; virtual sources are gathered
+//           as always.  Same maxima, same bits.
+template <bool REAL, bool FRONTIER, bool FUSED, bool STATS, int UNROLL, bool INIT = false>
 __global__ __launch_bounds__(256) void pass_kernel(const PassParams p)
 {
     __shared__ double s_raw[FUSED ? kTableLen : 1];
@@ -345,6 +350,26 @@ __global__ __launch_bounds__(256) void pass_kernel(const PassParams p)
             const bool real_src = first < p.n_pad;
             for (uint64_t e = beg; e < end; e += 4 * UNROLL) {
                 uint32_t idx[UNROLL];
+                if (INIT && real_src) {
+                    // pass 0: the sources' single registers come with the edge list
+#pragma unroll
+                    for (int u = 0; u < UNROLL; u++) {
+                        const uint64_t ee = e + 4 * u + q;
+                        idx[u] = (ee < end) ? (uint32_t)ld_stream(&p.src_jp[ee]) : 0u; // value 0 = nothing to merge
+                    }
+#pragma unroll
+                    for (int u = 0; u < UNROLL; u++) {
+#pragma unroll
+                        for (int k = 0; k < 4; k++) {
+                            const uint32_t v = k == 0 ? quad_bcast<0>(idx[u]) : k == 1 ? quad_bcast<1>(idx[u]) : k == 2 ? quad_bcast<2>(idx[u]) : quad_bcast<3>(idx[u]);
+                            const uint32_t j = v & 63u;
+                            const uint32_t x = ((j >> 4) == (uint32_t)q) ? ((v >> 8) << ((j & 3u) * 8u)) : 0u;
+                            const uint32_t wsel = (j & 15u) >> 2;
+                            acc_merge(acc, make_uint4(wsel == 0 ? x : 0u, wsel == 1 ? x : 0u, wsel == 2 ? x : 0u, wsel == 3 ? x : 0u));
+                        }
+                    }
+                    continue;
+                }
 #pragma unroll
                 for (int u = 0; u < UNROLL; u++) {
                     uint64_t ee = e + 4 * u + q;
@@ -1033,6 +1058,25 @@ __global__ __launch_bounds__(256) void epilogue_kernel(const PassParams p)
     for (int off = 32; off > 0; off >>= 1) cnt_out += __shfl_down(cnt_out, off);
     const unsigned long long v[4] = {cnt_changed, 0, 0, cnt_out};
     block_add_counters(p.counters, v, 0x9u);
+}
+
+// src_jp[e] for every entry of the work rows' source lists: the ONE register HyperLogLog::add(id) sets in the
+// source's initial counter (same arithmetic as init_kernel below), as index | value << 8; virtual sources: 0.
+__global__ __launch_bounds__(256) void src_jp_kernel(const uint32_t *src, uint64_t len, const uint64_t *id_low, const uint32_t *sid_of,
+                                                     uint64_t n_pad, uint16_t *jp)
+{
+    for (uint64_t e = (uint64_t)blockIdx.x * 256 + threadIdx.x; e < len; e += (uint64_t)gridDim.x * 256) {
+        const uint32_t s = src[e];
+        uint16_t v = 0;
+        if (s < n_pad && sid_of[s] != kNone) {
+            const uint64_t hash = id_low[s] * 11400714819323198549ull;
+            const uint32_t j = (uint32_t)(hash >> 58);
+            const uint64_t w = hash << 6;
+            const uint32_t pval = (w == 0 ? 64u : (uint32_t)__clzll((long long)w)) + 1u;
+            v = (uint16_t)(j | (pval << 8));
+        }
+        jp[e] = v;
+    }
 }
 
 // ---- initialisation: counter = HLL::default(); add_u128(id) (harmonic.rs:60-66) ----------
