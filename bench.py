@@ -16,9 +16,11 @@ torch.distributed.run, one rank per GPU).  Prints ONE JSON line on rank 0.
               the counters per pass: --partition dest (default) = rows by owner,
               ncclAllGather of the owned slices; --partition edge = the north-star edge partition
               with ncclAllReduce(max, u8).
-  roofline  = SURVEY.md §8(d): HBM-bound.  Headline `achieved`/`frac` = the WHOLE dense pass
-              (pass 0: 68*m_eff + 192.25*n algorithmic bytes; later dense passes B_t with their own
-              A_t) over its measured GPU time (HIP events on the library's stream) vs 8 TB/s.
+  roofline  = SURVEY.md §8(d): HBM-bound.  Headline `achieved`/`frac` = the WHOLE generic dense pass
+              (dense passes t >= 1: B_t with their own A_t) over its measured GPU time (HIP events on
+              the library's stream) vs 8 TB/s.  Pass 0 (68*m_eff + 192.25*n algorithmic bytes) is
+              reported apart in `pass0`: the library streams the sources' single initial registers
+              (2 B per edge) there instead of gathering counters, so it must not lift the headline.
               `dominant_kernel` = the level-1 hub-chunk launch alone: 68 B x the REAL edges it
               gathers (no partial-row traffic booked), over its own event-timed duration.
               `whole_loop` = sum_t B_t / t_loop with B_t = 68*A_t + 4*(m-A_t) + 184*V_t + 8n + n/4.
