@@ -142,6 +142,7 @@ VARIANTS = {
     "sparse_always_multilevel": dict(chunk=8, tune=(0, 0, 101, 0, 0, 0, 1)),
     "sparse_always_banded": dict(chunk=16, tune=(0, 0, 101, 6, 4, 0, 1)),
     "no_sparse": dict(flags=_lib.HB_FLAG_NO_SPARSE),
+    "no_init_pass": dict(flags=_lib.HB_FLAG_NO_INIT_PASS),  # pass 0 as a generic dense pass (the default streams the initial registers)
     "no_xcd_map": dict(flags=_lib.HB_FLAG_NO_XCD_MAP, chunk=16, tune=(0, 0, 0, 6, 4)),
     "xcd_slices_small_bands": dict(chunk=8, tune=(0, 0, 0, 4, 2)),
     "banded_chunks": dict(chunk=16, tune=(0, 0, 0, 6, 4)),
