@@ -35,9 +35,29 @@ def sst_vint(v):
         out.append(b | 128)
 
 
+def zstd_compress(data, level=3):
+    """ZSTD_compress through libzstd.so.1 (what `zstd::bulk::Compressor::new(3)` calls); None if the library is absent."""
+    import ctypes
+    try:
+        z = ctypes.CDLL("libzstd.so.1")
+    except OSError:
+        return None
+    z.ZSTD_compressBound.restype = ctypes.c_size_t
+    z.ZSTD_compressBound.argtypes = [ctypes.c_size_t]
+    z.ZSTD_compress.restype = ctypes.c_size_t
+    z.ZSTD_compress.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_int]
+    cap = z.ZSTD_compressBound(len(data))
+    dst = ctypes.create_string_buffer(cap)
+    n = z.ZSTD_compress(dst, cap, data, len(data), level)
+    if z.ZSTD_isError(n):
+        return None
+    return dst.raw[:n]
+
+
 def sstable_ranges(entries, block_len=4000):
     """Dictionary<RangeSSTable> bytes for sorted [(key, (start, end))].  Follows Writer::insert / DeltaWriter::flush_block /
-    Writer::finish; blocks above 2048 bytes would be zstd-compressed by the reference (not available here: asserted)."""
+    Writer::finish; blocks above 2048 bytes are zstd-compressed like the reference does (delta.rs:55-72) when libzstd.so.1
+    can be loaded."""
     out = bytearray()
     block, vals, prev_key, nblocks = bytearray(), [], b"", 0
 
@@ -51,11 +71,17 @@ def sstable_ranges(entries, block_len=4000):
             vb += sst_vint(v - prev)
             prev = v
         total = len(vb) + len(block)
-        assert total <= 2048, "the reference would zstd-compress this block (delta.rs:58)"
-        out.extend(struct.pack("<I", total + 1))
-        out.append(0)
-        out.extend(vb)
-        out.extend(block)
+        packed = zstd_compress(bytes(vb) + bytes(block)) if total > 2048 else None   # delta.rs:55-72: level 3, kept if smaller
+        if packed is not None and len(packed) < total:
+            out.extend(struct.pack("<I", len(packed) + 1))
+            out.append(1)
+            out.extend(packed)
+        else:
+            assert total <= 2048 or packed is not None, "the reference would zstd-compress this block (delta.rs:58); libzstd not loadable"
+            out.extend(struct.pack("<I", total + 1))
+            out.append(0)
+            out.extend(vb)
+            out.extend(block)
         block, vals = bytearray(), []
         nblocks += 1
 

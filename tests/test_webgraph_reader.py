@@ -201,3 +201,36 @@ def test_vint_lengths_of_the_reference_and_long_keys():
         at += 7 + 300 * i
     got = _sst(tf.sstable_ranges(entries), 1)
     assert got == entries
+
+
+def test_zstd_compressed_dictionary_block():
+    """sstable/delta.rs:55-72: a block above 2048 bytes is written zstd-compressed (level 3) when that is smaller.  The
+    native reader decompresses it through libzstd.so.1 (dlopen)."""
+    if tf.zstd_compress(b"x" * 100) is None:
+        pytest.skip("libzstd.so.1 not loadable here")
+    keys = [b"%05d_column_with_a_rather_long_and_repetitive_name" % i + b"\0\x06" for i in range(70)]   # little shared prefix: ~3.3 KB
+    entries, at = [], 0
+    for i, k in enumerate(keys):
+        entries.append((k, (at, at + 16 + i)))
+        at += 16 + i
+    raw_len = sum(len(k) for k in keys)
+    sst = tf.sstable_ranges(entries)
+    assert sst[4] == 1 and len(sst) < raw_len          # the block is flagged compressed and is smaller than its keys alone
+    lib = _lib.load()
+    buf = np.frombuffer(bytes(sst), dtype=np.uint8)
+    keys_out = np.zeros(16384, dtype=np.uint8)
+    ranges = np.zeros(512, dtype=np.uint64)
+    cnt = ctypes.c_uint64(0)
+    rc = lib.hbw_debug_sstable(buf.ctypes.data, len(buf), 1, keys_out.ctypes.data, len(keys_out), ranges.ctypes.data, len(ranges), ctypes.byref(cnt))
+    assert rc == 0, lib.hbw_last_error(None)
+    got, pos = [], 0
+    for i in range(cnt.value):
+        (kl,) = struct.unpack_from("<I", keys_out, pos)
+        got.append((bytes(keys_out[pos + 4:pos + 4 + kl]), (int(ranges[2 * i]), int(ranges[2 * i + 1]))))
+        pos += 4 + kl
+    assert got == entries
+    # a corrupted compressed block is refused, not mis-read
+    bad = bytearray(sst)
+    bad[20] ^= 0xFF
+    buf2 = np.frombuffer(bytes(bad), dtype=np.uint8)
+    assert lib.hbw_debug_sstable(buf2.ctypes.data, len(buf2), 1, keys_out.ctypes.data, len(keys_out), ranges.ctypes.data, len(ranges), ctypes.byref(cnt)) != 0
