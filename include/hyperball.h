@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define HB_ABI_VERSION 2
+#define HB_ABI_VERSION 3
 
 /* ---- error codes -------------------------------------------------------------- */
 #define HB_OK 0
@@ -199,18 +199,25 @@ int hb_load_edges(hb_ctx *ctx, const hb_u128 *node_ids, uint64_t n, const hb_edg
 int hb_append_edges(hb_ctx *ctx, const hb_edge *edges, uint64_t m);
 int hb_finalize(hb_ctx *ctx, const hb_u128 *node_ids, uint64_t n);
 
-/* HB_FLAG_REFERENCE_TAIL only; after the graph is loaded, before hb_begin / hb_run.  records = the page-level
- * (from_id, to_id, rel_flags) documents whose from_id is a host node id, i.e. the union over all hosts h of what
- * `graph.search(ForwardlinksQuery::new(h).with_limit(Unlimited))` returns (harmonic.rs:82-87; the query de-duplicates
- * by to_id and drops self links itself).  Any superset may be passed: records whose ends are not both host nodes fall
- * out at the counter lookup (harmonic.rs:91-92), records with a SKIPPED_REL flag at the filter (:87); duplicates and
- * self links are harmless (max is idempotent).  Replaces the records of an earlier call; count == 0 = "the query
- * finds nothing" (also the state before the first call). */
+/* HB_FLAG_REFERENCE_TAIL only; after the graph is loaded, before hb_begin / hb_run.  records = the store's page-level
+ * (from_id, to_id, rel_flags) documents, SEGMENT BY SEGMENT IN DOC ORDER (sort_score ascending, store.rs:67-72) - the
+ * order decides what `graph.search(ForwardlinksQuery::new(h).with_limit(Unlimited))` returns (harmonic.rs:82-87): the
+ * query runs one LinksScorer per segment over the documents whose from_id is h, which skips self links and every
+ * document whose to_id equals the to_id of the document it yielded LAST (adjacent de-duplication, plus a skip-list
+ * shortcut over whole 128-document blocks; query/raw/links.rs:115-232) BEFORE harmonic.rs:87 looks at the flags of
+ * what is left.  So of two neighbouring documents (h -> x) with different flags only the first one's flags count.
+ * The library replays exactly that per segment and host, then applies the rel filter (:87) and the two counter
+ * lookups (:91-92).  Any superset of the relevant documents may be passed (documents whose from_id is no host node
+ * are dropped at once); hb_tail_segment_end() marks the end of a segment, hb_begin closes the last one.
+ * hb_load_tail_edges replaces the records of earlier calls (one segment, or the first part of one); count == 0 =
+ * "the query finds nothing" (also the state before the first call). */
 int hb_load_tail_edges(hb_ctx *ctx, const hb_edge *records, uint64_t count);
-/* The same in batches (a crawl's page-level documents do not fit one array): every batch is filtered and mapped at
- * once, 8 bytes per surviving record stay on the host; batches add up (hb_load_tail_edges = forget all + append).
- * The index is built and uploaded by the next hb_begin / hb_run. */
+/* The same in batches (a crawl's page-level documents do not fit one array): a batch continues the current segment;
+ * 24 bytes per document whose from_id is a host node stay on the host until the segment ends, 8 bytes per surviving
+ * record after.  The index is built and uploaded by the next hb_begin / hb_run. */
 int hb_append_tail_edges(hb_ctx *ctx, const hb_edge *records, uint64_t count);
+/* The documents appended since the last call (or since hb_load_tail_edges) were one whole segment. */
+int hb_tail_segment_end(hb_ctx *ctx);
 
 /* Pre-reduced input (bench / large synthetic graphs): sorted_ids strictly ascending;
  * in-edges of node v (the v-th smallest id) are src[row_ptr[v] .. row_ptr[v+1]), already
@@ -321,9 +328,9 @@ int hb_host_ingest(const hb_u128 *node_ids, uint64_t n, const hb_edge *edges, ui
 int hb_host_plan(uint64_t n, const uint64_t *row_ptr, const uint32_t *src, uint32_t flags,
                  uint32_t chunk, const uint32_t *tune /* hb_options.tune or NULL */, uint64_t sizes[4],
                  uint32_t *order, uint64_t *plan_row_ptr, uint32_t *plan_src, uint64_t *level_begin);
-/* Host only (no GPU): the index hb_load_tail_edges / hb_append_tail_edges build from page-level records - CSR by SOURCE
- * device row (dev_of[sid]) over the records that pass the rel filter and whose two ids are nodes (harmonic.rs:87,91-92),
- * duplicates dropped.  ptr_out: n_pad + 1 offsets; to_out: target device rows (first to_cap), *to_len = their number. */
+/* Host only (no GPU): the index hb_load_tail_edges / hb_append_tail_edges build from page-level records (taken as ONE
+ * segment in doc order) - CSR by SOURCE device row (dev_of[sid]) over the records the per-host LinksScorer yields that
+ * pass the rel filter and whose two ids are nodes (harmonic.rs:87,91-92), duplicates dropped.  ptr_out: n_pad + 1 offsets; to_out: target device rows (first to_cap), *to_len = their number. */
 int hb_debug_tail_index(uint64_t n, const hb_u128 *sorted_ids, const uint32_t *dev_of, uint64_t n_pad, const hb_edge *records,
                         uint64_t count, uint64_t *ptr_out, uint32_t *to_out, uint64_t to_cap, uint64_t *to_len);
 

@@ -576,14 +576,57 @@ uint64_t hbo_faithful_run(const hbo_edge *edges, uint64_t m, hbo_u128 *out_ids, 
     return hbo_faithful_run_pages(edges, m, NULL, 0, out_ids, out_vals, cap, stats);
 }
 
+uint64_t hbo_faithful_run_pages(const hbo_edge *edges, uint64_t m, const hbo_edge *pages, uint64_t mp,
+                                hbo_u128 *out_ids, double *out_vals, uint64_t cap, hbo_faithful_stats *stats)
+{
+    return hbo_faithful_run_segments(edges, m, pages, mp, NULL, 0, out_ids, out_vals, cap, stats);
+}
+
+/* LinksScorer, crates/core/src/webgraph/query/raw/links.rs:115-232 - what a ForwardlinksQuery yields from ONE
+ * segment's posting list of the term from_id = self.  to[i] = ToId (the de-duplication column, forwardlink.rs:99-101)
+ * of the list's i-th document in doc order; emit[i] := 1 for the documents the scorer yields.
+ *   new() (:143-165): leading self links are skipped; last_dedup_val = to of the first document left.
+ *   advance() (:199-229): postings.advance(); WHILE has_seen(last doc of the current 128-document block) the whole
+ *   block is jumped (block_cursor.advance + reset_cursor_start_block, :203-213) - the skip entry only exists for full
+ *   blocks, the final partial block reports TERMINATED (tantivy postings/skip.rs:122-126,276-282), whose dedup value is
+ *   None; then documents are skipped while has_seen(doc) || skip_self(doc); last_dedup_val = to of the document
+ *   reached.  has_seen = "equals the LAST yielded to" only (:186-190): the de-duplication is adjacent, not global. */
+void hbo_links_scorer(const hbo_u128 *to, uint64_t len, hbo_u128 self, uint8_t *emit)
+{
+    const uint64_t B = 128; /* COMPRESSION_BLOCK_SIZE */
+    const uint64_t full = (len / B) * B;
+    const u128 me = to_u128(self);
+    for (uint64_t i = 0; i < len; i++) emit[i] = 0;
+    uint64_t pos = 0;
+    while (pos < len && to_u128(to[pos]) == me) pos++;
+    if (pos >= len) return;
+    u128 last = to_u128(to[pos]);
+    while (pos < len) {
+        emit[pos] = 1;
+        pos++;
+        while (pos < full && to_u128(to[(pos / B) * B + B - 1]) == last) pos = (pos / B) * B + B;
+        while (pos < len && (to_u128(to[pos]) == last || to_u128(to[pos]) == me)) pos++;
+        if (pos < len) last = to_u128(to[pos]);
+    }
+}
+
+typedef struct { uint32_t from; uint64_t idx; } pagedoc_t;
+static int cmp_pagedoc(const void *a, const void *b)
+{
+    const pagedoc_t *x = (const pagedoc_t *)a, *y = (const pagedoc_t *)b;
+    if (x->from != y->from) return x->from < y->from ? -1 : 1;
+    return x->idx < y->idx ? -1 : (x->idx > y->idx ? 1 : 0); /* doc order inside a posting list */
+}
+
 /* pages != NULL: update_changed_counters follows PAGE-level records like the reference does:
  * ForwardlinksQuery::new(host id) matches documents whose page-level from_id equals the host id and yields their
  * page-level to_id (query/forwardlink.rs:95-101,153-173); harmonic.rs:91-92 then looks both ends up in the
  * host-keyed maps.  `pages` = those (from_id, to_id, rel_flags) records (any superset of them: records whose
  * ends are not host nodes fall out at the map lookup).  pages == NULL: host-level semantics (the forward index of
  * the de-duplicated host edges). */
-uint64_t hbo_faithful_run_pages(const hbo_edge *edges, uint64_t m, const hbo_edge *pages, uint64_t mp,
-                                hbo_u128 *out_ids, double *out_vals, uint64_t cap, hbo_faithful_stats *stats)
+uint64_t hbo_faithful_run_segments(const hbo_edge *edges, uint64_t m, const hbo_edge *pages, uint64_t mp,
+                                   const uint64_t *seg_len, uint64_t nseg, hbo_u128 *out_ids, double *out_vals, uint64_t cap,
+                                   hbo_faithful_stats *stats)
 {
     hbo_faithful_stats st;
     memset(&st, 0, sizeof(st));
@@ -644,18 +687,53 @@ uint64_t hbo_faithful_run_pages(const hbo_edge *edges, uint64_t m, const hbo_edg
     st.m_unique = m_unique;
     st.m_eff = m_eff;
     uint64_t fwd_len = m_eff;
-    if (pages) { /* the tail follows the page-level records instead (harmonic.rs:82-87: rel filter on the result) */
+    if (pages) {
+        /* the tail follows what ForwardlinksQuery::new(host id) returns from the page-level documents instead
+         * (harmonic.rs:82-87): per segment (seg_len[]; NULL = all documents are one segment) and host, the documents the
+         * LinksScorer yields; THEN the rel filter on those (:87) and the two map lookups (:91-92) */
         free(fwd);
         fwd = (iedge_t *)malloc((mp + 1) * sizeof(iedge_t));
         fwd_len = 0;
-        for (uint64_t i = 0; i < mp; i++) {
-            if (pages[i].rel_flags & HBO_SKIPPED_REL_MASK) continue;
-            int64_t ui = node_find(ids, n, to_u128(pages[i].from)), vi = node_find(ids, n, to_u128(pages[i].to));
-            if (ui < 0 || vi < 0) continue; /* harmonic.rs:91-92: both lookups must hit */
-            fwd[fwd_len].from = (uint32_t)ui;
-            fwd[fwd_len].to = (uint32_t)vi;
-            fwd_len++;
+        const uint64_t one = mp;
+        if (!seg_len) { seg_len = &one; nseg = 1; }
+        pagedoc_t *docs = (pagedoc_t *)malloc((mp + 1) * sizeof(pagedoc_t));
+        hbo_u128 *tos = (hbo_u128 *)malloc((mp + 1) * sizeof(hbo_u128));
+        uint8_t *emit = (uint8_t *)malloc(mp + 1);
+        uint64_t base = 0;
+        for (uint64_t sgi = 0; sgi < nseg && base < mp; sgi++) {
+            const uint64_t cnt = seg_len[sgi] < mp - base ? seg_len[sgi] : mp - base;
+            uint64_t nd = 0;
+            for (uint64_t i = base; i < base + cnt; i++) { /* posting lists of the terms that are host node ids */
+                int64_t ui = node_find(ids, n, to_u128(pages[i].from));
+                if (ui < 0) continue;
+                docs[nd].from = (uint32_t)ui;
+                docs[nd].idx = i;
+                nd++;
+            }
+            qsort(docs, nd, sizeof(pagedoc_t), cmp_pagedoc);
+            for (uint64_t a = 0; a < nd;) {
+                uint64_t b = a;
+                while (b < nd && docs[b].from == docs[a].from) b++;
+                for (uint64_t k = a; k < b; k++) tos[k - a] = pages[docs[k].idx].to;
+                hbo_u128 self;
+                self.lo = (uint64_t)ids[docs[a].from];
+                self.hi = (uint64_t)(ids[docs[a].from] >> 64);
+                hbo_links_scorer(tos, b - a, self, emit);
+                for (uint64_t k = a; k < b; k++) {
+                    const hbo_edge *pg = &pages[docs[k].idx];
+                    if (!emit[k - a]) continue;
+                    if (pg->rel_flags & HBO_SKIPPED_REL_MASK) continue; /* :87 */
+                    int64_t vi = node_find(ids, n, to_u128(pg->to));
+                    if (vi < 0) continue; /* :91-92: both lookups must hit */
+                    fwd[fwd_len].from = docs[a].from;
+                    fwd[fwd_len].to = (uint32_t)vi;
+                    fwd_len++;
+                }
+                a = b;
+            }
+            base += cnt;
         }
+        free(docs); free(tos); free(emit);
     }
     qsort(fwd, fwd_len, sizeof(iedge_t), cmp_iedge_from);
     uint64_t *fwd_ptr = (uint64_t *)calloc(n + 2, 8);

@@ -138,9 +138,18 @@ uint64_t hbo_faithful_run(const hbo_edge *edges, uint64_t m, hbo_u128 *out_ids,
 
 /* Same, but the sqrt(n) tail (update_changed_counters, harmonic.rs:75-114) follows the given PAGE-level records
  * (from_id, to_id, rel_flags) like the reference's ForwardlinksQuery does instead of the
- * host-level edges.  pages == NULL = hbo_faithful_run. */
+ * host-level edges; the records are taken as ONE segment in doc order.  pages == NULL = hbo_faithful_run. */
 uint64_t hbo_faithful_run_pages(const hbo_edge *edges, uint64_t m, const hbo_edge *pages, uint64_t mp,
                                 hbo_u128 *out_ids, double *out_vals, uint64_t cap, hbo_faithful_stats *stats);
+
+/* The same with the documents' segment structure: pages = seg_len[0] documents of the first segment in doc order, then
+ * seg_len[1] of the second, ... (one LinksScorer per segment and host; its de-duplication is adjacent and order
+ * dependent, query/raw/links.rs:115-232).  seg_len == NULL: one segment. */
+uint64_t hbo_faithful_run_segments(const hbo_edge *edges, uint64_t m, const hbo_edge *pages, uint64_t mp,
+                                   const uint64_t *seg_len, uint64_t nseg, hbo_u128 *out_ids, double *out_vals, uint64_t cap,
+                                   hbo_faithful_stats *stats);
+/* LinksScorer over one posting list (documents of one segment whose from_id == self, doc order): emit[i] = yielded. */
+void hbo_links_scorer(const hbo_u128 *to, uint64_t len, hbo_u128 self, uint8_t *emit);
 
 /* U64BloomFilter pieces exposed for tests (bloom/src/lib.rs:36-41,108-123). */
 uint64_t hbo_bloom_num_bits(uint64_t estimated_items, double fp);

@@ -23,6 +23,10 @@ class PassStats(ctypes.Structure):
                 ("changed", ctypes.c_uint64), ("has_changes", ctypes.c_int)]
 
 
+class _U128S(ctypes.Structure):
+    _fields_ = [("lo", ctypes.c_uint64), ("hi", ctypes.c_uint64)]
+
+
 class FaithfulStats(ctypes.Structure):
     _fields_ = [("n", ctypes.c_uint64), ("m_unique", ctypes.c_uint64), ("m_eff", ctypes.c_uint64),
                 ("passes", ctypes.c_uint64), ("passes_exact", ctypes.c_uint64), ("seconds_loop", ctypes.c_double)]
@@ -203,9 +207,22 @@ class Dense:
             pass
 
 
-def faithful_run(edges, pages=None):
+def links_scorer(to_ids, self_id):
+    """hbo_links_scorer: emit mask of one posting list (to_ids: U128 array in doc order; self_id: one U128 record)."""
+    L = load()
+    to_ids = np.ascontiguousarray(to_ids, dtype=U128)
+    emit = np.zeros(max(len(to_ids), 1), dtype=np.uint8)
+    L.hbo_links_scorer.restype = None
+    L.hbo_links_scorer.argtypes = [ctypes.c_void_p, ctypes.c_uint64, _U128S, ctypes.c_void_p]
+    me = _U128S(int(self_id["lo"]), int(self_id["hi"]))
+    L.hbo_links_scorer(to_ids.ctypes.data if len(to_ids) else None, len(to_ids), me, emit.ctypes.data)
+    return emit[:len(to_ids)].astype(bool)
+
+
+def faithful_run(edges, pages=None, segments=None):
     """Structure-faithful single-thread path on raw SmallEdge records.  pages (EDGE records, may be empty): the
-    sqrt(n) tail follows these page-level records like the reference; None = host-level.
+    sqrt(n) tail follows these page-level records like the reference (doc order, `segments` = segment
+    lengths or None for one segment); None = host-level.
     Returns (ids[U128], vals[f64], stats dict)."""
     L = load()
     edges = np.ascontiguousarray(edges, dtype=EDGE)
@@ -219,8 +236,13 @@ def faithful_run(edges, pages=None):
     else:
         pages = np.ascontiguousarray(pages, dtype=EDGE)
         keep = np.zeros(1, dtype=EDGE)  # non-NULL even when there are no page records: "page-level, nothing found"
-        k = L.hbo_faithful_run_pages(edges.ctypes.data if len(edges) else None, len(edges),
-                                     pages.ctypes.data if len(pages) else keep.ctypes.data, len(pages), ids.ctypes.data,
-                                     vals.ctypes.data, cap, ctypes.byref(st))
+        seg = None if segments is None else np.ascontiguousarray(segments, dtype=np.uint64)
+        L.hbo_faithful_run_segments.restype = ctypes.c_uint64
+        L.hbo_faithful_run_segments.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p,
+                                                ctypes.c_uint64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p]
+        k = L.hbo_faithful_run_segments(edges.ctypes.data if len(edges) else None, len(edges),
+                                        pages.ctypes.data if len(pages) else keep.ctypes.data, len(pages),
+                                        seg.ctypes.data if seg is not None else None, 0 if seg is None else len(seg),
+                                        ids.ctypes.data, vals.ctypes.data, cap, ctypes.byref(st))
     assert k != 0xFFFFFFFFFFFFFFFF
     return ids[:k].copy(), vals[:k].copy(), {f: getattr(st, f) for f, _ in st._fields_}

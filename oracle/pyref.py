@@ -316,10 +316,119 @@ class Bloom:
         return v if 0 <= v < (1 << 64) else 0  # try_into::<u64>().unwrap_or_default()
 
 
-def harmonic_centrality_reference(edges, pages=None):
+TERMINATED = object()  # tantivy::TERMINATED (a doc id no document has)
+COMPRESSION_BLOCK_SIZE = 128
+
+
+class _SegmentPostings:
+    """tantivy SegmentPostings + BlockSegmentPostings + SkipReader as far as LinksScorer uses them
+    (crates/tantivy/src/postings/segment_postings.rs:145-163, block_segment_postings.rs:355-360, skip.rs:119-132,256-283):
+    the posting list is cut into full blocks of 128 documents plus one final partial block; `cur` walks the loaded
+    block (padded with TERMINATED); the skip reader knows the last document of FULL blocks only."""
+
+    def __init__(self, ndocs):
+        self.ndocs = ndocs
+        self.block = 0  # index of the loaded block
+        self.cur = 0
+
+    def _block_len(self, b):
+        return max(0, min(COMPRESSION_BLOCK_SIZE, self.ndocs - b * COMPRESSION_BLOCK_SIZE))
+
+    def doc(self):  # position in the posting list, or TERMINATED
+        return self.block * COMPRESSION_BLOCK_SIZE + self.cur if self.cur < self._block_len(self.block) else TERMINATED
+
+    def last_doc_in_block(self):  # skip.rs: remaining_docs >= 128 ? stored last doc : TERMINATED
+        if self._block_len(self.block) == COMPRESSION_BLOCK_SIZE:
+            return self.block * COMPRESSION_BLOCK_SIZE + COMPRESSION_BLOCK_SIZE - 1
+        return TERMINATED
+
+    def block_advance(self):  # BlockSegmentPostings::advance
+        self.block += 1
+
+    def reset_cursor_start_block(self):
+        self.cur = 0
+
+    def advance(self):  # SegmentPostings::advance
+        if self.cur == COMPRESSION_BLOCK_SIZE - 1:
+            self.cur = 0
+            self.block_advance()
+        else:
+            self.cur += 1
+        return self.doc()
+
+
+def links_scorer_docs(to_ids, self_id):
+    """LinksScorer (crates/core/src/webgraph/query/raw/links.rs:115-232) driven like a collector drives a DocSet
+    (`doc = scorer.doc(); while doc != TERMINATED { collect(doc); doc = scorer.advance(); }`): to_ids = the ToId
+    column of one segment's posting list of term from_id == self_id, in doc order.  Returns the yielded positions."""
+    if not to_ids:
+        return []  # read_postings finds no term: EmptyScorer (:88-101)
+    postings = _SegmentPostings(len(to_ids))
+
+    def dedup_val(doc):  # :179-185
+        return None if doc is TERMINATED else ("v", to_ids[doc])
+
+    # LinksScorer::new, :143-165
+    last = dedup_val(postings.doc())
+    while postings.doc() is not TERMINATED and last == ("v", self_id):
+        postings.advance()
+        last = dedup_val(postings.doc()) if postings.doc() is not TERMINATED else None
+
+    def has_seen(doc):  # :186-190
+        dv = dedup_val(doc)
+        return dv is not None and last == dv
+
+    def skip_self(doc):  # :192-194
+        return dedup_val(doc) == ("v", self_id)
+
+    out = []
+    doc = postings.doc()
+    while doc is not TERMINATED:
+        out.append(doc)
+        # advance(), :199-229
+        postings.advance()
+        while has_seen(postings.last_doc_in_block()) and postings.doc() is not TERMINATED:
+            postings.block_advance()
+            postings.reset_cursor_start_block()
+        while (has_seen(postings.doc()) or skip_self(postings.doc())) and postings.doc() is not TERMINATED:
+            postings.advance()
+        dv = dedup_val(postings.doc())
+        if dv is not None:
+            last = dv
+        doc = postings.doc()
+    return out
+
+
+def forwardlinks_result(pages, node_set, segments=None):
+    """What `graph.search(ForwardlinksQuery::new(h).with_limit(Unlimited))` + the filter of harmonic.rs:87 leave, for
+    every host node h: {h: [to, ...]} over the page-level documents `pages` = [(from_id, to_id, rel_flags)] in doc
+    order; segments = list of segment lengths (None: one segment).  One LinksScorer per segment and term."""
+    fwd = {}
+    if segments is None:
+        segments = [len(pages)]
+    base = 0
+    for cnt in segments:
+        lists = {}
+        for e in pages[base:base + cnt]:
+            if e[0] in node_set:
+                lists.setdefault(e[0], []).append(e)
+        for h, docs in lists.items():
+            for i in links_scorer_docs([d[1] for d in docs], h):
+                d = docs[i]
+                if (d[2] if len(d) > 2 else 0) & SKIPPED_REL:  # harmonic.rs:87, on the YIELDED document
+                    continue
+                if d[1] in node_set:  # :91-92
+                    fwd.setdefault(h, []).append(d[1])
+        base += cnt
+    return fwd
+
+
+def harmonic_centrality_reference(edges, pages=None, segments=None):
     """calculate_centrality (harmonic.rs:215-287) with the bloom filter, the exact-counting switch and the
     sqrt(n) tail as written.  pages: the page-level (from_id, to_id, rel_flags) records ForwardlinksQuery matches
-    in the tail; None = host-level edges (then the result equals harmonic_centrality()).
+    in the tail, in doc order, `segments` = their segment lengths (None: one segment) - the query's
+    LinksScorer de-duplicates neighbouring documents per segment before the rel filter sees them;
+    pages None = host-level edges (then the result equals harmonic_centrality()).
     Returns (dict, passes, passes that took update_changed_counters)."""
     nodes = sorted({x for e in edges for x in (e[0], e[1])})
     n = len(nodes)
@@ -336,10 +445,12 @@ def harmonic_centrality_reference(edges, pages=None):
         kept.append(k)
     node_set = set(nodes)
     fwd = {}
-    tail_src = kept if pages is None else [(e[0], e[1]) for e in pages if not ((e[2] if len(e) > 2 else 0) & SKIPPED_REL)]
-    for (f, to) in tail_src:
-        if f in node_set and to in node_set:  # harmonic.rs:91-92
-            fwd.setdefault(f, []).append(to)
+    if pages is None:
+        for (f, to) in kept:
+            if f in node_set and to in node_set:  # harmonic.rs:91-92
+                fwd.setdefault(f, []).append(to)
+    else:
+        fwd = forwardlinks_result(list(pages), node_set, segments)
     old = {}
     for v in nodes:
         c = hll_new()

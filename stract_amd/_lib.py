@@ -115,6 +115,7 @@ _SIGNATURES = [
     ("hb_finalize", ctypes.c_int, [_P, _P, _U64]),
     ("hb_load_tail_edges", ctypes.c_int, [_P, _P, _U64]),
     ("hb_append_tail_edges", ctypes.c_int, [_P, _P, _U64]),
+    ("hb_tail_segment_end", ctypes.c_int, [_P]),
     ("hb_debug_tail_index", ctypes.c_int, [_U64, _P, _P, _U64, _P, _U64, _P, _P, _U64, ctypes.POINTER(ctypes.c_uint64)]),
     ("hb_load_dense", ctypes.c_int, [_P, _P, _U64, _P, _P, _U64]),
     ("hb_run", ctypes.c_int, [_P, ctypes.POINTER(HbStats)]),
@@ -275,6 +276,10 @@ class Context:
     def append_tail_edges(self, records):
         records = np.ascontiguousarray(records, dtype=EDGE)
         self._check(self.lib.hb_append_tail_edges(self.h, _ptr(records) if len(records) else None, len(records)))
+
+    def tail_segment_end(self):
+        """The tail records appended since the last call were one whole segment of the store (doc order)."""
+        self._check(self.lib.hb_tail_segment_end(self.h))
 
     def finalize(self, node_ids=None):
         n = 0

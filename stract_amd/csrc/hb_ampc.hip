@@ -140,20 +140,39 @@ int reserve(hbu_table *t, uint64_t need)
 int apply(hbu_table *t, const hb_u128 *keys, const uint8_t *counters, uint64_t count, uint8_t *actions, bool upsert)
 {
     if (!t || (count && (!keys || !counters)) || (upsert && count && !actions)) return t ? fail(t, HB_ERR_INVALID, "NULL argument") : HB_ERR_INVALID;
-    if (count >= 0xFFFFFFFFull) return fail(t, HB_ERR_LIMIT, "batch too large");
+    // the kernels index 4 threads per pair / group with 32-bit thread ids
+    if (count >= (1ull << 30)) return fail(t, HB_ERR_LIMIT, "batch too large (< 2^30 pairs per call)");
     if (!count) return HB_OK;
     HBU_HIP(hipSetDevice(t->device));
-    // key -> slot (new keys get the next slot), then the pairs grouped by slot with their batch order kept
+    // key -> slot (new keys get the next slots), WITHOUT touching the table's key map yet: the device table is grown
+    // first, so that a failed allocation cannot leave keys registered whose slots were never written or allocated
     std::vector<uint32_t> slot(count), perm(count);
-    std::vector<uint8_t> fresh_slot; // indexed by slot - first_new
     const uint32_t first_new = (uint32_t)t->slot_of.size();
+    std::unordered_map<hb_u128, uint32_t, KeyHash, KeyEq> fresh;
     for (uint64_t i = 0; i < count; i++) {
         auto it = t->slot_of.find(keys[i]);
-        if (it == t->slot_of.end()) it = t->slot_of.emplace(keys[i], (uint32_t)t->slot_of.size()).first;
-        slot[i] = it->second;
+        if (it != t->slot_of.end()) {
+            slot[i] = it->second;
+            continue;
+        }
+        if ((uint64_t)first_new + fresh.size() >= 0xFFFFFFFEull) return fail(t, HB_ERR_LIMIT, "too many keys in one table (< 2^32)");
+        slot[i] = fresh.emplace(keys[i], first_new + (uint32_t)fresh.size()).first->second;
     }
-    int rc = reserve(t, t->slot_of.size());
+    int rc = reserve(t, (uint64_t)first_new + fresh.size());
     if (rc) return rc;
+    // the map update is transactional: whatever fails below (host or device allocation, copies, the launch), the
+    // keys this batch introduced are forgotten again (their slots are >= first_new and nothing else refers to them)
+    struct Rollback {
+        hbu_table *t;
+        const std::unordered_map<hb_u128, uint32_t, KeyHash, KeyEq> *added;
+        bool armed = true;
+        ~Rollback()
+        {
+            if (armed)
+                for (const auto &kv : *added) t->slot_of.erase(kv.first);
+        }
+    } rollback{t, &fresh};
+    for (const auto &kv : fresh) t->slot_of.emplace(kv.first, kv.second);
     std::iota(perm.begin(), perm.end(), 0u);
     std::stable_sort(perm.begin(), perm.end(), [&](uint32_t a, uint32_t b) { return slot[a] < slot[b]; });
     std::vector<uint32_t> gslot, gbegin;
@@ -199,7 +218,8 @@ int apply(hbu_table *t, const hb_u128 *keys, const uint8_t *counters, uint64_t c
     if (e == hipSuccess && upsert) e = hipMemcpyAsync(actions, d_actions, count, hipMemcpyDeviceToHost, t->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(t->stream);
     cleanup();
-    if (e != hipSuccess) return fail(t, HB_ERR_HIP, hipGetErrorString(e));
+    if (e != hipSuccess) return fail(t, e == hipErrorOutOfMemory ? HB_ERR_NOMEM : HB_ERR_HIP, hipGetErrorString(e));
+    rollback.armed = false;
     return HB_OK;
 }
 } // namespace
@@ -271,7 +291,7 @@ int hbu_batch_get(hbu_table *t, const hb_u128 *keys, uint64_t count, uint8_t *co
 {
     return guarded(t, [&]() -> int {
         if (!t || (count && (!keys || !counters_out))) return t ? fail(t, HB_ERR_INVALID, "NULL argument") : HB_ERR_INVALID;
-        if (count >= 0xFFFFFFFFull) return fail(t, HB_ERR_LIMIT, "batch too large");
+        if (count >= (1ull << 30)) return fail(t, HB_ERR_LIMIT, "batch too large (< 2^30 keys per call)"); // 4 threads per key, 32-bit ids
         if (!count) return HB_OK;
         HBU_HIP(hipSetDevice(t->device));
         std::vector<uint32_t> slots(count);

@@ -91,7 +91,8 @@ struct hb_ctx {
     uint64_t *d_tail_ptr = nullptr; // page-level records by source device row (hb_load_tail_edges), n_pad + 1
     uint32_t *d_tail_to = nullptr;
     uint64_t tail_count = 0;
-    std::vector<uint64_t> tail_keys; // records appended so far, mapped (hb_host.cpp map_tail_records)
+    std::vector<uint64_t> tail_keys; // records of the closed segments, mapped (hb_host.cpp tail_close_segment)
+    std::vector<TailDoc> tail_open;  // documents of the segment being appended (hb_tail_segment_end closes it)
     bool tail_dirty = false;         // tail_keys differ from what d_tail_* hold: rebuilt by hb_begin
     TailIndex *tail_index = nullptr; // id -> sid index for the batches of tail records (built at the first batch)
     uint32_t *d_bloom = nullptr;    // new_changed_nodes of the last pass (U64BloomFilter), bloom_bits bits
@@ -195,6 +196,7 @@ void free_graph_buffers(hb_ctx *c)
     c->d_tail_to = nullptr;
     c->tail_count = 0;
     std::vector<uint64_t>().swap(c->tail_keys);
+    std::vector<TailDoc>().swap(c->tail_open);
     c->tail_dirty = false;
     tail_index_free(c->tail_index);
     c->tail_index = nullptr;
@@ -799,7 +801,7 @@ int step_local(hb_ctx *c)
     // sweep mode when A_t * div < edges: measured crossover with the bitmap pass at A_t = 10-12 % of the edges
     // (profiles/r02c_sweep_*: 7.4 % -> 1.25 ms vs 2.15 ms, 16 % -> 4.1 ms vs 2.1 ms on the C3-sized graphs)
     const uint64_t sparse_div = c->opt.tune[6] ? c->opt.tune[6] : 10;
-    const bool sparse = frontier && c->sparse_ok && (c->last_active * sparse_div < c->m_global || c->opt.tune[6] == 1);
+    bool sparse = frontier && c->sparse_ok && (c->last_active * sparse_div < c->m_global || c->opt.tune[6] == 1);
     c->cur_mode = sparse ? 2 : (frontier ? 1 : 0);
     const bool fused = !unfused(c);
     hbk::PassParams pp = make_params(c);
@@ -812,6 +814,7 @@ int step_local(hb_ctx *c)
             // bloom filter of the previous pass' changed nodes INCLUDING its false positives (they may hold updates a
             // tail pass did not deliver); never a dense pass (it would deliver all of them)
             frontier = true;
+            sparse = false; // (the sweep support is never built in this mode anyway: it runs unfused)
             c->cur_mode = 1;
             hipLaunchKernelGGL(hbk::bloom_frontier_kernel, dim3((unsigned)(p.n_pad / 256 + 1)), dim3(256), 0, c->stream, (const uint32_t *)c->d_bloom,
                                (const uint64_t *)c->d_idlow, (const uint32_t *)c->d_sid_of, p.n_pad, c->bloom_bits, c->d_bits[c->cur]);
@@ -1302,7 +1305,23 @@ int hb_append_tail_edges(hb_ctx *c, const hb_edge *records, uint64_t count)
         if (rc) return rc;
         if ((rc = need_host_dev_of(c))) return rc;
         if (!c->tail_index && count) c->tail_index = tail_index_build(c->g.ids.data(), c->g.ids.size());
-        const std::string e = map_tail_records(c->tail_index, c->g.ids.size(), c->plan.dev_of.data(), records, count, &c->tail_keys);
+        if (!c->tail_index && count) return fail(c, HB_ERR_NOMEM, "out of host memory indexing the node ids");
+        const std::string e = tail_collect(c->tail_index, c->g.ids.size(), records, count, &c->tail_open);
+        if (!e.empty()) return fail(c, HB_ERR_NOMEM, e);
+        c->tail_dirty = true;
+        return HB_OK;
+    });
+}
+
+int hb_tail_segment_end(hb_ctx *c)
+{
+    return guarded(c, [&]() -> int {
+        if (!c) return HB_ERR_INVALID;
+        if (!ref_tail(c)) return fail(c, HB_ERR_INVALID, "tail records: create the context with HB_FLAG_REFERENCE_TAIL");
+        if (c->tail_open.empty()) return HB_OK;
+        int rc = need_host_dev_of(c);
+        if (rc) return rc;
+        const std::string e = tail_close_segment(c->tail_index, c->g.ids.data(), c->plan.dev_of.data(), &c->tail_open, &c->tail_keys);
         if (!e.empty()) return fail(c, HB_ERR_NOMEM, e);
         c->tail_dirty = true;
         return HB_OK;
@@ -1313,6 +1332,7 @@ int hb_load_tail_edges(hb_ctx *c, const hb_edge *records, uint64_t count)
 {
     if (c && ref_tail(c) && c->loaded) {
         c->tail_keys.clear();
+        c->tail_open.clear();
         c->tail_dirty = true;
     }
     return hb_append_tail_edges(c, records, count);
@@ -1408,7 +1428,8 @@ int hb_begin(hb_ctx *c)
                 if ((rc = dev_alloc(c, &c->d_bloom_ones, 2))) return rc;
                 if ((rc = dev_alloc(c, &c->d_list, c->ref_threshold + 2))) return rc;
             }
-            // no records given: the forward-links query finds nothing (an empty index)
+            // the segment still open ends here; no records given: the forward-links query finds nothing (an empty index)
+            if (!c->tail_open.empty() && (rc = hb_tail_segment_end(c))) return rc;
             if ((c->tail_dirty || !c->d_tail_ptr) && (rc = upload_tail_index(c))) return rc;
             c->exact_counting = c->exact_valid = c->stale = false;
         }
@@ -1831,7 +1852,9 @@ int hb_debug_tail_index(uint64_t n, const hb_u128 *sorted_ids, const uint32_t *d
         TailIndex *tix = n ? tail_index_build(sorted_ids, n) : nullptr;
         std::vector<uint64_t> keys, ptr;
         std::vector<uint32_t> to;
-        std::string e = map_tail_records(tix, n, dev_of, records, count, &keys);
+        std::vector<TailDoc> open; // the records are one segment in doc order
+        std::string e = tail_collect(tix, n, records, count, &open);
+        if (e.empty()) e = tail_close_segment(tix, sorted_ids, dev_of, &open, &keys);
         tail_index_free(tix);
         if (e.empty()) e = build_tail_csr(&keys, n_pad, &ptr, &to);
         if (!e.empty()) return fail(c, HB_ERR_NOMEM, e);

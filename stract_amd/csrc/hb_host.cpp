@@ -225,9 +225,10 @@ std::string ingest_edges(const hb_u128 *node_ids, uint64_t n_in, const hb_edge *
     return "";
 }
 
-// HB_FLAG_REFERENCE_TAIL: the page-level records update_changed_counters follows (harmonic.rs:82-92).  A batch of
-// records -> keys (source device row << 32 | target device row), appended to *keys: the rel filter (:87) and the two
-// counter lookups (:91-92) are applied here, so only records between two host nodes stay (8 bytes each).
+// HB_FLAG_REFERENCE_TAIL: the page-level records update_changed_counters follows (harmonic.rs:82-92) -> keys
+// (source device row << 32 | target device row): what ForwardlinksQuery::new(host id) YIELDS per segment (its
+// LinksScorer de-duplicates neighbouring documents on to_id BEFORE anything looks at the flags), then the rel
+// filter (:87) and the two counter lookups (:91-92); only records between two host nodes stay (8 bytes each).
 struct TailIndex {
     IdIndex index;
 };
@@ -245,26 +246,87 @@ TailIndex *tail_index_build(const hb_u128 *ids, uint64_t n)
 }
 void tail_index_free(TailIndex *t) { delete t; }
 
-std::string map_tail_records(const TailIndex *tix, uint64_t n, const uint32_t *dev_of, const hb_edge *recs, uint64_t count,
-                             std::vector<uint64_t> *keys)
+// One batch of page-level documents (doc order inside the current segment): the documents whose from_id is a host
+// node id are the posting lists ForwardlinksQuery::new(host id) walks (query/forwardlink.rs:95-101); they are kept
+// (from sid, to id, "passes the rel filter") until the segment ends.  Everything else can never be returned.
+std::string tail_collect(const TailIndex *tix, uint64_t n, const hb_edge *recs, uint64_t count, std::vector<TailDoc> *open)
 {
     if (n == 0 || count == 0) return "";
     if (!tix) return "out of host memory indexing the node ids";
     ThreadScope threads(count);
     try {
         const IdIndex &index = tix->index;
-        std::vector<uint64_t> mapped(count);
+        std::vector<int64_t> from(count);
 #pragma omp parallel for schedule(static)
-        for (int64_t i = 0; i < (int64_t)count; i++) {
-            uint64_t key = ~0ull;
-            if ((recs[i].rel_flags & HB_SKIPPED_REL_MASK) == 0) {
-                const int64_t f = index.find(recs[i].from), t = index.find(recs[i].to);
-                if (f >= 0 && t >= 0) key = ((uint64_t)dev_of[f] << 32) | (uint64_t)dev_of[t];
-            }
-            mapped[i] = key;
+        for (int64_t i = 0; i < (int64_t)count; i++) from[i] = index.find(recs[i].from);
+        for (uint64_t i = 0; i < count; i++) {
+            if (from[i] < 0) continue;
+            TailDoc d;
+            d.from_sid = (uint32_t)from[i];
+            d.pass = (recs[i].rel_flags & HB_SKIPPED_REL_MASK) == 0 ? 1u : 0u;
+            d.to = recs[i].to;
+            open->push_back(d);
         }
-        for (uint64_t k : mapped)
-            if (k != ~0ull) keys->push_back(k);
+    } catch (const std::bad_alloc &) {
+        return "out of host memory collecting the tail records";
+    }
+    return "";
+}
+
+// LinksScorer over one posting list (query/raw/links.rs:115-232; one scorer per segment and term): `to` = the
+// dedup column (ToId) of the list's documents in doc order, `self` = the queried node.  emit[i] = the scorer
+// yields document i.  What it does, as written: self links are skipped; a document is skipped when its to_id
+// equals the to_id of the LAST YIELDED document (adjacent de-duplication only - the store keeps documents sorted
+// by sort_score, so equal targets are normally neighbours); and after every advance whole 128-document blocks
+// are jumped over while the LAST document of the block has that same to_id (skip-list shortcut, :203-213),
+// whatever lies in between.  The final partial block has no skip entry (tantivy postings/skip.rs:122-126,
+// 276-282: last_doc_in_block = TERMINATED), so it is never jumped.
+static void links_scorer_walk(const hb_u128 *to, uint64_t len, const hb_u128 &self, uint8_t *emit)
+{
+    constexpr uint64_t kBlock = 128; // COMPRESSION_BLOCK_SIZE
+    const uint64_t full = len / kBlock * kBlock; // documents in full blocks
+    uint64_t pos = 0;
+    while (pos < len && u128_eq(to[pos], self)) pos++; // LinksScorer::new, :143-165
+    if (pos >= len) return;
+    hb_u128 last = to[pos];
+    while (pos < len) {
+        emit[pos] = 1;
+        pos++; // postings.advance()
+        while (pos < full && u128_eq(to[pos / kBlock * kBlock + kBlock - 1], last)) pos = pos / kBlock * kBlock + kBlock;
+        while (pos < len && (u128_eq(to[pos], last) || u128_eq(to[pos], self))) pos++;
+        if (pos < len) last = to[pos];
+    }
+}
+
+// End of a segment: walk every host's posting list like LinksScorer does, then apply what harmonic.rs does to the
+// query's result: the rel filter on the YIELDED document (:87) and the two counter lookups (:91-92).  Keys
+// (source device row << 32 | target device row) are appended to *keys; *open is emptied.
+std::string tail_close_segment(const TailIndex *tix, const hb_u128 *ids, const uint32_t *dev_of, std::vector<TailDoc> *open,
+                               std::vector<uint64_t> *keys)
+{
+    if (open->empty()) return "";
+    if (!tix) return "out of host memory indexing the node ids";
+    try {
+        const IdIndex &index = tix->index;
+        std::stable_sort(open->begin(), open->end(), [](const TailDoc &a, const TailDoc &b) { return a.from_sid < b.from_sid; });
+        std::vector<hb_u128> to;
+        std::vector<uint8_t> emit;
+        for (size_t i = 0; i < open->size();) {
+            size_t j = i;
+            while (j < open->size() && (*open)[j].from_sid == (*open)[i].from_sid) j++;
+            const uint32_t f = (*open)[i].from_sid;
+            to.resize(j - i);
+            for (size_t k = i; k < j; k++) to[k - i] = (*open)[k].to;
+            emit.assign(j - i, 0);
+            links_scorer_walk(to.data(), j - i, ids[f], emit.data());
+            for (size_t k = i; k < j; k++) {
+                if (!emit[k - i] || !(*open)[k].pass) continue;
+                const int64_t t = index.find((*open)[k].to);
+                if (t >= 0) keys->push_back(((uint64_t)dev_of[f] << 32) | (uint64_t)dev_of[t]);
+            }
+            i = j;
+        }
+        std::vector<TailDoc>().swap(*open);
     } catch (const std::bad_alloc &) {
         return "out of host memory mapping the tail records";
     }

@@ -158,8 +158,15 @@ void keep_owned_rows(DenseGraph *g, uint64_t world, uint64_t rank);
 struct TailIndex; // id -> sid hash index over the (sorted, caller-owned) id array, built once per graph
 TailIndex *tail_index_build(const hb_u128 *ids, uint64_t n);
 void tail_index_free(TailIndex *t);
-std::string map_tail_records(const TailIndex *tix, uint64_t n, const uint32_t *dev_of, const hb_edge *recs, uint64_t count,
-                             std::vector<uint64_t> *keys);
+// a page-level document whose from_id is a host node id, kept until its segment ends (hb_host.cpp)
+struct TailDoc {
+    uint32_t from_sid;
+    uint32_t pass; // rel_flags & SKIPPED_REL == 0
+    hb_u128 to;
+};
+std::string tail_collect(const TailIndex *tix, uint64_t n, const hb_edge *recs, uint64_t count, std::vector<TailDoc> *open);
+std::string tail_close_segment(const TailIndex *tix, const hb_u128 *ids, const uint32_t *dev_of, std::vector<TailDoc> *open,
+                               std::vector<uint64_t> *keys);
 std::string build_tail_csr(std::vector<uint64_t> *keys, uint64_t n_pad, std::vector<uint64_t> *ptr, std::vector<uint32_t> *to);
 // --- hb_ingest.hip: the same reduction on the GPU (stream = hipStream_t); identical output
 // keep != NULL: the CSR stays on the device (returned in *keep, owned by the caller) and out->row_ptr / out->src

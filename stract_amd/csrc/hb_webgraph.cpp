@@ -12,6 +12,7 @@
 #include <cstdio>
 #include <cstring>
 #include <new>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -579,11 +580,22 @@ int hbw_read_page_edges(const hbw_reader *r, uint64_t first, uint64_t count, hb_
 int hb_load_webgraph(hb_ctx *ctx, const char *edges_dir, uint32_t flags)
 {
     if (!ctx) return HB_ERR_INVALID;
-    hbw_reader *r = nullptr;
-    int rc = hbw_open(edges_dir, flags, &r);
+    hbw_reader *raw = nullptr;
+    int rc = hbw_open(edges_dir, flags, &raw);
     if (rc != HB_OK) return rc; // message: hbw_last_error(NULL)
+    std::unique_ptr<hbw_reader, void (*)(hbw_reader *)> guard(raw, hbw_close); // closed on every path, exceptions included
+    hbw_reader *r = raw;
     return guarded(r, [&]() -> int {
         const uint64_t slab = 1ull << 22; // 4 Mi records (160 MiB) per hand-over
+        if (flags & HBW_PAGE_IDS) {
+            // page-level records need a context in reference-tail mode: find out before the whole store is ingested
+            int rc0 = hb_load_tail_edges(ctx, nullptr, 0);
+            const char *msg = hb_last_error(ctx);
+            if (rc0 != HB_OK && msg && std::strstr(msg, "HB_FLAG_REFERENCE_TAIL")) {
+                g_open_error = msg;
+                return rc0;
+            }
+        }
         std::vector<hb_edge> buf((size_t)std::min<uint64_t>(slab, std::max<uint64_t>(r->total, 1)));
         int rc2 = HB_OK;
         for (uint64_t at = 0; at < r->total && rc2 == HB_OK; at += slab) {
@@ -593,16 +605,19 @@ int hb_load_webgraph(hb_ctx *ctx, const char *edges_dir, uint32_t flags)
         }
         if (rc2 == HB_OK) rc2 = hb_finalize(ctx, nullptr, 0); // node set = all endpoints = host_nodes() (store.rs:338-357)
         if (rc2 == HB_OK && (flags & HBW_PAGE_IDS)) {
-            // HB_FLAG_REFERENCE_TAIL: every document's page-level (from_id, to_id, rel_flags); the library keeps those
-            // between two host nodes = what ForwardlinksQuery::new(host id) can return (harmonic.rs:82-92)
+            // HB_FLAG_REFERENCE_TAIL: every document's page-level (from_id, to_id, rel_flags), segment by segment in doc
+            // order (a ForwardlinksQuery runs one LinksScorer per segment; its de-duplication depends on that order,
+            // query/raw/links.rs:115-232); the library keeps what ForwardlinksQuery::new(host id) can return (harmonic.rs:82-92)
             rc2 = hb_load_tail_edges(ctx, nullptr, 0);
-            for (uint64_t at = 0; at < r->total && rc2 == HB_OK; at += slab) {
-                const uint64_t n = std::min(slab, r->total - at);
-                rc2 = hbw_read_page_edges(r, at, n, buf.data());
-                if (rc2 == HB_OK) rc2 = hb_append_tail_edges(ctx, buf.data(), n);
+            for (const Segment &s : r->segs) {
+                for (uint64_t at = 0; at < s.num_rows && rc2 == HB_OK; at += slab) {
+                    const uint64_t n = std::min(slab, s.num_rows - at);
+                    rc2 = hbw_read_page_edges(r, s.first + at, n, buf.data());
+                    if (rc2 == HB_OK) rc2 = hb_append_tail_edges(ctx, buf.data(), n);
+                }
+                if (rc2 == HB_OK) rc2 = hb_tail_segment_end(ctx);
             }
         }
-        hbw_close(r);
         return rc2;
     });
 }

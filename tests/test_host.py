@@ -26,7 +26,7 @@ def test_header_symbols_all_exported():
     assert not missing, missing
     # and the Python binding covers exactly the declared set
     assert declared == set(_lib.SYMBOLS)
-    assert _lib.load().hb_abi_version() == 2
+    assert _lib.load().hb_abi_version() == 3
 
 
 def test_struct_layouts_match_header():
@@ -283,8 +283,9 @@ def test_host_stages_under_sanitizers(tmp_path):
 
 
 def test_tail_index_filter_and_mapping():
-    """hb_debug_tail_index (host only): the index behind hb_load_tail_edges - records that pass the rel filter and whose
-    two ids are host nodes (harmonic.rs:87,91-92), as a CSR by source device row, duplicates dropped."""
+    """hb_debug_tail_index (host only): the index behind hb_load_tail_edges - what ForwardlinksQuery::new(host) yields from
+    the documents (one segment, doc order; LinksScorer restated independently in oracle/pyref.py), then the rel filter and
+    the two lookups (harmonic.rs:87,91-92), as a CSR by source device row, duplicates dropped."""
     import ctypes
     from tests import graphs
     lib = _lib.load()
@@ -306,16 +307,22 @@ def test_tail_index_filter_and_mapping():
     flagged = rng.random(m) < 0.2
     recs["rel_flags"][flagged] = graphs.NOFOLLOW
     recs["rel_flags"][~flagged & (rng.random(m) < 0.3)] = 1  # a flag outside SKIPPED_REL: kept
-    recs[:50] = recs[50:100]                                # duplicates
+    recs[:50] = recs[50:100]                                # duplicates far apart in the stream
+    # neighbouring duplicates with conflicting flags: flagged first (the link is lost) / clean first (kept) - the query's
+    # LinksScorer keeps the first of a run, harmonic.rs:87 filters on the survivor (query/raw/links.rs:115-232)
+    for k in range(200, 400, 4):
+        recs[k + 1] = recs[k]
+        recs["rel_flags"][k] = graphs.NOFOLLOW if (k // 4) % 2 else 0
+        recs["rel_flags"][k + 1] = 0 if (k // 4) % 2 else graphs.NOFOLLOW
+    recs[400:460]["to"] = recs[400:460]["from"]             # self links: skipped by the query
+    from oracle import pyref
     key = {(int(r["hi"]) << 64) | int(r["lo"]): i for i, r in enumerate(ids)}
-    want = set()
-    for r in recs:
-        if int(r["rel_flags"]) & 0x6FED00:
-            continue
-        a = key.get((int(r["from"]["hi"]) << 64) | int(r["from"]["lo"]))
-        b = key.get((int(r["to"]["hi"]) << 64) | int(r["to"]["lo"]))
-        if a is not None and b is not None:
-            want.add((int(dev_of[a]), int(dev_of[b])))
+    as_int = lambda v: (int(v["hi"]) << 64) | int(v["lo"])
+    pages = [(as_int(r["from"]), as_int(r["to"]), int(r["rel_flags"])) for r in recs]
+    fwd = pyref.forwardlinks_result(pages, set(key))
+    want = {(int(dev_of[key[f]]), int(dev_of[key[t]])) for f, ts in fwd.items() for t in ts}
+    naive = {(int(dev_of[key[f]]), int(dev_of[key[t]])) for f, t, fl in pages if not fl & 0x6FED00 and f in key and t in key}
+    assert want < naive                                     # "any record that passes" would keep more
     ptr = np.zeros(n_pad + 1, dtype=np.uint64)
     to = np.zeros(m, dtype=np.uint32)
     k = ctypes.c_uint64(0)

@@ -424,8 +424,8 @@ def _tuples_to_edges(tuples):
     return graphs.EdgeListGraph.from_tuples(tuples).host_edges() if tuples else np.zeros(0, dtype=hbo.EDGE)
 
 
-def _faithful_dict(edges, pages):
-    ids, vals, st = hbo.faithful_run(edges, pages)
+def _faithful_dict(edges, pages, segments=None):
+    ids, vals, st = hbo.faithful_run(edges, pages, segments)
     return {(int(h) << 64) | int(l): float(v) for l, h, v in zip(ids["lo"], ids["hi"], vals)}, st
 
 
@@ -462,6 +462,88 @@ def test_reference_tail_two_restatements_agree():
     assert passes < base_passes and tail_passes == 1
     diff = [k for k in base if base[k] != py.get(k)]
     assert 0 < len(diff) < 60 and all(py.get(k, 0.0) < base[k] for k in diff)
+
+
+def test_links_scorer_two_restatements_agree():
+    """LinksScorer (query/raw/links.rs:115-232), the de-duplication a ForwardlinksQuery applies BEFORE harmonic.rs:87
+    sees any flags: pyref simulates tantivy's block cursor literally, the C oracle states the same walk in closed form.
+    Hand cases first (what the code does, as written), then random posting lists across the 128-document block sizes."""
+    import random
+
+    from oracle import pyref
+
+    def c_emit(vals, me):
+        to = np.zeros(len(vals), dtype=hbo.U128)
+        to["lo"] = np.array(vals, dtype=np.uint64)
+        meid = np.zeros(1, dtype=hbo.U128)
+        meid["lo"] = me
+        return [int(i) for i in np.nonzero(hbo.links_scorer(to, meid[0]))[0]]
+
+    hand = [
+        ([], 9, []),
+        ([9, 9, 9], 9, []),                               # only self links
+        ([9, 2, 2, 3, 2], 9, [1, 3, 4]),                  # adjacent duplicates only: the second `2` run is yielded again
+        ([2, 9, 2, 3], 9, [0, 3]),                        # a self link between two equal targets does not reset the memory
+        ([2] + [3] * 126 + [2] + [4, 5], 9, [0, 128, 129]),  # block jump: the LAST doc of the full block repeats -> `3` is never seen
+        ([2] + [3] * 126 + [4] + [4, 5], 9, [0, 1, 127, 129]),
+        ([1, 2] + [3] * 125 + [2] + [4] * 127 + [2] + [5], 9, [0, 1, 256]),
+    ]
+    for vals, me, want in hand:
+        assert pyref.links_scorer_docs(vals, me) == want, vals[:8]
+        assert c_emit(vals, me) == want, vals[:8]
+    rng = random.Random(5)
+    for _ in range(1500):
+        n = rng.choice([1, 2, 5, 127, 128, 129, 255, 256, 257, 300, 513])
+        me = 7
+        vals = [rng.choice([1, 2, 3, me]) if rng.random() < 0.7 else rng.randrange(1, 6) for _ in range(n)]
+        if rng.random() < 0.4:
+            for b in range(0, n - 127, 128):
+                if rng.random() < 0.6:
+                    vals[b + 127] = vals[b - 1] if b else vals[0]
+        assert c_emit(vals, me) == pyref.links_scorer_docs(vals, me)
+
+
+def test_reference_tail_conflicting_duplicate_flags():
+    """Page-level duplicates of one (from_id, to_id) with DIFFERENT rel flags: the query keeps the first of a run of
+    neighbours (per segment), harmonic.rs:87 then filters on that survivor's flags only - so a flagged document in front
+    of a clean one loses the link, the other order keeps it, and a segment boundary between them keeps it too."""
+    from oracle import pyref
+
+    host = graphs.tailed_graph()
+    e = _tuples_to_edges(host)
+    chain = host[-60:]
+    pages, lost, kept = [], set(), set()
+    for k, (f, t, _) in enumerate(host[:-60]):
+        pages.append((f, t, 0))
+    for k, (f, t, _) in enumerate(chain):
+        if k % 3 == 0:
+            pages += [(f, t, graphs.NOFOLLOW), (f, t, 0)]     # flagged first: the clean copy is de-duplicated away
+            lost.add((f, t))
+        elif k % 3 == 1:
+            pages += [(f, t, 0), (f, t, graphs.NOFOLLOW)]     # clean first: kept
+            kept.add((f, t))
+        else:
+            pages.append((f, t, 0))
+    nodes = {x for a, b, _ in host for x in (a, b)}
+    fwd = pyref.forwardlinks_result(pages, nodes)
+    got = {(f, t) for f, ts in fwd.items() for t in ts}
+    assert not (got & lost) and kept <= got
+    naive = {(f, t) for f, t, fl in pages if not fl & 0x6FED00}
+    assert lost <= naive                                      # "any duplicate passes" would keep them: the divergence
+    # one segment, and the same documents with a boundary right after every flagged-first document
+    py1, p1, t1 = pyref.harmonic_centrality_reference(host, pages)
+    g1, st1 = _faithful_dict(e, _tuples_to_edges(pages))
+    assert (st1["passes"], st1["passes_exact"]) == (p1, t1) and list(g1.keys()) == list(py1.keys())
+    assert [np.float64(v).view(np.uint64) for v in g1.values()] == [np.float64(v).view(np.uint64) for v in py1.values()]
+    cuts = [i + 1 for i, pg in enumerate(pages) if pg[2] and (pg[0], pg[1]) in lost]
+    segs = [b - a for a, b in zip([0] + cuts, cuts + [len(pages)])]
+    py2, p2, t2 = pyref.harmonic_centrality_reference(host, pages, segs)
+    g2, st2 = _faithful_dict(e, _tuples_to_edges(pages), segs)
+    assert (st2["passes"], st2["passes_exact"]) == (p2, t2) and list(g2.keys()) == list(py2.keys())
+    assert [np.float64(v).view(np.uint64) for v in g2.values()] == [np.float64(v).view(np.uint64) for v in py2.values()]
+    base, _ = pyref.harmonic_centrality(host)
+    assert py2 == base or p2 >= p1                            # with the boundaries every link is found again
+    assert py1 != py2                                         # the lost links change the result
 
 
 def test_pyref_bloom_matches_c_pieces():
