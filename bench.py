@@ -12,10 +12,17 @@ torch.distributed.run, one rank per GPU).  Prints ONE JSON line on rank 0.
   workload  = BASELINE.json configs[2] (10M-host / 200M-edge R-MAT, the roofline config) by
               default; --config C2 selects configs[1] (1M/20M: fits the 256 MiB Infinity Cache, so
               it says little about HBM), C4 = configs[3], C5 = configs[4], LT = the long-tail graph.
+  input     = N = 1: the graph enters through the drop-in boundary - raw 40-byte SmallEdge records (with
+              flagged-first pairs and duplicates, a stream the reference semantics reduce to exactly the
+              clean graph) streamed through hb_append_edges + hb_finalize (detail.input: records/s,
+              link rate, peak device bytes); --input dense = the bench-only hb_load_dense export.
   N > 1     = the same graph partitioned over the ranks (strong scaling), one RCCL collective of
-              the counters per pass: --partition dest (default) = rows by owner,
-              ncclAllGather of the owned slices; --partition edge = the north-star edge partition
-              with ncclAllReduce(max, u8).
+              the counters per pass.  `value` = the north-star decomposition: edge
+              partition + ncclAllReduce(max, u8); with --partition both (default) the destination
+              partition (+ ncclAllGather) and its changed-only variant run as extra legs under
+              detail.partitions, each with GTEPS, ms_collective, wire bytes and a same-result field.
+  c4 leg    = with the default config at N = 1 the line also carries detail.c4: BASELINE configs[3]
+              (100M hosts / 2B edges) on one GPU - GTEPS, roofline fractions, parity (~2-3 min).
   roofline  = SURVEY.md §8(d): HBM-bound.  Headline `achieved`/`frac` = the WHOLE generic dense pass
               (dense passes t >= 1: B_t with their own A_t) over its measured GPU time (HIP events on
               the library's stream) vs 8 TB/s.  Pass 0 (68*m_eff + 192.25*n algorithmic bytes) is
@@ -55,11 +62,18 @@ def parse():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--config", default=os.environ.get("HB_BENCH_CONFIG", "C3"), help="C1|C2|C3|C4|C5|LT or scale:m")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="CPU-baseline time bound (0 = skip)")
-    ap.add_argument("--partition", default="dest", choices=["dest", "edge"],
-                    help="N > 1: destination partition + all-gather per pass (default) or the north-star "
-                         "edge partition + all-reduce(max) per pass")
+    ap.add_argument("--input", default=os.environ.get("HB_BENCH_INPUT", "records"), choices=["records", "dense"],
+                    help="N = 1: how the graph enters the library.  records (default) = the drop-in boundary: raw 40-byte SmallEdge "
+                         "records streamed through hb_append_edges + hb_finalize (GPU ingest, device planner); dense = the bench-only "
+                         "hb_load_dense export (pre-reduced CSR).  N > 1 always uses dense (every rank slices the same CSR)")
+    ap.add_argument("--partition", default="both", choices=["both", "edge", "dest"],
+                    help="N > 1: edge = the north-star edge partition + ncclAllReduce(max,u8) per pass (this is `value`); dest = "
+                         "destination partition + ncclAllGather per pass; both (default) = edge first, then dest and dest+changed-only "
+                         "as extra legs under detail.partitions")
     ap.add_argument("--changed-only", action="store_true",
                     help="N > 1, --partition dest: exchange only the counters that changed (HB_FLAG_CHANGED_ONLY)")
+    ap.add_argument("--c4-leg", default="auto", choices=["auto", "on", "off"],
+                    help="append a BASELINE configs[3] (100M-host / 2B-edge) leg under detail.c4 (auto: with the default config at N = 1)")
     ap.add_argument("--flags", type=int, default=0)
     ap.add_argument("--chunk", type=int, default=0)
     ap.add_argument("--tune", default="", help="comma separated hb_options.tune values")
@@ -79,6 +93,173 @@ def pass_bytes(ps, n, m_eff, rows_with_in):
     else:
         v = int(ps["touched"])
     return 68.0 * a + 4.0 * (m_eff - a) + 184.0 * v + 8.0 * n + n / 4.0
+
+
+def moved_bytes(ps, n, m_eff, rows_with_in, work_rows, init_streamed):
+    """Bytes the pass actually has to move in THIS implementation (a model, next to the §8(d) bytes it is booked with):
+    pass 0 streams 2 B per edge instead of gathering; a sweep pass (mode 2) never reads the index lists of untouched rows
+    (no 4*(m - A_t) term, no per-node row pointers) but reads/clears the touch bitmap and three per-node bitmaps."""
+    a = min(int(ps["active_edges"]), m_eff)
+    if ps["pass"] == 0 and init_streamed:
+        return 2.0 * m_eff + 4.0 * m_eff + 192.25 * n  # initial registers + indices + the node state
+    if ps["mode"] == 2:
+        return 68.0 * a + 184.0 * int(ps["touched"]) + work_rows / 4.0 + 3.0 * n / 8.0
+    return pass_bytes(ps, n, m_eff, rows_with_in)
+
+
+def measure(ctx, steps, warmup, barrier, td, torch):
+    """W untimed + K timed complete runs (hb_begin + all passes + hb_finish); wall time bracketed by barrier + synchronize, max over ranks."""
+    for _ in range(warmup):
+        ctx.run()
+    barrier()
+    t0 = time.perf_counter()
+    r = {"loop_ms": 0.0, "gpu_ms": 0.0, "coll_ms": 0.0, "d2h_ms": 0.0, "passes": 0, "pass_stats": []}
+    for _ in range(steps):
+        ctx.run()
+        st = ctx.stats()
+        r["passes"] = int(st["passes"])
+        r["loop_ms"] += st["ms_loop"]
+        r["gpu_ms"] += st["ms_loop_gpu"]
+        r["coll_ms"] += st["ms_collective"]
+        r["d2h_ms"] += st["ms_d2h"]
+        r["pass_stats"].append(ctx.pass_stats())
+    barrier()
+    dt = time.perf_counter() - t0
+    if td is not None:
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        td.all_reduce(tt, op=td.ReduceOp.MAX)
+        dt = float(tt.item())
+    r["dt"] = dt
+    r["stats"] = ctx.stats()
+    return r
+
+
+def load_records(ctx, g, salt=2, slab=1 << 24):
+    """The drop-in boundary: the graph as raw SmallEdge records (stream order, flagged-first pairs, duplicates - a stream the
+    reference semantics reduce to exactly g), one pinned slab at a time through hb_append_edges, then hb_finalize."""
+    import torch
+
+    total = g.stream_len(salt)
+    slab = min(slab, max(total, 1))
+    from stract_amd import _lib
+    pinned = torch.empty(slab * _lib.EDGE.itemsize, dtype=torch.uint8, pin_memory=True)
+    buf = pinned.numpy().view(_lib.EDGE)
+    s_fill = s_append = 0.0
+    at = 0
+    while at < total:
+        t0 = time.perf_counter()
+        k = g.stream_fill(buf, at, salt)
+        t1 = time.perf_counter()
+        ctx.append_edges(buf[:k])
+        s_fill += t1 - t0
+        s_append += time.perf_counter() - t1
+        at += k
+    t0 = time.perf_counter()
+    ctx.finalize()
+    s_fin = time.perf_counter() - t0
+    st = ctx.stats()
+    ok = st["n"] == g.n and st["m_eff"] == g.m and st["m_input"] == total
+    if not ok:
+        raise RuntimeError("ingest of the record stream did not reduce to the clean graph: n %d/%d m_eff %d/%d" % (st["n"], g.n, st["m_eff"], g.m))
+    return {"path": "hb_append_edges x %d + hb_finalize (GPU ingest, device planner)" % ((total + slab - 1) // slab),
+            "records": total, "record_GB": round(total * 40 / 1e9, 2), "flagged_or_duplicate_records": total - int(g.m),
+            "s_fill_slabs_host": round(s_fill, 2), "s_append_edges": round(s_append, 2), "s_finalize": round(s_fin, 2),
+            "append_GBs": round(total * 40 / max(s_append, 1e-9) / 1e9, 2),
+            "records_per_s": round(total / max(s_append + s_fin, 1e-9)),
+            "ingest_peak_device_bytes": int(st["ingest_peak_bytes"]), "m_unique": int(st["m_unique"])}
+
+
+def per_pass_avg(all_pass_stats, n, m_eff, rows_in, work_rows, init_streamed):
+    T = len(all_pass_stats[-1]) if all_pass_stats else 0
+    avg = []
+    for t in range(T):
+        rows = [s[t] for s in all_pass_stats if len(s) == T]
+        d = dict(rows[-1])
+        for k in ("ms_gpu", "ms_main", "ms_level1", "ms_collective"):
+            d[k] = float(np.mean([r[k] for r in rows]))
+        d["alg_bytes"] = pass_bytes(d, n, m_eff, rows_in)
+        d["moved_bytes"] = moved_bytes(d, n, m_eff, rows_in, work_rows, init_streamed)
+        avg.append(d)
+    return avg
+
+
+def roofline_of(avg, stats, steps, n, m_eff, init_streamed, config):
+    """roofline object of the JSON line: headline = the whole generic dense pass; kernels[] = the launches /
+    passes the review tracks, each with its own algorithmic bytes and event-timed duration."""
+    dense = [d for d in avg if d["mode"] == 0 and (d["pass"] > 0 or not init_streamed)]
+    if not dense:
+        dense = [d for d in avg if d["mode"] == 0]
+    if not dense:
+        return None
+    rows_in = int(stats["rows_with_in_edges"])
+    gbs = lambda b, ms: b / (max(ms, 1e-9) * 1e-3) / 1e9
+    b_dense = sum(d["alg_bytes"] for d in dense)
+    ms_dense = sum(d["ms_gpu"] - d["ms_collective"] for d in dense)
+    achieved = gbs(b_dense, ms_dense)
+    l1_edges, direct = int(stats["level1_edges"]), int(stats["direct_edges"])
+    l1_ms = float(np.mean([d["ms_level1"] for d in dense]))
+    kernels = []
+    dom = None
+    pmc = _pmc(config)
+    if l1_edges and l1_ms > 0:
+        dom_b = 68.0 * l1_edges
+        tr = pmc.get("hub_level1_dense", {})
+        dom = {"kernel": "hbk::pass_kernel<false,false,false,false,4,false>, level-1 launch (dense pull over the hub chunks)",
+               "alg_bytes_per_launch": dom_b, "alg_bytes_def": "68 B x real edges gathered by the launch (%d)" % l1_edges,
+               "avg_launch_ms": round(l1_ms, 4), "launches": len(dense) * steps,
+               "achieved": round(gbs(dom_b, l1_ms), 1), "frac": round(gbs(dom_b, l1_ms) / HBM_PEAK_GBS, 4),
+               "traffic": tr.get("hbm_bytes_per_dispatch"), "l2_hit_rate": tr.get("l2_hit_rate"), "traffic_source": pmc.get("_source")}
+        kernels.append(dict(dom, name="hub_level1_dense"))
+    node_ms = float(np.mean([d["ms_main"] for d in dense]))
+    if node_ms > 0:
+        nb = 68.0 * direct + 192.25 * n
+        tr = pmc.get("node_rows_dense", {})
+        kernels.append({"name": "node_rows_dense", "kernel": "hbk::pass_kernel<true,false,true,false,2,false> (node rows: direct gathers + partials, "
+                        "merge, changed bits, fused estimator + Kahan)", "alg_bytes_per_launch": nb,
+                        "alg_bytes_def": "68 B x direct real edges (%d) + 192.25 B x nodes (%d)" % (direct, n), "avg_launch_ms": round(node_ms, 4),
+                        "achieved": round(gbs(nb, node_ms), 1), "frac": round(gbs(nb, node_ms) / HBM_PEAK_GBS, 4),
+                        "traffic": tr.get("hbm_bytes_per_dispatch"), "l2_hit_rate": tr.get("l2_hit_rate")})
+    for d in avg:
+        if d["mode"] == 1:
+            kernels.append({"name": "bitmap_pass_t%d" % d["pass"], "kernel": "whole pass, pass_kernel<*,FRONTIER=true,...> launches",
+                            "A_t_pct": round(100.0 * d["active_edges"] / m_eff, 2), "alg_bytes": d["alg_bytes"], "ms": round(d["ms_gpu"], 4),
+                            "achieved": round(gbs(d["alg_bytes"], d["ms_gpu"]), 1), "frac": round(gbs(d["alg_bytes"], d["ms_gpu"]) / HBM_PEAK_GBS, 4)})
+    sweeps = [d for d in avg if d["mode"] == 2]
+    if sweeps:
+        d = sweeps[0]
+        kernels.append({"name": "first_sweep_pass_t%d" % d["pass"], "kernel": "whole pass, sweep_collect/expand/rows launches",
+                        "A_t_pct": round(100.0 * d["active_edges"] / m_eff, 3), "alg_bytes": d["alg_bytes"], "moved_bytes_model": d["moved_bytes"],
+                        "ms": round(d["ms_gpu"], 4), "achieved": round(gbs(d["alg_bytes"], d["ms_gpu"]), 1),
+                        "frac": round(gbs(d["alg_bytes"], d["ms_gpu"]) / HBM_PEAK_GBS, 4),
+                        "frac_moved": round(gbs(d["moved_bytes"], d["ms_gpu"]) / HBM_PEAK_GBS, 4)})
+        tail = [x for x in sweeps if x["active_edges"] * 1000 < m_eff]
+        if tail:
+            kernels.append({"name": "far_tail_passes", "passes": len(tail), "ms_mean": round(float(np.mean([x["ms_gpu"] for x in tail])), 4),
+                            "ms_min": round(float(min(x["ms_gpu"] for x in tail)), 4), "bound": "launch latency, not bytes"})
+    p0 = avg[0]
+    b_loop = sum(d["alg_bytes"] for d in avg)
+    mv_loop = sum(d["moved_bytes"] for d in avg)
+    ms_loop_gpu = sum(d["ms_gpu"] for d in avg)
+    return {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+            "traffic": dom["traffic"] if dom else None,
+            "what": "whole dense pass (all launches of the pass), algorithmic bytes B_t of SURVEY.md 8(d) over event-timed GPU time, mean over "
+                    "the %d dense passes t >= 1%s; `traffic` = PMC HBM bytes of ONE level-1 launch of the dominant kernel" % (
+                        len(dense), " (pass 0 apart: it streams 2 B per edge instead of gathering, see pass0)" if init_streamed else ""),
+            "frac_of_measured_copy_6.29TBs": round(achieved / HBM_COPY_GBS, 4),
+            "pass0": {"alg_bytes": p0["alg_bytes"], "ms": round(p0["ms_gpu"] - p0["ms_collective"], 4),
+                      "achieved_on_alg_bytes": round(gbs(p0["alg_bytes"], p0["ms_gpu"] - p0["ms_collective"]), 1),
+                      "streamed_initial_registers": bool(init_streamed), "moved_bytes_model": p0["moved_bytes"],
+                      "frac_moved": round(gbs(p0["moved_bytes"], p0["ms_gpu"] - p0["ms_collective"]) / HBM_PEAK_GBS, 4)},
+            "dominant_kernel": dom, "kernels": kernels,
+            "whole_loop": {"alg_bytes": b_loop, "moved_bytes_model": mv_loop, "ms_gpu": round(ms_loop_gpu, 4),
+                           "achieved": round(gbs(b_loop, ms_loop_gpu), 1), "frac": round(gbs(b_loop, ms_loop_gpu) / HBM_PEAK_GBS, 4),
+                           "frac_moved": round(gbs(mv_loop, ms_loop_gpu) / HBM_PEAK_GBS, 4),
+                           "note": "frac books every pass with its 8(d) bytes (pass 0 and sweep passes move less than that); frac_moved uses the moved-bytes model"},
+            "per_pass": [{"t": int(d["pass"]), "mode": int(d["mode"]), "A_t": int(d["active_edges"]),
+                          "V_t": (n if d["pass"] == 0 else rows_in if d["mode"] == 0 else int(d["touched"])), "ms": round(d["ms_gpu"], 4),
+                          "ms_level1_or_expand": round(d["ms_level1"], 4), "ms_node_rows": round(d["ms_main"], 4), "changed": int(d["changed"]),
+                          "frac": round(gbs(d["alg_bytes"], d["ms_gpu"]) / HBM_PEAK_GBS, 4),
+                          "frac_moved": round(gbs(d["moved_bytes"], d["ms_gpu"]) / HBM_PEAK_GBS, 4)} for d in avg]}
 
 
 def main():
@@ -103,141 +284,70 @@ def main():
 
     from stract_amd import _lib, dist, synth
 
-    # ---- synthetic input (identical on every rank, deterministic seed)
-    t0 = time.perf_counter()
-    g, scale, label = synth.make_config(a.config)
-    t_gen = time.perf_counter() - t0
-    n, m_eff = int(g.n), int(g.m)
-
-    rccl_id = None
-    flags = a.flags
-    if world > 1:
-        rccl_id = dist.torch_unique_id(rank, world)
-        if a.partition == "dest":
-            flags |= _lib.HB_FLAG_DEST_PARTITION
-            if a.changed_only:
-                flags |= _lib.HB_FLAG_CHANGED_ONLY
-    tune = tuple(int(x) for x in a.tune.split(",")) if a.tune else ()
-    ctx = _lib.Context(device=local_rank, flags=flags, chunk=a.chunk, rank=rank, world_size=world, rccl_id=rccl_id,
-                       tune=tune)
-    if world > 1:
-        split = dist.partition_dense_by_dest if a.partition == "dest" else dist.partition_dense
-        rp, src = split(g.row_ptr, g.src, rank, world)
-    else:
-        rp, src = g.row_ptr, g.src
-    t0 = time.perf_counter()
-    ctx.load_dense(g.ids, rp, src)
-    t_load = time.perf_counter() - t0
-
     def barrier():
         torch.cuda.synchronize()
         if td is not None:
             td.barrier()
         torch.cuda.synchronize()
 
-    def one_step():
-        ctx.run()  # hb_begin + loop + hb_finish (normalise + result download), blocking
-        return ctx.stats()
-
-    for _ in range(a.warmup):
-        one_step()
-    barrier()
+    # ---- synthetic input (identical on every rank, deterministic seed)
     t0 = time.perf_counter()
-    loop_ms, gpu_ms, coll_ms, d2h_ms = 0.0, 0.0, 0.0, 0.0
-    passes = 0
-    all_pass_stats = []
-    for _ in range(a.steps):
-        st = one_step()
-        passes = int(st["passes"])
-        loop_ms += st["ms_loop"]
-        gpu_ms += st["ms_loop_gpu"]
-        coll_ms += st["ms_collective"]
-        d2h_ms += st["ms_d2h"]
-        all_pass_stats.append(ctx.pass_stats())
-    barrier()
-    dt = time.perf_counter() - t0
-    if td is not None:
-        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        td.all_reduce(tt, op=td.ReduceOp.MAX)
-        dt = float(tt.item())
+    g, scale, label = synth.make_config(a.config)
+    t_gen = time.perf_counter() - t0
+    n, m_eff = int(g.n), int(g.m)
+    tune = tuple(int(x) for x in a.tune.split(",")) if a.tune else ()
+    init_streamed = not (a.flags & _lib.HB_FLAG_NO_INIT_PASS)
+
+    def run_leg(partition, changed_only=False):
+        """One decomposition: context, load, W + K runs.  Returns (ctx, measurement, load info)."""
+        flags = a.flags
+        rccl_id = None
+        if world > 1:
+            rccl_id = dist.torch_unique_id(rank, world)
+            if partition == "dest":
+                flags |= _lib.HB_FLAG_DEST_PARTITION | (_lib.HB_FLAG_CHANGED_ONLY if changed_only else 0)
+        ctx = _lib.Context(device=local_rank, flags=flags, chunk=a.chunk, rank=rank, world_size=world, rccl_id=rccl_id, tune=tune)
+        t0 = time.perf_counter()
+        info = {"path": "hb_load_dense (bench-only export: pre-reduced CSR)"}
+        if world > 1:
+            split = dist.partition_dense_by_dest if partition == "dest" else dist.partition_dense
+            rp, src = split(g.row_ptr, g.src, rank, world)
+            ctx.load_dense(g.ids, rp, src)
+        elif a.input == "records":
+            try:
+                info = load_records(ctx, g)
+            except Exception as e:  # the bench line must still be produced; the failure is stated in it
+                ctx.close()
+                ctx = _lib.Context(device=local_rank, flags=flags, chunk=a.chunk, tune=tune)
+                ctx.load_dense(g.ids, g.row_ptr, g.src)
+                info = {"path": "hb_load_dense (the record path FAILED: %s)" % (str(e)[:300],)}
+        else:
+            ctx.load_dense(g.ids, g.row_ptr, g.src)
+        info["s_load"] = round(time.perf_counter() - t0, 2)
+        return ctx, measure(ctx, a.steps, a.warmup, barrier, td, torch), info
+
+    main_part = "single" if world == 1 else ("dest" if a.partition == "dest" else "edge")
+    ctx, ms, load = run_leg(main_part, a.changed_only and main_part == "dest")
     ids, vals = ctx.results()
-    stats = ctx.stats()
-    last_pass_stats = all_pass_stats[-1] if all_pass_stats else []
+    stats = ms["stats"]
+    passes = ms["passes"]
+    last_pass_stats = ms["pass_stats"][-1] if ms["pass_stats"] else []
 
     # ---- parity + CPU baseline (rank 0 computes; a checksum rerun, if needed, is collective)
     cpu, parity = None, None
+    cores_used = [None]
     if a.cpu_seconds > 0 or a.verify:
-        cpu, parity = cpu_and_parity(a, g, ctx, td, rank, world, passes, ids, vals, last_pass_stats)
+        cpu, parity = cpu_and_parity(a, g, ctx, td, rank, world, passes, ids, vals, last_pass_stats, cores_out=cores_used)
 
+    steps = max(a.steps, 1)
+    out = None
     if rank == 0:
-        steps = max(a.steps, 1)
-        teps = m_eff * passes * steps / dt
+        teps = m_eff * passes * steps / ms["dt"]
         rows_in = int(stats["rows_with_in_edges"])
-        # per-pass averages over the timed steps
-        T = len(last_pass_stats)
-        avg = []
-        for t in range(T):
-            rows = [s[t] for s in all_pass_stats if len(s) == T]
-            d = dict(rows[-1])
-            for k in ("ms_gpu", "ms_main", "ms_level1", "ms_collective"):
-                d[k] = float(np.mean([r[k] for r in rows]))
-            d["alg_bytes"] = pass_bytes(d, n, m_eff, rows_in)
-            avg.append(d)
-        # the generic dense pass = dense passes t >= 1.  Pass 0 is reported on its own: since r02x it streams the sources'
-        # single initial register with the edge list (2 B per edge) instead of gathering 64-byte counters, so its
-        # 8(d) bytes are not what it moves and it must not lift the headline (HB_FLAG_NO_INIT_PASS restores the gathers)
-        init_streamed = not (flags & _lib.HB_FLAG_NO_INIT_PASS)
-        dense = [d for d in avg if d["mode"] == 0 and (d["pass"] > 0 or not init_streamed)]
-        if not dense:
-            dense = [d for d in avg if d["mode"] == 0]
-        roof = None
-        if dense:
-            b_dense = sum(d["alg_bytes"] for d in dense)
-            ms_dense = sum(d["ms_gpu"] - d["ms_collective"] for d in dense)
-            achieved = b_dense / (ms_dense * 1e-3) / 1e9
-            b_loop = sum(d["alg_bytes"] for d in avg)
-            ms_loop_gpu = sum(d["ms_gpu"] for d in avg)
-            l1_edges = int(stats["level1_edges"])
-            l1_ms = float(np.mean([d["ms_level1"] for d in dense]))
-            dom = None
-            if l1_edges and l1_ms > 0:
-                dom_b = 68.0 * l1_edges
-                traffic, traffic_src = _pmc_traffic(a.config)
-                dom = {"kernel": "hbk::pass_kernel<false,false,false,false,4> level-1 launch (dense pull over hub chunks)",
-                       "alg_bytes_per_launch": dom_b, "alg_bytes_def": "68 B x real edges gathered by the launch (%d)" % l1_edges,
-                       "avg_launch_ms": round(l1_ms, 4), "launches": len(dense) * steps,
-                       "achieved": round(dom_b / (l1_ms * 1e-3) / 1e9, 1), "frac": round(dom_b / (l1_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                       "traffic": traffic, "traffic_source": traffic_src}
-            p0 = avg[0]
-            roof = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 4),
-                    "traffic": dom["traffic"] if dom else None,
-                    "what": "whole dense pass (all launches of the pass), algorithmic bytes B_t of SURVEY.md 8(d) over "
-                            "event-timed GPU time, mean over the %d dense passes t >= 1%s" % (
-                                len(dense), " (pass 0 apart: it streams 2 B per edge instead of gathering, see pass0)" if init_streamed else ""),
-                    "frac_of_measured_copy_6.29TBs": round(achieved / HBM_COPY_GBS, 4),
-                    "pass0": {"alg_bytes": p0["alg_bytes"], "ms": round(p0["ms_gpu"] - p0["ms_collective"], 4),
-                              "achieved": round(p0["alg_bytes"] / ((p0["ms_gpu"] - p0["ms_collective"]) * 1e-3) / 1e9, 1),
-                              "streamed_initial_registers": bool(init_streamed),
-                              "moved_bytes_model": (2.0 * m_eff + 192.25 * n) if init_streamed else p0["alg_bytes"]},
-                    "dominant_kernel": dom,
-                    "whole_loop": {"alg_bytes": b_loop, "ms_gpu": round(ms_loop_gpu, 4),
-                                   "achieved": round(b_loop / (ms_loop_gpu * 1e-3) / 1e9, 1),
-                                   "frac": round(b_loop / (ms_loop_gpu * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
-                    "per_pass": [{"t": int(d["pass"]), "mode": int(d["mode"]), "A_t": int(d["active_edges"]),
-                                  "V_t": (n if d["pass"] == 0 else rows_in if d["mode"] == 0 else int(d["touched"])),
-                                  "ms": round(d["ms_gpu"], 4),
-                                  "frac": round(d["alg_bytes"] / (max(d["ms_gpu"], 1e-6) * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
-                                 for d in avg]}
+        avg = per_pass_avg(ms["pass_stats"], n, m_eff, rows_in, int(stats["work_rows"]), init_streamed)
+        roof = roofline_of(avg, stats, steps, n, m_eff, init_streamed, a.config)
         gathered = sum(min(int(d["active_edges"]), m_eff) if d["pass"] else m_eff for d in avg)
-        n_pad = (n + 63) // 64 * 64
-        wire = None
-        if world > 1:
-            wire = {"ran": a.partition + ("+changed-only" if (a.partition == "dest" and a.changed_only) else ""),
-                    "received_bytes_per_gpu_per_run": int(stats["wire_bytes"]),
-                    "edge_allreduce_bytes_per_gpu_per_pass": 2.0 * (world - 1) / world * n_pad * 64,
-                    "dest_allgather_bytes_per_gpu_per_pass": (world - 1) / world * (n_pad * 64 + n_pad / 8),
-                    "ms_collective_per_pass": round(coll_ms / steps / max(passes, 1), 4)}
+        loop_ms = ms["loop_ms"]
         out = {
             "metric": "HyperBall traversed edges/sec (GTEPS)",
             "value": round(teps / 1e9, 4),
@@ -245,7 +355,7 @@ def main():
             "n_gpus": world,
             "steps": a.steps,
             "warmup": a.warmup,
-            "ms_per_step": round(dt * 1e3 / steps, 3),
+            "ms_per_step": round(ms["dt"] * 1e3 / steps, 3),
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
@@ -254,19 +364,20 @@ def main():
             "config": {"workload": "%s %s" % (a.config, label),
                        "n_hosts": n, "m_eff": m_eff, "passes_T": passes,
                        "parallelism": ("1 GPU" if world == 1 else
-                                       "destination-partition x%d + allgather(u8)/pass" % world if a.partition == "dest" else
+                                       "destination-partition x%d + allgather(u8)/pass" % world if main_part == "dest" else
                                        "edge-partition x%d + allreduce(max,u8)/pass" % world)},
             "parity_bit_exact": None if parity is None else parity["bit_exact"],
             "parity": parity,
             "roofline": roof,
             "cpu_baseline": cpu,
-            "detail": {"ms_loop_per_step": round(loop_ms / steps, 3), "ms_gpu_passes_per_step": round(gpu_ms / steps, 3),
-                       "ms_collective_per_step": round(coll_ms / steps, 3), "ms_finish_per_step": round(d2h_ms / steps, 3),
+            "detail": {"input": load,
+                       "ms_loop_per_step": round(loop_ms / steps, 3), "ms_gpu_passes_per_step": round(ms["gpu_ms"] / steps, 3),
+                       "ms_collective_per_step": round(ms["coll_ms"] / steps, 3), "ms_finish_per_step": round(ms["d2h_ms"] / steps, 3),
                        "loop_gteps": round(m_eff * passes / (loop_ms / steps * 1e-3) / 1e9, 4) if loop_ms else None,
                        "gathered_edges_per_run": gathered,
                        "gathered_gteps": round(gathered / (loop_ms / steps * 1e-3) / 1e9, 4) if loop_ms else None,
-                       "collective": wire,
-                       "results": int(len(vals)), "s_generate": round(t_gen, 2), "s_load": round(t_load, 2),
+                       "collective": wire_info(world, main_part, a.changed_only and main_part == "dest", stats, n, ms, steps) if world > 1 else None,
+                       "results": int(len(vals)), "s_generate": round(t_gen, 2), "s_load": load["s_load"],
                        "ms_plan": round(stats["ms_plan"], 1), "ms_h2d": round(stats["ms_h2d"], 1),
                        "device_bytes": int(stats["device_bytes"]), "virtual_rows": int(stats["virtual_rows"]),
                        "level1_edges": int(stats["level1_edges"]), "direct_edges": int(stats["direct_edges"])},
@@ -274,27 +385,109 @@ def main():
         if a.pass_log:
             with open(a.pass_log, "w") as f:
                 json.dump({"config": out["config"], "passes": avg}, f, indent=1)
-        print(json.dumps(out), flush=True)
+    ref_sig = (len(vals), int(vals.view(np.uint64).sum() & 0xFFFFFFFFFFFFFFFF)) if len(vals) else (0, 0)
     ctx.close()
+
+    # ---- N > 1: the other decompositions, same graph, same K / W (extra legs; `value` stays the edge partition)
+    if world > 1 and a.partition == "both":
+        legs = {}
+        for name, part, co in (("dest_allgather", "dest", False), ("dest_changed_only", "dest", True)):
+            c2, m2, _ = run_leg(part, co)
+            i2, v2 = c2.results()
+            same = (len(v2), int(v2.view(np.uint64).sum() & 0xFFFFFFFFFFFFFFFF) if len(v2) else 0) == ref_sig
+            if rank == 0:
+                legs[name] = {"value": round(m_eff * m2["passes"] * steps / m2["dt"] / 1e9, 4), "unit": "GTEPS",
+                              "ms_per_step": round(m2["dt"] * 1e3 / steps, 3), "same_result_as_edge_partition": bool(same),
+                              "collective": wire_info(world, part, co, m2["stats"], n, m2, steps)}
+            c2.close()
+        if rank == 0:
+            out["detail"]["partitions"] = legs
+
+    # ---- the north-star graph as an extra leg (BASELINE configs[3], 1 GPU): driver-visible C4 numbers + parity
+    want_c4 = a.c4_leg == "on" or (a.c4_leg == "auto" and world == 1 and a.config == "C3" and not a.flags and not a.tune and not a.chunk)
+    if want_c4 and world == 1:
+        g.close()
+        del g
+        try:
+            c4 = c4_leg(a, torch, barrier, cores_used[0])
+        except Exception as e:  # the main line must survive a failing leg
+            c4 = {"error": str(e)[:400]}
+        out["detail"]["c4"] = c4
+    if rank == 0:
+        print(json.dumps(out), flush=True)
     if td is not None:
         td.barrier()
         td.destroy_process_group()
 
 
-def _pmc_traffic(config):
-    """HBM bytes per launch of the dominant kernel: NOT measured by this run - read from the newest
-    committed rocprofv3 PMC summary (profiles/current_<config>_pmc.json, tools/export_profile.py);
-    returns (bytes or None, source file or None)."""
+def wire_info(world, part, changed_only, stats, n, ms, steps):
+    n_pad = (n + 63) // 64 * 64
+    return {"ran": part + ("+changed-only" if changed_only else ""),
+            "received_bytes_per_gpu_per_run": int(stats["wire_bytes"]),
+            "edge_allreduce_bytes_per_gpu_per_pass": 2.0 * (world - 1) / world * n_pad * 64,
+            "dest_allgather_bytes_per_gpu_per_pass": (world - 1) / world * (n_pad * 64 + n_pad / 8),
+            "ms_collective_per_pass": round(ms["coll_ms"] / steps / max(ms["passes"], 1), 4)}
+
+
+def c4_leg(a, torch, barrier, cores):
+    """BASELINE.json configs[3] (100M-host / 2B-edge R-MAT scale 28) on one GPU, appended to the default line so that the
+    north-star graph is measured under the driver's clock: GTEPS (1 warm-up + 2 timed runs), whole-dense-pass and dominant-kernel
+    fractions, and parity (state checksum after the passes the CPU oracle finishes in its budget; final list with --verify)."""
+    from stract_amd import _lib, synth
+
+    t0 = time.perf_counter()
+    g, scale, label = synth.make_config("C4")
+    t_gen = time.perf_counter() - t0
+    n, m_eff = int(g.n), int(g.m)
+    ctx = _lib.Context()
+    t0 = time.perf_counter()
+    info = {"path": "hb_load_dense (bench-only export: pre-reduced CSR)"}
+    if a.input == "records":
+        try:
+            info = load_records(ctx, g)
+        except Exception as e:
+            ctx.close()
+            ctx = _lib.Context()
+            ctx.load_dense(g.ids, g.row_ptr, g.src)
+            info = {"path": "hb_load_dense (the record path FAILED: %s)" % (str(e)[:300],)}
+    else:
+        ctx.load_dense(g.ids, g.row_ptr, g.src)
+    info["s_load"] = round(time.perf_counter() - t0, 2)
+    steps = 2
+    ms = measure(ctx, steps, 1, barrier, None, torch)
+    stats = ms["stats"]
+    ids, vals = ctx.results()
+    avg = per_pass_avg(ms["pass_stats"], n, m_eff, int(stats["rows_with_in_edges"]), int(stats["work_rows"]), True)
+    roof = roofline_of(avg, stats, steps, n, m_eff, True, "C4")
+    cpu, parity = cpu_and_parity(a, g, ctx, None, 0, 1, ms["passes"], ids, vals, ms["pass_stats"][-1], cores=cores, faithful=False)
+    ctx.close()
+    keep = ("frac", "achieved", "frac_of_measured_copy_6.29TBs", "pass0", "dominant_kernel", "kernels", "whole_loop", "per_pass")
+    return {"workload": "C4 %s" % label, "n_hosts": n, "m_eff": m_eff, "passes_T": ms["passes"],
+            "value": round(m_eff * ms["passes"] * steps / ms["dt"] / 1e9, 4), "unit": "GTEPS", "steps": steps, "warmup": 1,
+            "ms_per_step": round(ms["dt"] * 1e3 / steps, 3), "parity_bit_exact": None if parity is None else parity["bit_exact"], "parity": parity,
+            "roofline": {k: roof[k] for k in keep if roof and k in roof}, "cpu_baseline": cpu, "input": info,
+            "s_generate": round(t_gen, 1), "device_bytes": int(stats["device_bytes"]), "results": int(len(vals))}
+
+
+def _pmc(config):
+    """PMC numbers per launch class: NOT measured by this run - read from the newest committed rocprofv3 --pmc summary of the same
+    command (profiles/current_<config>_pmc.json, written by tools/profile.sh + tools/export_profile.py, which splits the dispatches
+    of one kernel template by launch: level 1 / level 2 ...).  {} when there is none."""
     rel = os.path.join("profiles", "current_%s_pmc.json" % config)
     try:
         with open(os.path.join(ROOT, rel)) as f:
             d = json.load(f)
-        for k, v in d.items():
-            if "pass_kernel<false, false, false, false, 4>" in k:
-                return v.get("hbm_bytes_per_dispatch"), rel + " (committed rocprofv3 --pmc run of the same command)"
     except Exception:
-        pass
-    return None, None
+        return {}
+    out = {"_source": rel + " (committed rocprofv3 --pmc runs of `bench.py --config %s`, per launch class)" % config}
+    for k, v in d.items():
+        if not isinstance(v, dict):
+            continue
+        if k.startswith("hbk::pass_kernel<false, false, false, false, 4, false>") and k.endswith("#L1"):
+            out["hub_level1_dense"] = v
+        if k.startswith("hbk::pass_kernel<true, false, true, false, 2, false>"):
+            out["node_rows_dense"] = v
+    return out
 
 
 def _cpu_quota():
@@ -336,7 +529,7 @@ def _pick_threads(hbo, synth, ncpu, quota):
     return cores
 
 
-def cpu_and_parity(a, g, ctx, td, rank, world, gpu_passes, gpu_ids, gpu_vals, gpu_pass_stats):
+def cpu_and_parity(a, g, ctx, td, rank, world, gpu_passes, gpu_ids, gpu_vals, gpu_pass_stats, cores=None, faithful=True, cores_out=None):
     """Rank 0: oracle (dense OpenMP port of the reference arithmetic) on this box's host cores, on the
     same graph, for as many passes as fit in --cpu-seconds (all of them with --verify).  Parity: the final
     (NodeID, f64) list when the oracle converged, else a checksum of registers (+ Kahan state on one GPU)
@@ -351,7 +544,10 @@ def cpu_and_parity(a, g, ctx, td, rank, world, gpu_passes, gpu_ids, gpu_vals, gp
 
         ncpu = os.cpu_count() or 1
         quota = _cpu_quota()  # containers: the cgroup CPU quota can be far below the visible hardware threads
-        cores = _pick_threads(hbo, synth, ncpu, quota)
+        if cores is None:
+            cores = _pick_threads(hbo, synth, ncpu, quota)
+        if cores_out is not None:
+            cores_out[0] = cores
         o = hbo.Dense(g.id_low64(), g.row_ptr, g.src, threads=cores)
         t0 = time.perf_counter()
         has = True
@@ -382,12 +578,16 @@ def cpu_and_parity(a, g, ctx, td, rank, world, gpu_passes, gpu_ids, gpu_vals, gp
                       "oracle": "oracle/hb_oracle.c dense form (parity unpinned against the Rust reference, see DESIGN.md)"}
         # the structure-faithful single-thread form (what `stract centrality harmonic` does), C1 only
         try:
+            if not faithful:
+                raise LookupError
             c1 = synth.RmatGraph(synth.CONFIGS["C1"]["scale"], synth.CONFIGS["C1"]["m"])
             _, _, fst = hbo.faithful_run(c1.edges())
             cpu["cpu_faithful"] = {"value": round(fst["m_eff"] * fst["passes"] / fst["seconds_loop"] / 1e9, 6), "unit": "GTEPS",
                                    "cores": 1, "sample": "C1 (%d hosts / %d edges), all %d passes, %.2f s, single thread, "
                                    "ordered map + per-pass clone + re-dedup + bloom (hbo.faithful_run)"
                                    % (fst["n"], fst["m_eff"], fst["passes"], fst["seconds_loop"])}
+        except LookupError:
+            pass
         except Exception as e:  # pragma: no cover
             cpu["cpu_faithful"] = {"error": str(e)}
     # did the oracle stop early?  then compare state checksums after `done` passes

@@ -111,7 +111,9 @@ typedef struct hb_options {
     uint32_t tune[8];       /* tuning knobs, 0 = default:
                              *  [0] workgroups per CU of the pass launches: low byte = node rows (dense 64, bitmap 32),
                              *      second byte = hub chunks (dense 2, bitmap 4)
-                             *  [1] gather unroll 1|2|4 (hub chunks 4, node rows 2)
+                             *  [1] low byte: gather unroll 1|2|4 (hub chunks 4, node rows 2); bit 8: dense fused node rows with the
+                             *      old per-tile estimator/Kahan epilogue instead of the once-per-row one; bit 9: bitmap passes with
+                             *      the older per-16-sources loop instead of the batched frontier kernel (measurement switches)
                              *  [2] frontier mode when A_t < tune[2] % of the edges (50; > 100 = always)
                              *  [3] log2 of the hotness slice width in counters (16 = 4 MiB; 1 = no slices)
                              *  [4] min sources of a chunk at a slice cut (8)
@@ -149,6 +151,8 @@ typedef struct hb_stats {
     uint64_t rows_with_in_edges; /* nodes with >= 1 in-edge: V_t of a dense pass t >= 1      */
     uint64_t wire_bytes;    /* destination partition: counter + changed-bit bytes this rank received in
                                the collectives of the last run (what HB_FLAG_CHANGED_ONLY reduces)   */
+    uint64_t ingest_peak_bytes; /* high-water mark of the device memory the GPU ingest held (record chunks + work
+                                   arrays; 0 = host ingest / hb_load_dense)                            */
 } hb_stats;
 
 typedef struct hb_pass_stats {
@@ -164,7 +168,8 @@ typedef struct hb_pass_stats {
     float    ms_gpu;        /* GPU time of the pass (all its launches + collective)         */
     float    ms_main;       /* GPU time of the dominant launch (real rows)                  */
     float    ms_collective;
-    float    ms_level1;     /* GPU time of the level-1 hub-chunk launch (dense / frontier passes)   */
+    float    ms_level1;     /* GPU time of the level-1 hub-chunk launch (dense / frontier passes); sweep passes: of the
+                               seed collection + expansion launches (then ms_main = node rows, the rest = virtual levels) */
     uint32_t reserved;
 } hb_pass_stats;
 
@@ -193,9 +198,12 @@ int hb_load_edges(hb_ctx *ctx, const hb_u128 *node_ids, uint64_t n, const hb_edg
                   uint64_t m);
 /* Streamed variant for callers that cannot (or need not) hold all records: append any number of batches in stream
  * order, then finalize (node_ids as above).  Every batch is uploaded and unpacked on the device at once (2 x 16-byte
- * endpoint keys + 1 flag byte per record stay resident there); nothing is buffered on the host, so the caller's
- * peak memory is one batch.  With HB_FLAG_HOST_INGEST, or if the device runs out of memory mid-stream, the
- * records are buffered on the host instead (same result). */
+ * endpoint keys + 1 flag byte per record stay resident there, in chunks of 64 Mi records: no reallocation as the
+ * stream grows); nothing is buffered on the host, so the caller's peak memory is one batch.  Device memory: 33 B per
+ * record while the stream is held + 12 B per record at hb_finalize (+ 16 B per node), then 24 B per record for the
+ * stable sort once the chunks are gone (hb_stats.ingest_peak_bytes reports the high-water mark).  With
+ * HB_FLAG_HOST_INGEST, if the device runs out of memory mid-stream, or at 2^32 - 256 records (positions are 32-bit
+ * on the device), the records are buffered on the host instead (same result). */
 int hb_append_edges(hb_ctx *ctx, const hb_edge *edges, uint64_t m);
 int hb_finalize(hb_ctx *ctx, const hb_u128 *node_ids, uint64_t n);
 
@@ -312,6 +320,11 @@ int hb_debug_exchange(hb_ctx **ctxs, int count, int phase);
  * then (edge partition / HB_FLAG_UNFUSED) estimator/Kahan/changed detection, bookkeeping. */
 int hb_step_local(hb_ctx *ctx);
 int hb_step_finish(hb_ctx *ctx, int *has_changes);
+
+/* Test hook: lowers the limits of the device ingest so that its refusal (>= max_records -> host ingest), its
+ * out-of-memory spill (chunk memory beyond max_device_bytes counts as a failed allocation) and its multi-chunk
+ * paths (chunk_records per chunk) can be reached with small inputs.  0 = default for each. */
+int hb_debug_set_ingest_limits(hb_ctx *ctx, uint64_t max_records, uint64_t max_device_bytes, uint64_t chunk_records);
 
 /* ---- host-only test exports (no device needed) -------------------------------------------- */
 /* The reference ingest semantics alone (node set, first-occurrence de-duplication, flag

@@ -76,6 +76,7 @@ class HbStats(ctypes.Structure):
         ("direct_edges", ctypes.c_uint64),
         ("rows_with_in_edges", ctypes.c_uint64),
         ("wire_bytes", ctypes.c_uint64),
+        ("ingest_peak_bytes", ctypes.c_uint64),
     ]
 
     def as_dict(self):
@@ -116,6 +117,7 @@ _SIGNATURES = [
     ("hb_load_tail_edges", ctypes.c_int, [_P, _P, _U64]),
     ("hb_append_tail_edges", ctypes.c_int, [_P, _P, _U64]),
     ("hb_tail_segment_end", ctypes.c_int, [_P]),
+    ("hb_debug_set_ingest_limits", ctypes.c_int, [_P, _U64, _U64, _U64]),
     ("hb_debug_tail_index", ctypes.c_int, [_U64, _P, _P, _U64, _P, _U64, _P, _P, _U64, ctypes.POINTER(ctypes.c_uint64)]),
     ("hb_load_dense", ctypes.c_int, [_P, _P, _U64, _P, _P, _U64]),
     ("hb_run", ctypes.c_int, [_P, ctypes.POINTER(HbStats)]),
@@ -276,6 +278,10 @@ class Context:
     def append_tail_edges(self, records):
         records = np.ascontiguousarray(records, dtype=EDGE)
         self._check(self.lib.hb_append_tail_edges(self.h, _ptr(records) if len(records) else None, len(records)))
+
+    def set_ingest_limits(self, max_records=0, max_device_bytes=0, chunk_records=0):
+        """Test hook (hb_debug_set_ingest_limits): reach the device ingest's refusal / spill / multi-chunk paths with small inputs."""
+        self._check(self.lib.hb_debug_set_ingest_limits(self.h, max_records, max_device_bytes, chunk_records))
 
     def tail_segment_end(self):
         """The tail records appended since the last call were one whole segment of the store (doc order)."""

@@ -42,9 +42,8 @@ struct hb_ctx {
     std::vector<hb_edge> pending;  // hb_append_edges, host-ingest mode only
     // hb_append_edges, default: records are unpacked on the device as they arrive (2 x 16-byte endpoint keys + 1
     // flag byte each); nothing is buffered on the host
-    void *d_app_end = nullptr;
-    uint8_t *d_app_bad = nullptr;
-    uint64_t app_count = 0, app_cap = 0;
+    IngestStream app;
+    uint64_t lim_records = 0xFFFFFF00ull, lim_bytes = 0, lim_chunk = 0; // hb_debug_set_ingest_limits
     DenseGraph g;                  // ids kept; row_ptr/src kept only for hb_debug_copy_graph
     Plan plan;
     bool loaded = false, begun = false, finished = false;
@@ -532,14 +531,29 @@ int need_host_dev_of(hb_ctx *c)
 
 // ---- kernel dispatch ----------------------------------------------------------------------
 template <bool REAL, bool FRONTIER, bool FUSED>
-void launch_pass_u(hb_ctx *c, const hbk::PassParams &pp, bool stats, int unroll, dim3 grid, bool init = false)
+void launch_pass_u(hb_ctx *c, const hbk::PassParams &pp, bool stats, int unroll, dim3 grid, bool init = false, bool epi4 = false)
 {
     hipStream_t s = c->stream;
     if constexpr (!FRONTIER) {
         if (init && !stats) { // pass 0: the sources' initial registers stream in with the edge list (hb_kernels.hip.h)
+            if constexpr (REAL && FUSED) {
+                if (epi4) {
+                    if (unroll == 2) hipLaunchKernelGGL((hbk::pass_kernel<REAL, false, FUSED, false, 2, true, true>), grid, dim3(256), 0, s, pp);
+                    else hipLaunchKernelGGL((hbk::pass_kernel<REAL, false, FUSED, false, 4, true, true>), grid, dim3(256), 0, s, pp);
+                    return;
+                }
+            }
             if (unroll == 2) hipLaunchKernelGGL((hbk::pass_kernel<REAL, false, FUSED, false, 2, true>), grid, dim3(256), 0, s, pp);
             else hipLaunchKernelGGL((hbk::pass_kernel<REAL, false, FUSED, false, 4, true>), grid, dim3(256), 0, s, pp);
             return;
+        }
+        if constexpr (REAL && FUSED) {
+            if (epi4 && !stats) { // once-per-row estimator / Kahan epilogue (default for the dense fused node rows)
+                if (unroll == 1) hipLaunchKernelGGL((hbk::pass_kernel<REAL, false, FUSED, false, 1, false, true>), grid, dim3(256), 0, s, pp);
+                else if (unroll == 2) hipLaunchKernelGGL((hbk::pass_kernel<REAL, false, FUSED, false, 2, false, true>), grid, dim3(256), 0, s, pp);
+                else hipLaunchKernelGGL((hbk::pass_kernel<REAL, false, FUSED, false, 4, false, true>), grid, dim3(256), 0, s, pp);
+                return;
+            }
         }
     }
 #define HB_LAUNCH(ST, UN) hipLaunchKernelGGL((hbk::pass_kernel<REAL, FRONTIER, FUSED, ST, UN>), grid, dim3(256), 0, s, pp)
@@ -558,7 +572,8 @@ void launch_pass_u(hb_ctx *c, const hbk::PassParams &pp, bool stats, int unroll,
 void launch_pass(hb_ctx *c, const hbk::PassParams &pp, bool real, bool frontier, bool fused)
 {
     const bool stats = (c->opt.flags & HB_FLAG_PASS_STATS) != 0;
-    int unroll = (int)c->opt.tune[1];
+    int unroll = (int)(c->opt.tune[1] & 0xFFu);
+    const bool epi4 = !(c->opt.tune[1] & 0x100u); // tune[1] bit 8: the old per-tile epilogue (measurement switch)
     // default: 16 gathers in flight per quad for the hub chunks (pure gather loops); 8 for the node rows,
     // whose fused estimator/Kahan epilogue needs the registers (unroll 4 drops them to 4 waves/SIMD)
     if (unroll != 1 && unroll != 2 && unroll != 4) unroll = real ? 2 : 4;
@@ -580,12 +595,27 @@ void launch_pass(hb_ctx *c, const hbk::PassParams &pp, bool real, bool frontier,
         if (pp.xcd_map) blocks = std::max<uint64_t>((blocks + 7) / 8 * 8, 8);
     }
     dim3 grid((unsigned)blocks);
+    if (frontier && !(c->opt.tune[1] & 0x200u)) {
+        // the bitmap pass: all indices / all bit words / needed gathers of a row as three batched round trips
+        // (hb_kernels.hip.h frontier_kernel; tune[1] bit 9 = the older per-16-sources loop of pass_kernel, measurement switch)
+        hipStream_t st = c->stream;
+#define HB_FRONT(R, F) \
+    do { \
+        if (stats) hipLaunchKernelGGL((hbk::frontier_kernel<R, F, true, (R ? 4 : 16)>), grid, dim3(256), 0, st, pp); \
+        else hipLaunchKernelGGL((hbk::frontier_kernel<R, F, false, (R ? 4 : 16)>), grid, dim3(256), 0, st, pp); \
+    } while (0)
+        if (real && fused) HB_FRONT(true, true);
+        else if (real) HB_FRONT(true, false);
+        else HB_FRONT(false, false);
+#undef HB_FRONT
+        return;
+    }
     if (real) {
         if (frontier) {
             if (fused) launch_pass_u<true, true, true>(c, pp, stats, unroll, grid);
             else launch_pass_u<true, true, false>(c, pp, stats, unroll, grid);
         } else {
-            if (fused) launch_pass_u<true, false, true>(c, pp, stats, unroll, grid, init);
+            if (fused) launch_pass_u<true, false, true>(c, pp, stats, unroll, grid, init, epi4);
             else launch_pass_u<true, false, false>(c, pp, stats, unroll, grid, init);
         }
     } else {
@@ -840,6 +870,7 @@ int step_local(hb_ctx *c)
         hipLaunchKernelGGL(hbk::sweep_collect_kernel, dim3(sblocks), dim3(256), 0, c->stream, sp);
         hipLaunchKernelGGL(hbk::sweep_expand_kernel, dim3(wblocks), dim3(256), 0, c->stream, sp);
         hipLaunchKernelGGL(hbk::sweep_expand_heavy_kernel, dim3(wblocks), dim3(256), 0, c->stream, sp);
+        HB_HIP(hipEventRecord(c->ev[5], c->stream)); // sweep passes: ms_level1 = seed collection + expansion
         auto sweep_blocks = [&](uint64_t rows) { // a wave-iteration covers 16 groups of 128 rows
             const uint64_t waves = (rows + 2047) / 2048;
             return (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((waves + 3) / 4, (uint64_t)c->num_cu * 4));
@@ -970,7 +1001,7 @@ int step_finish(hb_ctx *c, int *has_changes)
     ps.ms_gpu = ms_all;
     ps.ms_main = ms_main;
     ps.ms_collective = c->comm ? ms_coll : 0.f;
-    if (c->cur_mode < 2 && p.level_begin.size() > 1) {
+    if ((c->cur_mode < 2 && p.level_begin.size() > 1) || c->cur_mode == 2) {
         float ms_l1 = 0.f;
         HB_HIP(hipEventElapsedTime(&ms_l1, c->ev[0], c->ev[5]));
         ps.ms_level1 = ms_l1;
@@ -1011,25 +1042,28 @@ int guarded(hb_ctx *c, F &&f)
 // ran out of memory in the middle of a stream
 int spill_appended_to_host(hb_ctx *c)
 {
-    const uint64_t k = c->app_count;
+    const uint64_t k = c->app.count;
     if (k) {
-        std::vector<hb_u128> keys(2 * k);
-        std::vector<uint8_t> bad(k);
-        HB_HIP(hipMemcpyAsync(keys.data(), c->d_app_end, k * 32, hipMemcpyDeviceToHost, c->stream));
-        HB_HIP(hipMemcpyAsync(bad.data(), c->d_app_bad, k, hipMemcpyDeviceToHost, c->stream));
-        HB_HIP(hipStreamSynchronize(c->stream));
+        std::vector<hb_u128> keys;
+        std::vector<uint8_t> bad;
         c->pending.resize(k);
-        for (uint64_t i = 0; i < k; i++) {
-            c->pending[i].from = keys[2 * i];
-            c->pending[i].to = keys[2 * i + 1];
-            c->pending[i].rel_flags = bad[i] ? HB_SKIPPED_REL_MASK : 0;
+        uint64_t base = 0;
+        for (const IngestChunk &ch : c->app.chunks) {
+            if (!ch.count) continue;
+            keys.resize(2 * ch.count);
+            bad.resize(ch.count);
+            HB_HIP(hipMemcpyAsync(keys.data(), ch.d_end, ch.count * 32, hipMemcpyDeviceToHost, c->stream));
+            HB_HIP(hipMemcpyAsync(bad.data(), ch.d_bad, ch.count, hipMemcpyDeviceToHost, c->stream));
+            HB_HIP(hipStreamSynchronize(c->stream));
+            for (uint64_t i = 0; i < ch.count; i++) {
+                c->pending[base + i].from = keys[2 * i];
+                c->pending[base + i].to = keys[2 * i + 1];
+                c->pending[base + i].rel_flags = bad[i] ? HB_SKIPPED_REL_MASK : 0;
+            }
+            base += ch.count;
         }
     }
-    if (c->d_app_end) (void)hipFree(c->d_app_end);
-    if (c->d_app_bad) (void)hipFree(c->d_app_bad);
-    c->d_app_end = nullptr;
-    c->d_app_bad = nullptr;
-    c->app_count = c->app_cap = 0;
+    c->app.free_all();
     return HB_OK;
 }
 
@@ -1139,8 +1173,7 @@ void hb_destroy(hb_ctx *ctx)
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     if (ctx->comm) (void)ncclCommDestroy(ctx->comm);
-    if (ctx->d_app_end) (void)hipFree(ctx->d_app_end);
-    if (ctx->d_app_bad) (void)hipFree(ctx->d_app_bad);
+    ctx->app.free_all();
     free_graph_buffers(ctx);
     if (ctx->h_counters) (void)hipHostFree(ctx->h_counters);
     for (int i = 0; i < 6; i++)
@@ -1179,18 +1212,20 @@ int hb_load_edges(hb_ctx *c, const hb_u128 *node_ids, uint64_t n, const hb_edge 
         // node/edge-set reduction: on the GPU (hb_ingest.hip) unless the host path is forced; identical output
         // The device pipeline keeps ~100 B per record resident at its peak (endpoint keys, sort double buffers):
         // when that cannot fit, or an allocation fails anyway, the host path produces the same graph.
-        bool on_host = (c->opt.flags & HB_FLAG_HOST_INGEST) != 0;
+        bool on_host = (c->opt.flags & HB_FLAG_HOST_INGEST) != 0 || m >= c->lim_records;
         if (!on_host) {
             size_t free_b = 0, total_b = 0;
-            const double need = 100.0 * (double)m + 48.0 * (double)((node_ids && n) ? n : 0) + 512e6;
+            const double need = 50.0 * (double)m + 48.0 * (double)((node_ids && n) ? n : 0) + 512e6;
             if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && need > (double)free_b) on_host = true;
         }
         DeviceCsr csr;
         const bool keep_on_device = !on_host && device_plan(c);
+        uint64_t peak = 0;
         std::string e = on_host ? ingest_edges(node_ids, n, edges, m, &c->g)
-                                : gpu_ingest_edges((void *)c->stream, node_ids, n, edges, m, &c->g, keep_on_device ? &csr : nullptr);
+                                : gpu_ingest_edges((void *)c->stream, node_ids, n, edges, m, &c->g, keep_on_device ? &csr : nullptr, &peak);
         if (!on_host && !e.empty() && (e.find("out of memory") != std::string::npos || e.find("OutOfMemory") != std::string::npos)) {
             (void)hipGetLastError(); // clear the sticky allocation error
+            peak = 0;
             e = ingest_edges(node_ids, n, edges, m, &c->g);
         }
         if (!e.empty())
@@ -1204,6 +1239,7 @@ int hb_load_edges(hb_ctx *c, const hb_u128 *node_ids, uint64_t n, const hb_edge 
         if (csr.d_row_ptr) (void)hipFree(csr.d_row_ptr); // only if plan_and_upload bailed out before taking them
         if (csr.d_src) (void)hipFree(csr.d_src);
         c->stats.ms_ingest = ing;
+        c->stats.ingest_peak_bytes = peak;
         return rc;
     });
 }
@@ -1217,39 +1253,15 @@ int hb_append_edges(hb_ctx *c, const hb_edge *edges, uint64_t m)
         if (rc) return rc;
         const bool on_host = (c->opt.flags & HB_FLAG_HOST_INGEST) != 0 || !c->pending.empty();
         if (!on_host) {
-            // grow the device arrays (amortised doubling), then unpack this batch behind what is already there
-            const uint64_t need = c->app_count + m;
-            hipError_t e = hipSuccess;
-            if (need > c->app_cap) {
-                const uint64_t cap = std::max<uint64_t>(need, std::max<uint64_t>(2 * c->app_cap, 1ull << 20));
-                void *n_end = nullptr;
-                uint8_t *n_bad = nullptr;
-                e = hipMalloc(&n_end, cap * 32);
-                if (e == hipSuccess) e = hipMalloc((void **)&n_bad, cap);
-                if (e == hipSuccess && c->app_count) {
-                    e = hipMemcpyAsync(n_end, c->d_app_end, c->app_count * 32, hipMemcpyDeviceToDevice, c->stream);
-                    if (e == hipSuccess) e = hipMemcpyAsync(n_bad, c->d_app_bad, c->app_count, hipMemcpyDeviceToDevice, c->stream);
-                    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-                }
-                if (e == hipSuccess) {
-                    if (c->d_app_end) (void)hipFree(c->d_app_end);
-                    if (c->d_app_bad) (void)hipFree(c->d_app_bad);
-                    c->d_app_end = n_end;
-                    c->d_app_bad = n_bad;
-                    c->app_cap = cap;
-                } else {
-                    if (n_end) (void)hipFree(n_end);
-                    if (n_bad) (void)hipFree(n_bad);
-                    (void)hipGetLastError();
-                }
-            }
-            if (e == hipSuccess) {
-                const std::string err = gpu_ingest_unpack((void *)c->stream, edges, m, c->app_count, c->d_app_end, c->d_app_bad);
-                if (!err.empty()) return fail(c, HB_ERR_HIP, err);
-                c->app_count += m;
-                return HB_OK;
-            }
-            // the device cannot hold the stream: bring back what is there and continue on the host
+            // unpack this batch behind what is already on the device (chunked: no reallocation, 33 bytes per record)
+            c->app.max_records = c->lim_records;
+            c->app.max_bytes = c->lim_bytes;
+            c->app.chunk_records = c->lim_chunk;
+            const std::string err = gpu_ingest_append((void *)c->stream, &c->app, edges, m);
+            if (err.empty()) return HB_OK;
+            if (err.find("out of memory") == std::string::npos && err.find("too many records") == std::string::npos) return fail(c, HB_ERR_HIP, err);
+            // the device cannot hold the stream (memory, or the 2^32-record limit of the device reduction): bring back
+            // what is there and continue on the host
             rc = spill_appended_to_host(c);
             if (rc) return rc;
         }
@@ -1264,22 +1276,20 @@ int hb_finalize(hb_ctx *c, const hb_u128 *node_ids, uint64_t n)
         if (!c) return HB_ERR_INVALID;
         int rc = set_device(c);
         if (rc) return rc;
-        if (!c->d_app_end) { // host mode (or nothing appended)
+        if (c->app.chunks.empty()) { // host mode (or nothing appended)
+            const uint64_t keep_lim = c->lim_records;
+            if (!c->pending.empty()) c->lim_records = 0; // the stream was spilled: it stays on the host path
             rc = hb_load_edges(c, node_ids, n, c->pending.data(), c->pending.size());
+            c->lim_records = keep_lim;
             std::vector<hb_edge>().swap(c->pending);
             return rc;
         }
         c->stats = hb_stats{};
         const double t0 = now_ms();
-        void *d_end = c->d_app_end;
-        uint8_t *d_bad = c->d_app_bad;
-        const uint64_t m = c->app_count;
-        c->d_app_end = nullptr;
-        c->d_app_bad = nullptr;
-        c->app_count = c->app_cap = 0;
         DeviceCsr csr;
         const bool keep_on_device = device_plan(c);
-        const std::string e = gpu_ingest_reduce((void *)c->stream, node_ids, n, d_end, d_bad, m, &c->g, keep_on_device ? &csr : nullptr);
+        uint64_t peak = 0;
+        const std::string e = gpu_ingest_reduce((void *)c->stream, node_ids, n, &c->app, &c->g, keep_on_device ? &csr : nullptr, &peak);
         if (!e.empty())
             return fail(c, e.find("memory") != std::string::npos ? HB_ERR_NOMEM : (e.find("hip") != std::string::npos ? HB_ERR_HIP : HB_ERR_LIMIT), e);
         if (dest_mode(c)) keep_owned_rows(&c->g, (uint64_t)std::max(c->opt.world_size, 1), (uint64_t)c->opt.rank);
@@ -1290,8 +1300,18 @@ int hb_finalize(hb_ctx *c, const hb_u128 *node_ids, uint64_t n)
         if (csr.d_row_ptr) (void)hipFree(csr.d_row_ptr);
         if (csr.d_src) (void)hipFree(csr.d_src);
         c->stats.ms_ingest = ing;
+        c->stats.ingest_peak_bytes = peak;
         return rc;
     });
+}
+
+int hb_debug_set_ingest_limits(hb_ctx *c, uint64_t max_records, uint64_t max_device_bytes, uint64_t chunk_records)
+{
+    if (!c) return HB_ERR_INVALID;
+    c->lim_records = max_records ? std::min<uint64_t>(max_records, 0xFFFFFF00ull) : 0xFFFFFF00ull;
+    c->lim_bytes = max_device_bytes;
+    c->lim_chunk = chunk_records;
+    return HB_OK;
 }
 
 int hb_append_tail_edges(hb_ctx *c, const hb_edge *records, uint64_t count)

@@ -172,13 +172,32 @@ std::string build_tail_csr(std::vector<uint64_t> *keys, uint64_t n_pad, std::vec
 // keep != NULL: the CSR stays on the device (returned in *keep, owned by the caller) and out->row_ptr / out->src
 // are only filled for small graphs (m_eff <= kKeepHostGraph, for hb_debug_copy_graph)
 std::string gpu_ingest_edges(void *stream, const hb_u128 *node_ids, uint64_t n, const hb_edge *edges, uint64_t m,
-                             DenseGraph *out, struct DeviceCsr *keep = nullptr);
+                             DenseGraph *out, struct DeviceCsr *keep = nullptr, uint64_t *peak_bytes = nullptr);
 constexpr uint64_t kKeepHostGraph = 1ull << 26;
-// the two halves of gpu_ingest_edges, for streamed input (hb_append_edges): unpack slabs of records into device
-// arrays of 2 x 16-byte endpoint keys + 1 flag byte per record as they arrive, reduce once at hb_finalize
-std::string gpu_ingest_unpack(void *stream, const hb_edge *edges, uint64_t m, uint64_t base, void *d_end, uint8_t *d_bad);
-std::string gpu_ingest_reduce(void *stream, const hb_u128 *node_ids, uint64_t n, void *d_end, uint8_t *d_bad, uint64_t m, DenseGraph *out,
-                              struct DeviceCsr *keep);
+// the two halves of gpu_ingest_edges, for streamed input (hb_append_edges): batches of records are unpacked on the
+// device as they arrive into chunks of 2 x 16-byte endpoint keys + 1 flag byte per record; one reduction at hb_finalize
+struct IngestChunk {
+    void *d_end = nullptr;   // 2 * cap endpoint keys (from, to), stream order
+    uint8_t *d_bad = nullptr; // cap "rel_flags & SKIPPED_REL" bytes
+    uint64_t count = 0, cap = 0;
+};
+struct IngestStream {
+    std::vector<IngestChunk> chunks;
+    uint64_t count = 0;         // records held
+    uint64_t bytes = 0;         // device bytes of the chunks
+    void *d_slab[2] = {nullptr, nullptr}; // H2D staging
+    uint64_t slab_cap = 0;
+    // limits (0 = none / default); the test hooks of hb_debug_set_ingest_limits lower them to reach the refusal and
+    // spill paths at small sizes
+    uint64_t max_records = 0;   // refuse to hold more records than this ("too many records")
+    uint64_t max_bytes = 0;     // treat chunk memory beyond this as a failed allocation ("out of memory")
+    uint64_t chunk_records = 0; // records per chunk (default 2^26)
+    void free_all();
+};
+std::string gpu_ingest_append(void *stream, IngestStream *st, const hb_edge *edges, uint64_t m);
+// consumes *st (freed on every path); *peak_bytes = high-water mark of the device memory the ingest held
+std::string gpu_ingest_reduce(void *stream, const hb_u128 *node_ids, uint64_t n, IngestStream *st, DenseGraph *out, struct DeviceCsr *keep,
+                              uint64_t *peak_bytes = nullptr);
 std::string check_dense(const hb_u128 *sorted_ids, uint64_t n, const uint64_t *row_ptr,
                         const uint32_t *src, uint64_t m);
 // out_degree[sid] over the local edges.

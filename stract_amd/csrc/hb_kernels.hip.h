@@ -162,61 +162,77 @@ __device__ __forceinline__ double pow2_neg(uint32_t r) // ONE_OVER_POWER_OF_TWO[
     return __hiloint2double((int)((1023u - r) << 20), 0);
 }
 
-// All 4 lanes of the quad call this with their uint4; all get the same result.
-// raw/bias/lc: tables (LDS or global).
-__device__ __forceinline__ uint64_t hll_size_quad(const uint4 &v, const double *raw, const double *bias,
-                                                  const uint8_t *lc)
+// HyperLogLog<64>::size() in two halves, so that the f64 half can run once per ROW instead of once per lane of the
+// row's quad (pass_kernel collects the integer halves of four tiles and evaluates 64 distinct rows per wave).
+//
+// First half, all 4 lanes of the quad call it with their uint4 and all get the same result: sum = sum of 2^-r over the
+// 64 registers (the left fold of hyperloglog.rs:4488-4492 is exact and order-independent in f64 when every register
+// is <= 47: all partial sums are multiples of 2^-47 below 2^7), zeros = number of zero registers, big = some register
+// is > 47 (then the fold must be replayed in register order: hll_fold_quad).
+__device__ __forceinline__ void hll_sum_quad(const uint4 &v, double &sum_out, uint32_t &zeros_out, uint32_t &big_out)
 {
     const uint32_t w[4] = {v.x, v.y, v.z, v.w};
-    // Fast path: every register <= 47  =>  all partial sums of the left fold
-    // (hyperloglog.rs:4488-4492) are multiples of 2^-47 below 2^7, hence exact in f64 and
-    // order-independent: sum them as integers scaled by 2^47.
-    uint64_t s = 0;
-    uint32_t zeros = 0, big = 0;
+    // The 16 terms 2^-r of this lane are added as doubles built from their exponent field (hi word = (1023 - r) << 20):
+    // with every register <= 47 all partial sums are multiples of 2^-47 below 2^7, so these additions are exact in any
+    // order - the same value as the reference's left fold; four v_add_f64 per word instead of 64-bit integer shifts / adds.
+    double acc = 0.0;
+    uint32_t zeros = 0, mx = 0;
 #pragma unroll
     for (int k = 0; k < 4; k++) {
 #pragma unroll
         for (int b = 0; b < 4; b++) {
-            uint32_t r = (w[k] >> (8 * b)) & 0xFFu;
-            zeros += (r == 0);
-            big |= (r > 47u);
-            s += (r > 47u) ? 0ull : (1ull << (47u - r));
+            const uint32_t r = (w[k] >> (8 * b)) & 0xFFu;
+            acc += __hiloint2double((int)((1023u << 20) - (r << 20)), 0); // r <= 255: the exponent field stays positive
         }
+        // zero bytes of the word: bit 7 of every byte of z marks a zero byte
+        const uint32_t z = ~(((w[k] & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | w[k] | 0x7F7F7F7Fu);
+        zeros += __popc(z);
+        // largest register of the word, as max over the 16-bit lanes' high bytes and low bytes
+        mx = pkmax(mx, pkmax(w[k] & 0x00FF00FFu, (w[k] >> 8) & 0x00FF00FFu));
     }
-    // quad reduction (xor 1, xor 2)
+    uint32_t big = ((mx & 0xFFFFu) > 47u || (mx >> 16) > 47u) ? 1u : 0u;
+    // quad reduction (xor 1, xor 2); the f64 sums stay exact for the same reason
     {
-        uint32_t lo = (uint32_t)s, hi = (uint32_t)(s >> 32);
-        uint64_t o = ((uint64_t)quad_perm<0xB1>(hi) << 32) | quad_perm<0xB1>(lo);
-        s += o;
+        uint32_t lo = (uint32_t)__double2loint(acc), hi = (uint32_t)__double2hiint(acc);
+        acc += __hiloint2double((int)quad_perm<0xB1>(hi), (int)quad_perm<0xB1>(lo));
         zeros += quad_perm<0xB1>(zeros);
         big |= quad_perm<0xB1>(big);
-        lo = (uint32_t)s; hi = (uint32_t)(s >> 32);
-        o = ((uint64_t)quad_perm<0x4E>(hi) << 32) | quad_perm<0x4E>(lo);
-        s += o;
+        lo = (uint32_t)__double2loint(acc); hi = (uint32_t)__double2hiint(acc);
+        acc += __hiloint2double((int)quad_perm<0x4E>(hi), (int)quad_perm<0x4E>(lo));
         zeros += quad_perm<0x4E>(zeros);
         big |= quad_perm<0x4E>(big);
     }
-    double sum;
-    if (big == 0) {
-        sum = (double)s * 0x1p-47; // s <= 2^53: exact
-    } else {
-        // Rare (a register > 47 needs a hash with > 46 leading zeros): replay the
-        // reference's sequential f64 fold over all 64 registers in index order.
-        uint32_t all[16];
+    sum_out = acc; // when big != 0 the value is unused - the fold is replayed in register order
+    zeros_out = zeros;
+    big_out = big;
+}
+
+// The rare case (a register > 47 needs a hash with > 46 leading zeros): the reference's sequential f64 fold over all
+// 64 registers in index order; all 4 lanes of the quad call it.
+__device__ __forceinline__ double hll_fold_quad(const uint4 &v)
+{
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+    uint32_t all[16];
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            all[0 + k] = quad_bcast<0>(w[k]);
-            all[4 + k] = quad_bcast<1>(w[k]);
-            all[8 + k] = quad_bcast<2>(w[k]);
-            all[12 + k] = quad_bcast<3>(w[k]);
-        }
-        sum = 0.0;
-#pragma unroll
-        for (int k = 0; k < 16; k++) {
-#pragma unroll
-            for (int b = 0; b < 4; b++) sum += pow2_neg((all[k] >> (8 * b)) & 0xFFu);
-        }
+    for (int k = 0; k < 4; k++) {
+        all[0 + k] = quad_bcast<0>(w[k]);
+        all[4 + k] = quad_bcast<1>(w[k]);
+        all[8 + k] = quad_bcast<2>(w[k]);
+        all[12 + k] = quad_bcast<3>(w[k]);
     }
+    double sum = 0.0;
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+#pragma unroll
+        for (int b = 0; b < 4; b++) sum += pow2_neg((all[k] >> (8 * b)) & 0xFFu);
+    }
+    return sum;
+}
+
+// f64 half (hyperloglog.rs:4494-4515) from sum = sum_i 2^-reg[i] and the number of zero registers; any lane, any row.
+// raw/bias/lc: tables (LDS or global).
+__device__ __forceinline__ uint64_t hll_size_from(double sum, uint32_t zeros, const double *raw, const double *bias, const uint8_t *lc)
+{
     const double z = 1.0 / sum;                 // :4494
     const double e = (0.709 * 4096.0) * z;      // :4496  am() * m.powi(2) * z
     double e_star = e;
@@ -225,6 +241,17 @@ __device__ __forceinline__ uint64_t hll_size_quad(const uint4 &v, const double *
     uint32_t l = lc[zeros]; // zeros in 0..64
     if (zeros != 0 && l != 0xFFu) return (uint64_t)l;
     return f64_as_usize(e_star);
+}
+
+// All 4 lanes of the quad call this with their uint4; all get the same result.
+__device__ __forceinline__ uint64_t hll_size_quad(const uint4 &v, const double *raw, const double *bias,
+                                                  const uint8_t *lc)
+{
+    double sum;
+    uint32_t zeros, big;
+    hll_sum_quad(v, sum, zeros, big);
+    if (big) sum = hll_fold_quad(v); // quad-uniform branch
+    return hll_size_from(sum, zeros, raw, bias, lc);
 }
 
 // update_centralities for one node (harmonic.rs:159-176) + KahanSum::add_assign.
@@ -258,7 +285,10 @@ __device__ __forceinline__ bool kahan_update(double &sum, double &err, uint64_t 
 //           set (harmonic.rs:60-62) - so instead of gathering 64 bytes at random the row streams 2 bytes per edge
 //           (src_jp, written once at load time) and rebuilds the block in registers; virtual sources are gathered
 //           as always.  Same maxima, same bits.
-template <bool REAL, bool FRONTIER, bool FUSED, bool STATS, int UNROLL, bool INIT = false>
+// EPI4      dense fused node rows only: the estimator's f64 half and the Kahan update are deferred until four tiles
+//           (64 rows) are merged and then run ONCE PER ROW, lane (g, q) taking row g of the q-th pending tile, instead
+//           of four times redundantly per quad; same arithmetic per row, same bits.
+template <bool REAL, bool FRONTIER, bool FUSED, bool STATS, int UNROLL, bool INIT = false, bool EPI4 = false>
 __global__ __launch_bounds__(256) void pass_kernel(const PassParams p)
 {
     __shared__ double s_raw[FUSED ? kTableLen : 1];
@@ -294,6 +324,39 @@ __global__ __launch_bounds__(256) void pass_kernel(const PassParams p)
     // (row_ptr -> index -> gather -> self -> size/ksum/kerr) shrinks to (index -> gather); node rows have ~5
     // sources each, so that chain, not bandwidth, bounded the node-row kernel.
     constexpr bool kDenseReal = REAL && !FRONTIER;
+    constexpr bool kEpi4 = EPI4 && kDenseReal && FUSED;
+    // deferred epilogue (kEpi4): per wave the first row / Kahan-dirty word of the pending tiles, per lane ITS pending row
+    __shared__ uint64_t s_prow16[kEpi4 ? 4 : 1][4];
+    __shared__ uint32_t s_pkd16[kEpi4 ? 4 : 1][4];
+    uint64_t p_row = 0, p_szfull = 0, p_sz = 0;
+    double p_sum = 0.0, p_ks = 0.0, p_ke = 0.0;
+    uint32_t p_zeros = 0, p_flags = 0; // 1 = row exists, 2 = changed, 4 = Kahan-dirty, 8 = a register > 47 (p_szfull holds size())
+    int npend = 0;                     // pending tiles of this wave, 0..3
+    auto flush_pending = [&]() {
+        bool err_nz = false;
+        if (q < npend && (p_flags & 1u) && (p_flags & 6u)) {
+            const uint64_t sz_old = p_sz;
+            uint64_t sz_new = sz_old;
+            if (p_flags & 2u) sz_new = (p_flags & 8u) ? p_szfull : hll_size_from(p_sum, p_zeros, s_raw, s_bias, s_lc);
+            double ks = p_ks, ke = p_ke;
+            err_nz = kahan_update(ks, ke, sz_new, sz_old, p.t_plus_1); // still moving -> visit again
+            if (err_nz) {
+                p.ksum[p_row] = ks;
+                p.kerr[p_row] = ke;
+            }
+            if (p_flags & 2u) p.size[p_row] = sz_new;
+        }
+        const uint64_t bal = __ballot(err_nz); // bit 4g + k = row g of pending tile k
+        if (lane == 0) {
+            for (int k = 0; k < npend; k++) {
+                const uint32_t nk16 = pack16(bal & (0x1111111111111111ull << k));
+                const uint64_t r16 = s_prow16[kEpi4 ? wave : 0][k];
+                const uint32_t kd16 = s_pkd16[kEpi4 ? wave : 0][k];
+                if (nk16 | kd16) ((uint16_t *)p.kdirty)[r16 >> 4] = (uint16_t)nk16;
+            }
+        }
+        npend = 0;
+    };
     uint64_t nbeg = 0, nend = 0;
     uint32_t nod = 0;
     uint4 nself = make_uint4(0, 0, 0, 0);
@@ -329,10 +392,18 @@ __global__ __launch_bounds__(256) void pass_kernel(const PassParams p)
         uint64_t pre_sz = 0;
         double pre_ks = 0.0, pre_ke = 0.0;
         if (kDenseReal && FUSED && valid) {
-            pre_sz = ld_stream(&p.size[row]);
-            if (q == 0) {
-                pre_ks = ld_stream(&p.ksum[row]);
-                pre_ke = ld_stream(&p.kerr[row]);
+            if (kEpi4) {
+                if (q == npend) { // this lane owns the row's deferred epilogue
+                    pre_sz = ld_stream(&p.size[row]);
+                    pre_ks = ld_stream(&p.ksum[row]);
+                    pre_ke = ld_stream(&p.kerr[row]);
+                }
+            } else {
+                pre_sz = ld_stream(&p.size[row]);
+                if (q == 0) {
+                    pre_ks = ld_stream(&p.ksum[row]);
+                    pre_ke = ld_stream(&p.kerr[row]);
+                }
             }
         }
         const uint4 *selfp = REAL ? (p.rd + row * 4 + q) : (p.part + (row - p.n_pad) * 4 + q);
@@ -465,7 +536,29 @@ __global__ __launch_bounds__(256) void pass_kernel(const PassParams p)
             cnt_changed += __popc(ch16);
             if (changed && q == 0) cnt_out += od;
         }
-        if (REAL && FUSED) {
+        if (kEpi4) {
+            double rsum;
+            uint32_t zeros, big;
+            hll_sum_quad(accv, rsum, zeros, big);
+            uint64_t szfull = 0;
+            if (big) szfull = hll_size_from(hll_fold_quad(accv), zeros, s_raw, s_bias, s_lc); // quad-uniform branch (rare)
+            if (q == npend) {
+                p_row = row;
+                p_sum = rsum;
+                p_zeros = zeros;
+                p_szfull = szfull;
+                p_sz = pre_sz;
+                p_ks = pre_ks;
+                p_ke = pre_ke;
+                p_flags = (need ? 1u : 0u) | (changed ? 2u : 0u) | (kd ? 4u : 0u) | (big ? 8u : 0u);
+            }
+            if (lane == 0) {
+                s_prow16[kEpi4 ? wave : 0][npend] = row16;
+                s_pkd16[kEpi4 ? wave : 0][npend] = row16 < row_hi ? kd16 : 0u;
+            }
+            if (++npend == 4) flush_pending();
+        }
+        if (REAL && FUSED && !kEpi4) {
             bool err_nz = false;
             if (need && (changed || kd)) {
                 const uint64_t sz_old = kDenseReal ? pre_sz : p.size[row];
@@ -484,6 +577,7 @@ __global__ __launch_bounds__(256) void pass_kernel(const PassParams p)
             if (lane == 0 && row16 < row_hi && (nk16 | kd16)) ((uint16_t *)p.kdirty)[row16 >> 4] = (uint16_t)nk16;
         }
     }
+    if (kEpi4 && npend) flush_pending();
     // ---- totals: wave -> block -> one atomic per word into the block's counter stripe
     if (REAL || STATS) {
 #pragma unroll
@@ -495,6 +589,205 @@ __global__ __launch_bounds__(256) void pass_kernel(const PassParams p)
         // cnt_changed is identical in all lanes of the wave (derived from a ballot)
         const unsigned long long v[4] = {cnt_changed, cnt_active, cnt_rows, cnt_out};
         block_add_counters(p.counters, v, (REAL ? 0x9u : 0u) | (STATS ? 0x2u : 0u) | ((REAL && FRONTIER) ? 0x4u : 0u));
+    }
+}
+
+// ---- the bitmap (frontier) pass, restructured ------------------------------------------------------------------------
+// Same rows, same semantics and same bits as pass_kernel<REAL, FRONTIER = true, ...> (a source is gathered only if its
+// changed bit is set; rows nothing happened to are left alone), but built for what bounds that pass: with few active
+// sources it is a chain of DEPENDENT round trips per row - index -> changed-bit word -> counter gather, repeated for every
+// 16 sources, then the row's own counter - at a handful of waves per SIMD, not bytes.  Here a quad takes ALL (<= 64)
+// indices of its row in one go (16 per lane), then all their bit words, then issues only the gathers that are needed,
+// together with the row's own counter: three round trips per row instead of up to fourteen.  Gather slots in which no
+// quad of the wave has an active source are skipped altogether (wave-uniform test on a ballot).
+// W = index slots per lane and batch: 16 (64 sources per quad: hub chunks) or 4 (16 sources: node rows have ~5)
+template <bool REAL, bool FUSED, bool STATS, int W>
+__global__ __launch_bounds__(256) void frontier_kernel(const PassParams p)
+{
+    __shared__ double s_raw[FUSED ? kTableLen : 1];
+    __shared__ double s_bias[FUSED ? kTableLen : 1];
+    __shared__ uint8_t s_lc[68];
+    if (FUSED) {
+        for (int i = threadIdx.x; i < kTableLen; i += 256) {
+            s_raw[i] = p.raw[i];
+            s_bias[i] = p.bias[i];
+        }
+        if (threadIdx.x < 65) s_lc[threadIdx.x] = p.lc[threadIdx.x];
+        __syncthreads();
+    }
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int g = lane >> 2, q = lane & 3;
+    const int qshift = lane & ~3;
+    uint64_t row_lo = p.row_lo, row_hi = p.row_hi, tile0 = blockIdx.x, tstride = gridDim.x;
+    if (!REAL && p.xcd_map) {
+        const int x = blockIdx.x & 7;
+        row_lo = p.xcd_lo[x];
+        row_hi = p.xcd_hi[x];
+        tile0 = blockIdx.x >> 3;
+        tstride = gridDim.x >> 3; // the grid is a multiple of 8
+    }
+    const uint64_t ntiles = (row_hi - row_lo + 63) >> 6;
+    unsigned long long cnt_changed = 0, cnt_active = 0, cnt_rows = 0, cnt_out = 0;
+    // row pointers (and the changed / Kahan-dirty words) of the NEXT tile are requested one iteration ahead
+    uint64_t nbeg = 0, nend = 0;
+    uint32_t nprev16 = 0, nkd16 = 0;
+    auto request = [&](uint64_t tile) {
+        nbeg = nend = 0;
+        nprev16 = nkd16 = 0;
+        const uint64_t r16 = row_lo + (tile << 6) + ((uint64_t)wave << 4), r = r16 + (uint64_t)g;
+        if (tile < ntiles && r < row_hi) {
+            nbeg = ld_stream(&p.row_ptr[r]);
+            nend = ld_stream(&p.row_ptr[r + 1]);
+        }
+        if (REAL && tile < ntiles && r16 < row_hi) {
+            nprev16 = (uint32_t)((const uint16_t *)p.bits_rd)[r16 >> 4];
+            if (FUSED) nkd16 = (uint32_t)((const uint16_t *)p.kdirty)[r16 >> 4];
+        }
+    };
+    request(tile0);
+    for (uint64_t tile = tile0; tile < ntiles; tile += tstride) {
+        const uint64_t row16 = row_lo + (tile << 6) + ((uint64_t)wave << 4); // first row of this wave
+        const uint64_t row = row16 + (uint64_t)g;
+        const bool valid = row < row_hi;
+        const uint64_t beg = nbeg, end = nend;
+        const uint32_t prev16 = nprev16, kd16 = nkd16;
+        request(tile + tstride);
+        const bool self_prev = (prev16 >> g) & 1u;
+        const bool kd = (kd16 >> g) & 1u;
+        const uint4 *selfp = REAL ? (p.rd + row * 4 + q) : (p.part + (row - p.n_pad) * 4 + q);
+        // node rows that must be written anyway (changed last pass / Kahan still moving): their own counter is requested now
+        uint4 selfv = make_uint4(0, 0, 0, 0);
+        const bool early_self = REAL && valid && (self_prev || kd);
+        if (early_self) selfv = *selfp;
+        Acc acc;
+        acc_zero(acc);
+        bool lane_act = false;
+        for (uint64_t e0 = beg; e0 < end; e0 += 4 * W) { // hub chunks: one iteration unless hb_options.chunk > 64
+            // ---- round trip 1: all indices of the batch, W per lane (slot j of lane q = source e0 + 4 j + q)
+            const uint64_t span = end - e0;
+            uint32_t idx[W];
+            uint64_t bal4[W / 4];
+#pragma unroll
+            for (int b = 0; b < W / 4; b++) bal4[b] = __ballot(span > (uint64_t)(16 * b));
+#pragma unroll
+            for (int b = 0; b < W / 4; b++) {
+                if (bal4[b]) { // wave-uniform: some row of the wave reaches this quarter
+#pragma unroll
+                    for (int j = 4 * b; j < 4 * b + 4; j++) {
+                        const uint64_t ee = e0 + 4 * j + q;
+                        idx[j] = (ee < end) ? ld_stream(&p.src[ee]) : kNone;
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 4 * b; j < 4 * b + 4; j++) idx[j] = kNone;
+                }
+            }
+            // all sources of one row are of one kind: real nodes (read rd) or virtual rows (read part)
+            const uint32_t first = quad_bcast<0>(idx[0]);
+            const bool real_src = first < p.n_pad;
+            const uint4 *base = real_src ? p.rd : (const uint4 *)(p.part - p.n_pad * 4);
+            // ---- round trip 2: the changed bits of all of them
+            uint32_t wb[W];
+#pragma unroll
+            for (int b = 0; b < W / 4; b++) {
+                if (bal4[b]) {
+#pragma unroll
+                    for (int j = 4 * b; j < 4 * b + 4; j++) wb[j] = (idx[j] != kNone) ? p.bits_rd[idx[j] >> 5] : 0u;
+                } else {
+#pragma unroll
+                    for (int j = 4 * b; j < 4 * b + 4; j++) wb[j] = 0u;
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < W; j++) {
+                if (!((wb[j] >> (idx[j] & 31u)) & 1u)) idx[j] = kNone;
+                lane_act |= (idx[j] != kNone);
+                if (STATS && real_src) cnt_active += (idx[j] != kNone);
+            }
+            // a hub chunk reads its stored partial only if something reaches it: known now, requested with the gathers
+            if (!REAL && e0 == beg) {
+                const bool t0 = ((__ballot(lane_act) >> qshift) & 0xFull) != 0;
+                if (valid && t0) selfv = *selfp;
+            }
+            // ---- round trip 3: the gathers that are needed, two slots (8 sources per quad) at a time
+#pragma unroll
+            for (int j = 0; j < W; j += 2) {
+                if (!__ballot((idx[j] != kNone) | (idx[j + 1] != kNone))) continue; // no quad of the wave has work in these slots
+                uint4 r[2][4];
+#pragma unroll
+                for (int u = 0; u < 2; u++) {
+                    const uint32_t s0 = quad_bcast<0>(idx[j + u]), s1 = quad_bcast<1>(idx[j + u]);
+                    const uint32_t s2 = quad_bcast<2>(idx[j + u]), s3 = quad_bcast<3>(idx[j + u]);
+                    r[u][0] = r[u][1] = r[u][2] = r[u][3] = make_uint4(0, 0, 0, 0); // max with 0 = identity
+                    if (s0 != kNone) r[u][0] = base[(uint64_t)s0 * 4 + q];
+                    if (s1 != kNone) r[u][1] = base[(uint64_t)s1 * 4 + q];
+                    if (s2 != kNone) r[u][2] = base[(uint64_t)s2 * 4 + q];
+                    if (s3 != kNone) r[u][3] = base[(uint64_t)s3 * 4 + q];
+                }
+#pragma unroll
+                for (int u = 0; u < 2; u++) {
+#pragma unroll
+                    for (int k = 0; k < 4; k++) acc_merge(acc, r[u][k]);
+                }
+            }
+        }
+        // ---- row epilogue: exactly pass_kernel's frontier epilogue
+        const bool touched = ((__ballot(lane_act) >> qshift) & 0xFull) != 0;
+        if (REAL) cnt_rows += (valid && touched && q == 0); // V_t (hb_pass_stats.touched)
+        const bool need = valid && (touched || (REAL && (self_prev || kd)));
+        if (need) {
+            if (REAL && !early_self) selfv = *selfp; // a node row reached by a changed source only
+            acc_merge(acc, selfv);
+        }
+        const uint4 accv = acc_value(acc);
+        const bool lane_diff = need && u4_ne(accv, selfv);
+        const uint64_t bal = __ballot(lane_diff);
+        const bool changed = ((bal >> qshift) & 0xFull) != 0;
+        if (REAL) {
+            // lazy double buffer: wr[row] already holds the right value unless the row changed in this or in the previous pass
+            if (need && (changed || self_prev)) st_stream(&p.wr[row * 4 + q], accv);
+        } else {
+            if (changed) st_stream(&p.part[(row - p.n_pad) * 4 + q], accv);
+        }
+        const uint32_t ch16 = pack16(bal);
+        if (FUSED || !REAL) {
+            // changed bits: real rows -> next frontier; virtual rows -> this pass' bits
+            uint16_t *dst = REAL ? (uint16_t *)p.bits_wr : (uint16_t *)p.bits_rd;
+            if (lane == 0 && row16 < row_hi) dst[row16 >> 4] = (uint16_t)ch16;
+        }
+        if (REAL && FUSED) {
+            cnt_changed += __popc(ch16);
+            if (changed && q == 0) cnt_out += p.outdeg[row];
+            bool err_nz = false;
+            if (need && (changed || kd)) {
+                const uint64_t sz_old = p.size[row];
+                const uint64_t sz_new = changed ? hll_size_quad(accv, s_raw, s_bias, s_lc) : sz_old;
+                if (q == 0) {
+                    double ks = p.ksum[row], ke = p.kerr[row];
+                    err_nz = kahan_update(ks, ke, sz_new, sz_old, p.t_plus_1); // still moving -> visit again
+                    if (err_nz) {
+                        p.ksum[row] = ks;
+                        p.kerr[row] = ke;
+                    }
+                    if (changed) p.size[row] = sz_new;
+                }
+            }
+            const uint32_t nk16 = pack16(__ballot(err_nz));
+            if (lane == 0 && row16 < row_hi && (nk16 | kd16)) ((uint16_t *)p.kdirty)[row16 >> 4] = (uint16_t)nk16;
+        }
+    }
+    // ---- totals: wave -> block -> one atomic per word into the block's counter stripe
+    if (REAL || STATS) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            cnt_out += __shfl_down(cnt_out, off);
+            if (STATS) cnt_active += __shfl_down(cnt_active, off);
+            if (REAL) cnt_rows += __shfl_down(cnt_rows, off);
+        }
+        // cnt_changed is identical in all lanes of the wave (derived from a ballot)
+        const unsigned long long v[4] = {cnt_changed, cnt_active, cnt_rows, cnt_out};
+        block_add_counters(p.counters, v, (REAL ? 0xDu : 0u) | (STATS ? 0x2u : 0u));
     }
 }
 

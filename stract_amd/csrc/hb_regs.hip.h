@@ -39,7 +39,10 @@ __device__ __forceinline__ uint32_t pkmax(uint32_t a, uint32_t b)
     return __builtin_bit_cast(uint32_t, z);
 }
 
-// 16 registers of one lane kept as even/odd bytes so that one merge is 2 AND + 2 v_pk_max_u16
+// 16 registers of one lane kept as even/odd bytes so that one merge is 1 AND + 2 v_pk_max_u16 per word: the even bytes
+// are compared as clean 16-bit lanes (0x00FF00FF masked); the odd bytes as the HIGH bytes of the unmasked 16-bit lanes -
+// a lane's maximum has the larger high byte whatever the low bytes are, so o[] carries garbage in its low bytes until
+// acc_value() masks it once.
 struct Acc {
     uint32_t e[4], o[4];
 };
@@ -54,12 +57,13 @@ __device__ __forceinline__ void acc_merge(Acc &a, const uint4 &r)
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         a.e[k] = pkmax(a.e[k], w[k] & 0x00FF00FFu);
-        a.o[k] = pkmax(a.o[k], w[k] & 0xFF00FF00u);
+        a.o[k] = pkmax(a.o[k], w[k]);
     }
 }
 __device__ __forceinline__ uint4 acc_value(const Acc &a)
 {
-    return make_uint4(a.e[0] | a.o[0], a.e[1] | a.o[1], a.e[2] | a.o[2], a.e[3] | a.o[3]);
+    return make_uint4(a.e[0] | (a.o[0] & 0xFF00FF00u), a.e[1] | (a.o[1] & 0xFF00FF00u), a.e[2] | (a.o[2] & 0xFF00FF00u),
+                      a.e[3] | (a.o[3] & 0xFF00FF00u));
 }
 __device__ __forceinline__ bool u4_ne(const uint4 &a, const uint4 &b)
 {

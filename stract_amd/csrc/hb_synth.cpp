@@ -123,7 +123,9 @@ static hbs_graph *build_graph(int scale, uint64_t m_target, uint64_t seed, int t
     if (scale < 1 || scale > 31) return nullptr;
 #ifdef _OPENMP
     {   // small graphs: a few threads beat every hardware thread of a many-core box
-        int nt = threads > 0 ? threads : omp_get_max_threads();
+        // all hardware threads unless told otherwise: NOT omp_get_max_threads(), which another library of the process
+        // (the oracle's omp_set_num_threads) may have lowered - the random-access phases scale with threads
+        int nt = threads > 0 ? threads : omp_get_num_procs();
         const uint64_t cap = m_target / 65536 + 1;
         if ((uint64_t)nt > cap) nt = (int)cap;
         omp_set_num_threads(nt < 1 ? 1 : nt);
@@ -345,6 +347,147 @@ uint64_t hbs_export_edges(const hbs_graph *g, hbs_edge *out, uint64_t cap, int s
     }
     (void)mask;
     return recs.size();
+}
+
+} // extern "C"
+
+// ---- streamed export (for graphs whose 40-byte records do not fit host memory at once) --------------------------
+// Record p of the stream is a pure function of (graph, salt, p), so any slab [first, first + count) can be produced on
+// its own, in parallel, and fed to hb_append_edges batch by batch.
+//   salt = 0: the m clean edges in a pseudo-random order (affine permutation of the edge index), rel_flags = 0.
+//   salt = 2 ("reduces to the clean graph"): the same, with
+//     * harmless flag bits (outside SKIPPED_REL) on some clean records;
+//     * phase A: after every 15 clean records one EXTRA record: an edge between two existing hosts that is NOT in the
+//       clean graph, carrying a SKIPPED_REL bit - its first occurrence is flagged, so the pair is lost for good
+//       (store.rs:313 de-duplicates first, harmonic.rs:131 filters after);
+//     * phase B (after all clean records): for extra j a CLEAN copy of the same pair (stays lost), and a FLAGGED
+//       duplicate of some clean edge (ignored: the clean copy came first).
+//     The reference semantics therefore reduce the stream to exactly the clean graph (same node set, same CSR): the
+//     oracle's dense run over hbs_row_ptr / hbs_src is the expected result.  tests/test_host.py checks this claim on
+//     small graphs against the structure-faithful oracle.
+struct hbs_stream_plan {
+    uint64_t m, n, full_blocks, len_a, len, mul, add;
+};
+
+static uint64_t gcd64(uint64_t a, uint64_t b)
+{
+    while (b) {
+        const uint64_t t = a % b;
+        a = b;
+        b = t;
+    }
+    return a;
+}
+
+static hbs_stream_plan stream_plan(const hbs_graph *g, int salt)
+{
+    hbs_stream_plan p;
+    p.m = g->edges.size();
+    p.n = g->ids.size();
+    p.full_blocks = (salt == 2 && p.n >= 4) ? p.m / 15 : 0;
+    p.len_a = p.m + p.full_blocks;
+    p.len = p.len_a + 2 * p.full_blocks;
+    // affine permutation c -> (c * mul + add) mod m of the clean-edge index
+    p.mul = 1;
+    p.add = 0;
+    if (p.m > 2) {
+        uint64_t a = (uint64_t)((long double)p.m * 0.6180339887498949L) | 1;
+        while (a >= p.m || gcd64(a, p.m) != 1) a = a >= p.m ? 1 : a + 2;
+        p.mul = a;
+        p.add = splitmix64(g->seed ^ 0x57EA) % p.m;
+    }
+    return p;
+}
+
+static inline uint64_t stream_perm(const hbs_stream_plan &p, uint64_t c)
+{
+    return p.m ? (uint64_t)(((unsigned __int128)c * p.mul + p.add) % p.m) : 0;
+}
+
+// extra j: (from, to) dense indices of a pair that is not a clean edge and not a self loop; false if none was found
+// (then the extra degenerates to a flagged self loop, which the filter drops)
+static inline bool stream_extra(const hbs_graph *g, const hbs_stream_plan &p, uint64_t j, uint32_t *from, uint32_t *to)
+{
+    for (int attempt = 0; attempt < 8; attempt++) {
+        const uint64_t h = splitmix64(g->seed + 0xE17A + j * 0x2545F4914F6CDD1Dull + (uint64_t)attempt * 0x9E3779B97F4A7C15ull);
+        const uint32_t f = (uint32_t)(h % p.n), t = (uint32_t)((h >> 32) % p.n);
+        if (f == t) continue;
+        // (f -> t) a clean edge?  the sources of row t are ascending: a short search inside the row
+        const uint32_t *rb = g->src.data() + g->row_ptr[t], *re = g->src.data() + g->row_ptr[t + 1];
+        if (std::binary_search(rb, re, f)) continue;
+        *from = f;
+        *to = t;
+        return true;
+    }
+    *from = *to = (uint32_t)(splitmix64(j) % p.n);
+    return false;
+}
+
+extern "C" {
+
+uint64_t hbs_stream_len(const hbs_graph *g, int salt) { return stream_plan(g, salt).len; }
+// pairs that only occur flagged-first (they count in m_unique, not in m_eff): for the expected hb_stats
+uint64_t hbs_stream_lost_pairs(const hbs_graph *g, int salt)
+{
+    const hbs_stream_plan p = stream_plan(g, salt);
+    // distinct (from, to) pairs among the extras (two extras may draw the same pair; degenerate extras are flagged self
+    // loops (v, v)): each is one unique pair of the stream that never becomes an edge
+    std::vector<uint64_t> pairs(p.full_blocks);
+#pragma omp parallel for schedule(static) num_threads(omp_get_num_procs())
+    for (int64_t j = 0; j < (int64_t)p.full_blocks; j++) {
+        uint32_t f, t;
+        stream_extra(g, p, (uint64_t)j, &f, &t);
+        pairs[j] = ((uint64_t)t << 32) | f;
+    }
+    HBS_SORT(pairs.begin(), pairs.end());
+    return (uint64_t)(std::unique(pairs.begin(), pairs.end()) - pairs.begin());
+}
+
+uint64_t hbs_stream_fill(const hbs_graph *g, int salt, uint64_t first, uint64_t count, hbs_edge *out)
+{
+    const hbs_stream_plan p = stream_plan(g, salt);
+    if (first > p.len) return 0;
+    if (count > p.len - first) count = p.len - first;
+    static const int skipped_bits[12] = {8, 10, 11, 13, 14, 15, 16, 17, 18, 19, 21, 22};
+    static const int harmless_bits[11] = {0, 1, 2, 3, 4, 5, 6, 7, 9, 12, 20};
+#pragma omp parallel for schedule(static) num_threads(omp_get_num_procs())
+    for (int64_t i = 0; i < (int64_t)count; i++) {
+        const uint64_t pos = first + (uint64_t)i;
+        uint32_t f, t;
+        uint64_t flags = 0;
+        if (pos < p.len_a) {
+            const uint64_t b = pos / 16, r = pos % 16;
+            if (b < p.full_blocks && r == 15) { // extra b: flagged first occurrence of a pair outside the clean graph
+                stream_extra(g, p, b, &f, &t);
+                const uint64_t h = splitmix64(b ^ 0xF1A6);
+                flags = (1ull << skipped_bits[h % 12]) | ((h & 0x100) ? 1ull << harmless_bits[(h >> 16) % 11] : 0);
+            } else {
+                const uint64_t c = b < p.full_blocks ? 15 * b + r : pos - p.full_blocks;
+                const uint64_t key = g->edges[stream_perm(p, c)];
+                f = (uint32_t)key;
+                t = (uint32_t)(key >> 32);
+                if (salt == 2) {
+                    const uint64_t h = splitmix64(c ^ 0xC1EA);
+                    if ((h & 7) == 0) flags = 1ull << harmless_bits[(h >> 8) % 11];
+                }
+            }
+        } else {
+            const uint64_t q = pos - p.len_a, j = q / 2;
+            if (q & 1) { // clean copy of extra j: stays lost (degenerate extras repeat their flagged self loop)
+                const bool real = stream_extra(g, p, j, &f, &t);
+                flags = real ? 0 : (1ull << skipped_bits[j % 12]);
+            } else {     // flagged duplicate of a clean edge: ignored, the clean record came first
+                const uint64_t key = g->edges[stream_perm(p, (j * 15 + 7) % p.m)];
+                f = (uint32_t)key;
+                t = (uint32_t)(key >> 32);
+                flags = 1ull << skipped_bits[splitmix64(j ^ 0xD0B1) % 12];
+            }
+        }
+        out[i].from = g->ids[f];
+        out[i].to = g->ids[t];
+        out[i].rel_flags = flags;
+    }
+    return count;
 }
 
 } // extern "C"

@@ -29,6 +29,12 @@ def _load():
         for f in ("hbs_ids", "hbs_row_ptr", "hbs_src"):
             getattr(L, f).restype = ctypes.c_void_p
             getattr(L, f).argtypes = [ctypes.c_void_p]
+        L.hbs_stream_len.restype = ctypes.c_uint64
+        L.hbs_stream_len.argtypes = [ctypes.c_void_p, ctypes.c_int]
+        L.hbs_stream_lost_pairs.restype = ctypes.c_uint64
+        L.hbs_stream_lost_pairs.argtypes = [ctypes.c_void_p, ctypes.c_int]
+        L.hbs_stream_fill.restype = ctypes.c_uint64
+        L.hbs_stream_fill.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_void_p]
         L.hbs_export_edges.restype = ctypes.c_uint64
         L.hbs_export_edges.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_int, ctypes.c_uint64]
         _lib = L
@@ -72,6 +78,30 @@ class RmatGraph:
         k = L.hbs_export_edges(self._g, out.ctypes.data, cap, salt, salt_seed)
         assert k == cap
         return out
+
+    def stream_len(self, salt=0):
+        """Records of the streamed export (salt 0: the clean edges permuted; salt 2: plus flagged-first extras, their
+        clean copies and flagged duplicates - a stream that the reference semantics reduce to exactly this graph)."""
+        return int(_load().hbs_stream_len(self._g, salt))
+
+    def stream_lost_pairs(self, salt=0):
+        return int(_load().hbs_stream_lost_pairs(self._g, salt))
+
+    def stream_fill(self, out, first, salt=0):
+        """Fills out[:k] (EDGE records, any writable contiguous buffer) with records first.. of the stream; returns k."""
+        assert out.dtype == EDGE and out.flags["C_CONTIGUOUS"]
+        return int(_load().hbs_stream_fill(self._g, salt, first, len(out), out.ctypes.data))
+
+    def stream(self, salt=0, slab=1 << 22, buf=None):
+        """Yields the stream slab by slab (views of one reused buffer)."""
+        total = self.stream_len(salt)
+        if buf is None:
+            buf = np.zeros(min(slab, max(total, 1)), dtype=EDGE)
+        at = 0
+        while at < total:
+            k = self.stream_fill(buf, at, salt)
+            yield buf[:k]
+            at += k
 
     def close(self):
         if self._g:

@@ -124,11 +124,12 @@ def column_bytes(ctype, values):
     out = bytearray([0])  # Cardinality::Full
     if ctype == U128:
         v = np.ascontiguousarray(values)  # structured (lo, hi) little-endian = u128 little-endian
-        ints = [(int(h) << 64) | int(l) for l, h in zip(v["lo"], v["hi"])] or [0]
         out.append(0)  # u128 CodecType::Raw
         out += struct.pack("<I", n)
-        for x in (min(ints), max(ints)):
-            out += struct.pack("<QQ", x & 0xFFFFFFFFFFFFFFFF, x >> 64)
+        for pick in (np.min, np.max):  # min / max of the u128 values: extreme high half, then the extreme low half among those
+            hi = pick(v["hi"]) if n else 0
+            lo = pick(v["lo"][v["hi"] == hi]) if n else 0
+            out += struct.pack("<QQ", int(lo), int(hi))
         out += v.tobytes()
     else:
         v = np.ascontiguousarray(values, dtype="<u8")

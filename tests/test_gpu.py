@@ -147,6 +147,11 @@ VARIANTS = {
     "xcd_slices_small_bands": dict(chunk=8, tune=(0, 0, 0, 4, 2)),
     "banded_chunks": dict(chunk=16, tune=(0, 0, 0, 6, 4)),
     "banded_frontier_small_direct": dict(chunk=32, tune=(0, 0, 101, 5, 8, 8)),
+    # measurement switches of round 3: the older kernels stay bit-identical
+    "old_per_tile_epilogue": dict(tune=(0, 0x100)),                                  # dense node rows: estimator/Kahan per quad, not once per row
+    "old_frontier_loop": dict(chunk=8, tune=(0, 0x200, 101, 0, 0, 0, 1000000)),      # bitmap passes through pass_kernel<.., FRONTIER>
+    "frontier_always_chunk128": dict(chunk=128, tune=(0, 0, 101, 0, 0, 0, 1000000)), # rows with > 64 sources: two batches per hub chunk
+    "frontier_always_pass_stats": dict(flags=_lib.HB_FLAG_PASS_STATS, tune=(0, 0, 101, 0, 0, 0, 1000000)),
 }
 
 
@@ -218,6 +223,50 @@ def test_salted_edge_records_match_faithful_oracle(gpu_ctx_factory):
         ctx.run()
         ids2, vals2 = ctx.results()
     assert np.array_equal(ids2, fids) and np.array_equal(vals2.view(np.uint64), fvals.view(np.uint64))
+
+
+def test_streamed_ingest_chunks_refusal_and_spill(gpu_ctx_factory):
+    """hb_append_edges at its edges, reached with small inputs through hb_debug_set_ingest_limits: many small record chunks
+    (the node set is merged chunk by chunk, pair keys are mapped chunk by chunk), the record-count refusal of the device
+    reduction (the stream moves to the host path) and an out-of-memory spill in the MIDDLE of a stream.  Input: the
+    synthetic stream that the reference semantics reduce to exactly the clean graph (flagged-first pairs stay lost,
+    later flagged duplicates are ignored) - so the oracle's dense run over the clean graph is the expected result, and
+    the faithful oracle on the records says the same."""
+    g = synth.RmatGraph(12, 30_000)
+    total = g.stream_len(2)
+    o = hbo.Dense(g.id_low64(), g.row_ptr, g.src)
+    T = o.run()
+    ovals, keep, k = o.finish()
+    recs = np.concatenate([sl.copy() for sl in g.stream(2, slab=5000)])
+    fids, fvals, fst = hbo.faithful_run(recs)
+    assert fst["n"] == g.n and fst["m_eff"] == g.m and np.array_equal(fids, g.ids[keep])
+    assert np.array_equal(fvals.view(np.uint64), ovals[keep].view(np.uint64))
+    cases = {"default": dict(), "chunks_of_4096": dict(chunk_records=4096), "chunks_of_1000_odd_batches": dict(chunk_records=1000),
+             "refused_at_10000_records": dict(max_records=10_000), "oom_after_3_chunks": dict(chunk_records=4096, max_device_bytes=3 * 4096 * 33),
+             "oom_at_once": dict(max_device_bytes=1)}
+    for name, lim in cases.items():
+        with gpu_ctx_factory() as ctx:
+            ctx.set_ingest_limits(**lim)
+            slab = 3333 if "odd" in name else 5000
+            for part in g.stream(2, slab=slab):
+                ctx.append_edges(part)
+            ctx.finalize()
+            st = ctx.run()
+            ids, vals = ctx.results()
+            gi, grp, gsrc = ctx.graph()
+        assert (st["n"], st["m_input"], st["m_eff"], st["m_unique"]) == (g.n, total, g.m, g.m + g.stream_lost_pairs(2)), name
+        assert np.array_equal(gi, g.ids) and np.array_equal(grp, g.row_ptr) and np.array_equal(gsrc, g.src), name
+        assert st["passes"] == T and np.array_equal(ids, g.ids[keep]) and np.array_equal(vals.view(np.uint64), ovals[keep].view(np.uint64)), name
+        spilled = name.startswith(("refused", "oom"))
+        assert (st["ingest_peak_bytes"] == 0) == spilled, (name, st["ingest_peak_bytes"])
+        if not spilled:   # 33 B per record held + 12 B per record of pair keys + node set and sort buffers of one chunk
+            assert 45 * total <= st["ingest_peak_bytes"] < 45 * total + (64 << 20), (name, st["ingest_peak_bytes"])
+    # hb_load_edges with more records than the device reduction takes: host ingest, same graph
+    with gpu_ctx_factory() as ctx:
+        ctx.set_ingest_limits(max_records=1000)
+        ctx.load_edges(recs)
+        st = ctx.stats()
+        assert (st["n"], st["m_eff"], st["ingest_peak_bytes"]) == (g.n, g.m, 0)
 
 
 def test_load_webgraph_from_edge_store(gpu_ctx_factory, tmp_path):

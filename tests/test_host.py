@@ -32,7 +32,7 @@ def test_header_symbols_all_exported():
 def test_struct_layouts_match_header():
     assert ctypes.sizeof(_lib.HbOptions) == 4 * 7 + 128 + 32
     assert _lib.EDGE.itemsize == 40 and _lib.U128.itemsize == 16
-    assert ctypes.sizeof(_lib.HbStats) == 23 * 8
+    assert ctypes.sizeof(_lib.HbStats) == 24 * 8
     assert ctypes.sizeof(_lib.HbPassStats) == 4 * 8 + 6 * 4
 
 
@@ -280,6 +280,35 @@ def test_host_stages_under_sanitizers(tmp_path):
     env.pop("LD_PRELOAD", None)
     r = subprocess.run([exe], capture_output=True, text=True, timeout=900, env=env)
     assert r.returncode == 0 and "asan_host_check: ok" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
+
+
+def test_streamed_export_reduces_to_clean_graph():
+    """stract_amd/csrc/hb_synth.cpp hbs_stream_*: the record stream used to feed BASELINE-sized graphs through the real
+    boundary (hb_append_edges) slab by slab.  Claim: under the reference semantics (store.rs:313 first occurrence,
+    harmonic.rs:131 filter after) the salted stream reduces to EXACTLY the clean graph.  Checked against the
+    structure-faithful oracle on the records and the host ingest; slabs of any size give the same bytes."""
+    from oracle import hbo
+    for scale, m in ((10, 6000), (13, 60_000)):
+        g = synth.RmatGraph(scale, m)
+        for salt in (0, 2):
+            total = g.stream_len(salt)
+            full = np.zeros(total, dtype=_lib.EDGE)
+            assert g.stream_fill(full, 0, salt) == total
+            parts = np.concatenate([sl.copy() for sl in g.stream(salt, slab=4097)])
+            assert parts.tobytes() == full.tobytes()
+            assert total == g.m + (g.m // 15) * 3 * (salt == 2)
+            ids, rp, src, m_unique = _lib.host_ingest(full)
+            assert np.array_equal(ids, g.ids) and np.array_equal(rp, g.row_ptr) and np.array_equal(src, g.src)
+            assert m_unique == g.m + g.stream_lost_pairs(salt)
+            if salt == 2:
+                flagged = (full["rel_flags"] & np.uint64(0x6FED00)) != 0
+                assert 0.1 < flagged.mean() < 0.2 and g.stream_lost_pairs(2) > g.m // 20
+            fids, fvals, fst = hbo.faithful_run(full)
+            o = hbo.Dense(g.id_low64(), g.row_ptr, g.src)
+            T = o.run()
+            ovals, keep, k = o.finish()
+            assert (fst["n"], fst["m_eff"], fst["m_unique"], fst["passes"]) == (g.n, g.m, m_unique, T)
+            assert np.array_equal(fids, g.ids[keep]) and np.array_equal(fvals.view(np.uint64), ovals[keep].view(np.uint64))
 
 
 def test_tail_index_filter_and_mapping():

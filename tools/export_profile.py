@@ -2,8 +2,14 @@
 """Turn a tools/profile.sh output directory (rocprofv3 rocpd .db files) into the small text
 summaries that are committed under profiles/.
 usage: export_profile.py <gpurun_out/prof_dir> <profiles/prefix>
-writes <prefix>_kernel_stats.csv (rocprofv3 --kernel-trace --stats: per-kernel calls/avg/total)
-       <prefix>_pmc.json         (per kernel: FETCH_SIZE / WRITE_SIZE / TCC hit+miss per dispatch)"""
+writes <prefix>_kernel_stats.csv (rocprofv3 --kernel-trace --stats: per launch class calls/avg/total)
+       <prefix>_pmc.json         (per launch class: FETCH_SIZE / WRITE_SIZE / TCC hit+miss per dispatch)
+
+Launch classes: the hub-chunk kernel `pass_kernel<false, ...>` is launched once per tree LEVEL in every pass with
+the same template arguments; the level-1 launch (the dominant kernel: all real hub edges) and the small upper-level
+launches must not be averaged together.  Dispatches are walked in dispatch order and a hub launch gets the suffix
+`#L<k>` = it is the k-th consecutive hub launch since the last kernel of another kind (the node-row / sweep /
+init launch that ends a pass)."""
 import csv
 import glob
 import json
@@ -12,30 +18,61 @@ import sqlite3
 import sys
 
 
+def classify(rows):
+    """rows: (dispatch_id, name, ...) in dispatch order -> list of class names (hub launches get #L<level>)."""
+    out, lvl = [], 0
+    for r in rows:
+        name = r[1].split("(")[0].strip()
+        if name.startswith("void "):
+            name = name[5:]
+        if name.startswith("hbk::pass_kernel<false,"):
+            lvl += 1
+            out.append("%s#L%d" % (name, lvl))
+        else:
+            lvl = 0
+            out.append(name)
+    return out
+
+
 def main():
     src, prefix = sys.argv[1], sys.argv[2]
     os.makedirs(os.path.dirname(prefix) or ".", exist_ok=True)
     dbs = glob.glob(os.path.join(src, "trace", "**", "*.db"), recursive=True)
     if dbs:
         c = sqlite3.connect(dbs[0])
-        rows = c.execute("select name, count(*), sum(duration), avg(duration), min(duration), max(duration) "
-                         "from kernels group by name order by sum(duration) desc").fetchall()
-        tot = sum(r[2] for r in rows) or 1
+        rows = c.execute("select dispatch_id, name, duration from kernels order by dispatch_id").fetchall()
+        agg = {}
+        for cls, r in zip(classify(rows), rows):
+            a = agg.setdefault(cls, [0, 0, None, None])
+            a[0] += 1
+            a[1] += r[2]
+            a[2] = r[2] if a[2] is None else min(a[2], r[2])
+            a[3] = r[2] if a[3] is None else max(a[3], r[2])
+        tot = sum(a[1] for a in agg.values()) or 1
         with open(prefix + "_kernel_stats.csv", "w", newline="") as f:
             w = csv.writer(f)
             w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs"])
-            for r in rows:
-                w.writerow([r[0], r[1], int(r[2]), round(r[3], 1), round(100.0 * r[2] / tot, 3), int(r[4]), int(r[5])])
+            for name, a in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+                w.writerow([name, a[0], int(a[1]), round(a[1] / a[0], 1), round(100.0 * a[1] / tot, 3), int(a[2]), int(a[3])])
     pmc = {}
     for db in sorted(glob.glob(os.path.join(src, "pmc_*", "**", "*.db"), recursive=True)):
         c = sqlite3.connect(db)
-        for name, counter, cnt, total in c.execute(
-                "select kernel_name, counter_name, count(*), sum(value) from counters_collection "
-                "group by kernel_name, counter_name"):
+        rows = c.execute("select dispatch_id, kernel_name, counter_name, value from counters_collection order by dispatch_id").fetchall()
+        # several counters per dispatch: classify on the distinct dispatches
+        disp = []
+        for r in rows:
+            if not disp or disp[-1][0] != r[0]:
+                disp.append((r[0], r[1]))
+        cls_of = dict(zip([d[0] for d in disp], classify(disp)))
+        for did, name, counter, value in rows:
             if "rocclr" in name:
                 continue
-            pmc.setdefault(name.split("(")[0], {})[counter] = {"dispatches": cnt, "sum": total, "per_dispatch": total / cnt}
+            e = pmc.setdefault(cls_of[did], {}).setdefault(counter, {"dispatches": 0, "sum": 0.0})
+            e["dispatches"] += 1
+            e["sum"] += value
     for k, cs in pmc.items():
+        for e in cs.values():
+            e["per_dispatch"] = e["sum"] / e["dispatches"]
         if "FETCH_SIZE" in cs and "WRITE_SIZE" in cs:
             # FETCH_SIZE / WRITE_SIZE are KiB.  Calibration on this access pattern
             # (tools/gather_bench.hip, exactly-once 64-byte quad gathers over 8 GiB): FETCH_SIZE
@@ -45,6 +82,7 @@ def main():
         if "TCC_HIT_sum" in cs and "TCC_MISS_sum" in cs:
             h, m = cs["TCC_HIT_sum"]["sum"], cs["TCC_MISS_sum"]["sum"]
             cs["l2_hit_rate"] = h / (h + m) if h + m else None
+            cs["l2_misses_per_dispatch"] = cs["TCC_MISS_sum"]["per_dispatch"]
     with open(prefix + "_pmc.json", "w") as f:
         json.dump(pmc, f, indent=1, sort_keys=True)
     print("wrote", prefix + "_kernel_stats.csv", prefix + "_pmc.json")

@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
 #include <vector>
 
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
@@ -112,7 +113,14 @@ int main(int argc, char **argv)
     struct Case { const char *name; uint64_t region; int perm; };
     Case cases[] = {{"L2_4MiB", 1ull << 16, 0},   {"L2x8_32MiB", 1ull << 19, 0}, {"MALL_128MiB", 1ull << 21, 0},
                     {"MALL_256MiB", 1ull << 22, 0}, {"HBM_512MiB", 1ull << 23, 0}, {"HBM_8GiB", 1ull << 27, 0},
-                    {"perm_8GiB_once", 1ull << 27, 1}, {"seq_8GiB_once", 1ull << 27, 2}};
+                    {"perm_8GiB_once", 1ull << 27, 1}, {"seq_8GiB_once", 1ull << 27, 2},
+                    // round 3: does address ORDER or a moving WINDOW lift the ~45 G/s of random 64-byte gathers?
+                    // sorted_rows: the 64 sources of every row ascending (what sorting the sources inside a chunk would give);
+                    // window_*: rows processed at the same time draw their sources from one window of that many counters that
+                    // slides over the 8 GiB (what a band-major / locality-aware order of cold sources would give)
+                    {"HBM_8GiB_sorted_rows", 1ull << 27, 3},
+                    {"window_4MiB_in_8GiB", 1ull << 16, 4}, {"window_32MiB_in_8GiB", 1ull << 19, 4}, {"window_256MiB_in_8GiB", 1ull << 22, 4},
+                    {"window_1GiB_in_8GiB", 1ull << 24, 4}};
     for (const Case &c : cases) {
         if (only[0] && strcmp(only, c.name)) continue;
         uint64_t s = 42;
@@ -121,6 +129,16 @@ int main(int argc, char **argv)
             for (uint64_t i = 0; i < rows * deg; i++) idx[i] = (uint32_t)(((i * 0x9E3779B1ull) ^ 0x5A5A5A5ull) & (total - 1));
         } else if (c.perm == 2) {
             for (uint64_t i = 0; i < rows * deg; i++) idx[i] = (uint32_t)i;
+        } else if (c.perm == 3) {
+            for (uint64_t r = 0; r < rows; r++) {
+                for (int k = 0; k < deg; k++) idx[r * deg + k] = (uint32_t)(sm(s) & (total - 1));
+                std::sort(idx.begin() + r * deg, idx.begin() + (r + 1) * deg);
+            }
+        } else if (c.perm == 4) {
+            for (uint64_t r = 0; r < rows; r++) {
+                const uint64_t base = (uint64_t)((double)r / (double)rows * (double)(total - c.region));
+                for (int k = 0; k < deg; k++) idx[r * deg + k] = (uint32_t)(base + (sm(s) & (c.region - 1)));
+            }
         } else {
             for (uint64_t i = 0; i < rows * deg; i++) idx[i] = (uint32_t)(sm(s) & (c.region - 1));
         }

@@ -45,7 +45,8 @@ def main():
                 "front_ms_sum": round(float(np.sum([p["ms_gpu"] for p in front])), 3) if front else None,
                 "sparse_ms_sum": round(float(np.sum([p["ms_gpu"] for p in sparse])), 3) if sparse else None,
                 "changed": [p["changed"] for p in ps], "active_pct": [round(100.0 * p["active_edges"] / g.m, 2) for p in ps],
-                "modes": [p["mode"] for p in ps], "ms": [round(p["ms_gpu"], 2) for p in ps],
+                "modes": [p["mode"] for p in ps], "ms": [round(p["ms_gpu"], 3) for p in ps],
+                "ms_level1_or_expand": [round(p["ms_level1"], 3) for p in ps], "ms_node_rows": [round(p["ms_main"], 3) for p in ps],
                 "virtual_rows": best["virtual_rows"], "s_load": round(t_load, 2), "ms_plan": round(best["ms_plan"]),
                 "same_result": sig == ref}), flush=True)
 
