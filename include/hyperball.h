@@ -113,7 +113,10 @@ typedef struct hb_options {
                              *      second byte = hub chunks (dense 2, bitmap 4)
                              *  [1] low byte: gather unroll 1|2|4 (hub chunks 4, node rows 2); bit 8: dense fused node rows with the
                              *      old per-tile estimator/Kahan epilogue instead of the once-per-row one; bit 9: bitmap passes with
-                             *      the older per-16-sources loop instead of the batched frontier kernel (measurement switches)
+                             *      the older per-16-sources loop instead of the batched frontier kernel; bit 10: batched frontier kernel without
+                             *      the LDS-staged summary of the changed bitmap; bit 11: sweep passes always with the three-launch seed
+                             *      collection / expansion, also in the convergence tail (measurement switches); bits 16..23: log2 of the
+                             *      summary capacity in words (tests)
                              *  [2] frontier mode when A_t < tune[2] % of the edges (50; > 100 = always)
                              *  [3] log2 of the hotness slice width in counters (16 = 4 MiB; 1 = no slices)
                              *  [4] min sources of a chunk at a slice cut (8)

@@ -57,6 +57,7 @@ struct hb_ctx {
     uint4 *d_part = nullptr;
     uint32_t *d_bits[2] = {nullptr, nullptr};
     uint32_t *d_kdirty = nullptr;
+    uint32_t *d_summary = nullptr; // bitmap passes: coarse summary of the changed bitmap (hb_kernels.hip.h frontier_kernel)
     double *d_ksum = nullptr, *d_kerr = nullptr;
     uint64_t *d_size = nullptr;
     uint64_t *d_idlow = nullptr;
@@ -172,6 +173,7 @@ void free_graph_buffers(hb_ctx *c)
     c->d_part = nullptr;
     c->d_bits[0] = c->d_bits[1] = nullptr;
     c->d_kdirty = nullptr;
+    c->d_summary = nullptr;
     c->d_ksum = c->d_kerr = nullptr;
     c->d_size = nullptr;
     c->d_idlow = nullptr;
@@ -439,6 +441,7 @@ int plan_and_upload(hb_ctx *c, DeviceCsr *csr_in, uint64_t m_eff)
     if ((rc = dev_alloc(c, &c->d_bits[0], c->bits_words))) return rc;
     if ((rc = dev_alloc(c, &c->d_bits[1], c->bits_words))) return rc;
     if ((rc = dev_alloc(c, &c->d_kdirty, p.n_pad / 32 + 2))) return rc;
+    if ((rc = dev_alloc(c, &c->d_summary, hbk::kSummaryWords + 2))) return rc;
     // Kahan ownership: one contiguous slice of rows per rank (multiple of 64 rows)
     const uint64_t world = c->comm ? (uint64_t)c->opt.world_size : 1;
     c->slice_rows = dest_mode(c) ? p.slice : ((p.n_pad + world - 1) / world + 63) / 64 * 64;
@@ -594,6 +597,10 @@ void launch_pass(hb_ctx *c, const hbk::PassParams &pp, bool real, bool frontier,
         blocks = std::min<uint64_t>(ntiles, (uint64_t)c->num_cu * 8);
         if (pp.xcd_map) blocks = std::max<uint64_t>((blocks + 7) / 8 * 8, 8);
     }
+    if (frontier && real && pp.summary && !(c->opt.tune[0] & 0xFFu)) {
+        // every workgroup stages the 32 KB summary in LDS: a few per CU (its LDS holds 5), not dozens
+        blocks = std::min<uint64_t>(ntiles, (uint64_t)c->num_cu * 5);
+    }
     dim3 grid((unsigned)blocks);
     if (frontier && !(c->opt.tune[1] & 0x200u)) {
         // the bitmap pass: all indices / all bit words / needed gathers of a row as three batched round trips
@@ -601,8 +608,9 @@ void launch_pass(hb_ctx *c, const hbk::PassParams &pp, bool real, bool frontier,
         hipStream_t st = c->stream;
 #define HB_FRONT(R, F) \
     do { \
-        if (stats) hipLaunchKernelGGL((hbk::frontier_kernel<R, F, true, (R ? 4 : 16)>), grid, dim3(256), 0, st, pp); \
-        else hipLaunchKernelGGL((hbk::frontier_kernel<R, F, false, (R ? 4 : 16)>), grid, dim3(256), 0, st, pp); \
+        if (stats) hipLaunchKernelGGL((hbk::frontier_kernel<R, F, true, (R ? 4 : 16), false>), grid, dim3(256), 0, st, pp); \
+        else if (pp.summary) hipLaunchKernelGGL((hbk::frontier_kernel<R, F, false, (R ? 4 : 16), true>), grid, dim3(256), 0, st, pp); \
+        else hipLaunchKernelGGL((hbk::frontier_kernel<R, F, false, (R ? 4 : 16), false>), grid, dim3(256), 0, st, pp); \
     } while (0)
         if (real && fused) HB_FRONT(true, true);
         else if (real) HB_FRONT(true, false);
@@ -851,6 +859,22 @@ int step_local(hb_ctx *c)
             HB_HIP(hipGetLastError());
         }
     }
+    if (frontier && !sparse && !(c->opt.tune[1] & 0x600u) && !(c->opt.flags & HB_FLAG_PASS_STATS) && p.n_pad) {
+        // bitmap pass: coarse summary of the changed bitmap for the two-level test (tune[1] bit 10 = off, measurement switch)
+        const uint64_t words = p.n_pad / 32;
+        uint32_t shift = 0;
+        // tune[1] bits 16..23: log2 of the summary capacity in words (0 = the 8192 words that fit LDS; tests shrink it)
+        const uint32_t cap_log2 = (c->opt.tune[1] >> 16) & 0xFFu;
+        const uint64_t cap_words = (cap_log2 >= 1 && cap_log2 < 13) ? (1ull << cap_log2) : (uint64_t)hbk::kSummaryWords;
+        while (((words + (1ull << shift) - 1) >> shift) > cap_words * 32) shift++;
+        const uint64_t sbits = (words + (1ull << shift) - 1) >> shift;
+        const uint32_t swords = (uint32_t)((sbits + 63) / 64 * 2); // whole 64-bit ballots
+        hipLaunchKernelGGL(hbk::summary_kernel, dim3(swords * 32 / 256 + 1), dim3(256), 0, c->stream, (const uint32_t *)c->d_bits[c->cur], words, shift,
+                           c->d_summary, swords);
+        pp.summary = c->d_summary;
+        pp.summary_shift = shift;
+        pp.summary_words = swords;
+    }
     if (sparse) {
         // sweep mode: changed nodes -> touch bits of their readers; then the levels, then the node rows
         hbk::SweepParams sp{};
@@ -860,16 +884,23 @@ int step_local(hb_ctx *c)
         sp.touch = c->d_touch;
         sp.seeds = c->d_seeds;
         sp.heavy = c->d_heavy;
-        sp.counts = c->d_sparse_counts;
         const uint64_t real_words = p.n_pad / 32;
-        HB_HIP(hipMemsetAsync(c->d_sparse_counts, 0, 64 * sizeof(unsigned int), c->stream));
+        // the seed / heavy counters live in two slots used by alternate passes: this pass' first kernel zeroes the other one
+        // (no memset launch per pass; hb_begin clears both)
+        sp.counts = c->d_sparse_counts + 2 * (c->t & 1);
+        sp.counts_next = c->d_sparse_counts + 2 * ((c->t & 1) ^ 1);
         // no bitmap is cleared here: the sweep kernels rewrite every word of this pass' changed bits (node rows in
         // bits_wr, virtual rows in the upper part of bits_rd) and keep the touch bitmap all-zero between passes
         const unsigned sblocks = (unsigned)std::min<uint64_t>(std::max<uint64_t>(real_words / 256, 1), (uint64_t)c->num_cu * 4);
         const unsigned wblocks = (unsigned)c->num_cu * 4;
-        hipLaunchKernelGGL(hbk::sweep_collect_kernel, dim3(sblocks), dim3(256), 0, c->stream, sp);
-        hipLaunchKernelGGL(hbk::sweep_expand_kernel, dim3(wblocks), dim3(256), 0, c->stream, sp);
-        hipLaunchKernelGGL(hbk::sweep_expand_heavy_kernel, dim3(wblocks), dim3(256), 0, c->stream, sp);
+        if (c->last_changed <= 4096 && !(c->opt.tune[1] & 0x800u)) {
+            // convergence tail: one launch instead of collect + expand + heavy (tune[1] bit 11 = the general path, measurement switch)
+            hipLaunchKernelGGL(hbk::sweep_seed_small_kernel, dim3(sblocks), dim3(256), 0, c->stream, sp);
+        } else {
+            hipLaunchKernelGGL(hbk::sweep_collect_kernel, dim3(sblocks), dim3(256), 0, c->stream, sp);
+            hipLaunchKernelGGL(hbk::sweep_expand_kernel, dim3(wblocks), dim3(256), 0, c->stream, sp);
+            hipLaunchKernelGGL(hbk::sweep_expand_heavy_kernel, dim3(wblocks), dim3(256), 0, c->stream, sp);
+        }
         HB_HIP(hipEventRecord(c->ev[5], c->stream)); // sweep passes: ms_level1 = seed collection + expansion
         auto sweep_blocks = [&](uint64_t rows) { // a wave-iteration covers 16 groups of 128 rows
             const uint64_t waves = (rows + 2047) / 2048;
@@ -1430,6 +1461,7 @@ int hb_begin(hb_ctx *c)
         HB_HIP(hipMemsetAsync(c->d_bits[0], 0, c->bits_words * 4, c->stream));
         HB_HIP(hipMemsetAsync(c->d_bits[1], 0, c->bits_words * 4, c->stream));
         HB_HIP(hipMemsetAsync(c->d_counters, 0, ((size_t)c->max_passes + 1) * hbk::kCounterWords * sizeof(unsigned long long), c->stream));
+        if (c->d_sparse_counts) HB_HIP(hipMemsetAsync(c->d_sparse_counts, 0, 64 * sizeof(unsigned int), c->stream));
         if (c->ksum_len > p.n_pad) // slice padding beyond the rows init_kernel writes (all-reduce mode)
             HB_HIP(hipMemsetAsync(c->d_ksum + p.n_pad, 0, (c->ksum_len - p.n_pad) * sizeof(double), c->stream));
         if (p.n_pad) {

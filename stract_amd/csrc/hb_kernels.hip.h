@@ -110,7 +110,12 @@ struct PassParams {
     uint64_t n, n_pad;
     uint64_t slice_lo, slice_hi; // rows whose Kahan state this rank owns
     double t_plus_1;          // (t + 1) as f64, harmonic.rs:174
+    // bitmap passes: one bit per 2^summary_shift words of bits_rd (node rows) = "some node of that range changed", at most
+    // kSummaryWords words, staged in LDS by frontier_kernel so that most indices are rejected without a global load
+    const uint32_t *summary;
+    uint32_t summary_shift, summary_words;
 };
+constexpr uint32_t kSummaryWords = 8192; // 32 KB of LDS: 256 Ki summary bits
 
 // ---- HyperLogLog<64>::size(), one quad per counter -------------------------------------
 // slice::binary_search_by of Rust >= 1.82 (see oracle/hb_oracle.c)
@@ -289,7 +294,7 @@ __device__ __forceinline__ bool kahan_update(double &sum, double &err, uint64_t 
 //           (64 rows) are merged and then run ONCE PER ROW, lane (g, q) taking row g of the q-th pending tile, instead
 //           of four times redundantly per quad; same arithmetic per row, same bits.
 template <bool REAL, bool FRONTIER, bool FUSED, bool STATS, int UNROLL, bool INIT = false, bool EPI4 = false>
-__global__ __launch_bounds__(256) void pass_kernel(const PassParams p)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((REAL && UNROLL >= 4) ? 3 : 4))) void pass_kernel(const PassParams p)
 {
     __shared__ double s_raw[FUSED ? kTableLen : 1];
     __shared__ double s_bias[FUSED ? kTableLen : 1];
@@ -325,6 +330,15 @@ __global__ __launch_bounds__(256) void pass_kernel(const PassParams p)
     // sources each, so that chain, not bandwidth, bounded the node-row kernel.
     constexpr bool kDenseReal = REAL && !FRONTIER;
     constexpr bool kEpi4 = EPI4 && kDenseReal && FUSED;
+    // pass 0 (INIT): per wave 16 scratch counters of 64 x u32 (one per row of the tile), register r of row g at word
+    // (r + 4 g) & 63 of the row - the rotation spreads the lanes' 16-byte read-backs over all LDS banks
+    __shared__ uint4 s_init4[INIT ? 4 * 16 * 16 : 1];
+    uint32_t *init_row = (uint32_t *)s_init4 + (INIT ? (wave * 16 + g) * 64 : 0);
+    bool init_used = false;
+    if (INIT) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) s_init4[(wave * 16 + g) * 16 + ((4 * q + k + g) & 15)] = make_uint4(0, 0, 0, 0);
+    }
     // deferred epilogue (kEpi4): per wave the first row / Kahan-dirty word of the pending tiles, per lane ITS pending row
     __shared__ uint64_t s_prow16[kEpi4 ? 4 : 1][4];
     __shared__ uint32_t s_pkd16[kEpi4 ? 4 : 1][4];
@@ -422,7 +436,9 @@ __global__ __launch_bounds__(256) void pass_kernel(const PassParams p)
             for (uint64_t e = beg; e < end; e += 4 * UNROLL) {
                 uint32_t idx[UNROLL];
                 if (INIT && real_src) {
-                    // pass 0: the sources' single registers come with the edge list
+                    // pass 0: the sources' single registers come with the edge list.  Each lane max-accumulates ITS sources
+                    // into the row's 64 x u32 scratch counter in LDS (one ds_max_u32 per source) - nothing is broadcast
+                    // to the other lanes of the quad and no lane tests registers that are not its own
 #pragma unroll
                     for (int u = 0; u < UNROLL; u++) {
                         const uint64_t ee = e + 4 * u + q;
@@ -430,15 +446,10 @@ __global__ __launch_bounds__(256) void pass_kernel(const PassParams p)
                     }
 #pragma unroll
                     for (int u = 0; u < UNROLL; u++) {
-#pragma unroll
-                        for (int k = 0; k < 4; k++) {
-                            const uint32_t v = k == 0 ? quad_bcast<0>(idx[u]) : k == 1 ? quad_bcast<1>(idx[u]) : k == 2 ? quad_bcast<2>(idx[u]) : quad_bcast<3>(idx[u]);
-                            const uint32_t j = v & 63u;
-                            const uint32_t x = ((j >> 4) == (uint32_t)q) ? ((v >> 8) << ((j & 3u) * 8u)) : 0u;
-                            const uint32_t wsel = (j & 15u) >> 2;
-                            acc_merge(acc, make_uint4(wsel == 0 ? x : 0u, wsel == 1 ? x : 0u, wsel == 2 ? x : 0u, wsel == 3 ? x : 0u));
-                        }
+                        const uint32_t v = idx[u];
+                        if (v >> 8) __hip_atomic_fetch_max(&init_row[((v & 63u) + 4u * (uint32_t)g) & 63u], v >> 8, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     }
+                    init_used = true;
                     continue;
                 }
 #pragma unroll
@@ -498,6 +509,26 @@ __global__ __launch_bounds__(256) void pass_kernel(const PassParams p)
                         for (int j = 0; j < 4; j++) acc_merge(acc, r[u][j]);
                     }
                 }
+            }
+        }
+        if (INIT) {
+            // the rows' scratch counters -> register blocks (lane q: registers 16 q .. 16 q + 15), scratch cleared for the next tile
+            if (__ballot(init_used)) { // wave-uniform: some row of this tile streamed real sources
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                uint32_t wv[4];
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    uint4 *cell = &s_init4[(wave * 16 + g) * 16 + ((4 * q + k + g) & 15)]; // registers 16 q + 4 k .. + 3
+                    const uint4 c = *cell;
+                    *cell = make_uint4(0, 0, 0, 0);
+                    wv[k] = c.x | (c.y << 8) | (c.z << 16) | (c.w << 24);
+                }
+                acc_merge(acc, make_uint4(wv[0], wv[1], wv[2], wv[3]));
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                init_used = false;
             }
         }
         // ---- row epilogue (quad-uniform decisions come from ballots)
@@ -592,6 +623,20 @@ __global__ __launch_bounds__(256) void pass_kernel(const PassParams p)
     }
 }
 
+// summary bit j = OR of the words [j << shift, (j + 1) << shift) of the node rows' changed bitmap (`words` words)
+__global__ __launch_bounds__(256) void summary_kernel(const uint32_t *bits, uint64_t words, uint32_t shift, uint32_t *summary, uint32_t summary_words)
+{
+    const uint64_t j = (uint64_t)blockIdx.x * 256 + threadIdx.x; // summary bit; the grid covers summary_words * 32 bits exactly
+    uint32_t any = 0;
+    const uint64_t w0 = j << shift, w1 = (j + 1) << shift;
+    for (uint64_t w = w0; w < w1 && w < words; w++) any |= bits[w];
+    const uint64_t bal = __ballot(any != 0);
+    if ((threadIdx.x & 63) == 0 && (j >> 5) + 1 < (uint64_t)summary_words + 1) {
+        summary[j >> 5] = (uint32_t)bal;
+        if ((j >> 5) + 1 < summary_words) summary[(j >> 5) + 1] = (uint32_t)(bal >> 32);
+    }
+}
+
 // ---- the bitmap (frontier) pass, restructured ------------------------------------------------------------------------
 // Same rows, same semantics and same bits as pass_kernel<REAL, FRONTIER = true, ...> (a source is gathered only if its
 // changed bit is set; rows nothing happened to are left alone), but built for what bounds that pass: with few active
@@ -601,20 +646,28 @@ __global__ __launch_bounds__(256) void pass_kernel(const PassParams p)
 // together with the row's own counter: three round trips per row instead of up to fourteen.  Gather slots in which no
 // quad of the wave has an active source are skipped altogether (wave-uniform test on a ballot).
 // W = index slots per lane and batch: 16 (64 sources per quad: hub chunks) or 4 (16 sources: node rows have ~5)
-template <bool REAL, bool FUSED, bool STATS, int W>
+// SUMMARY: a two-level changed test - a coarse summary of the node rows' changed bitmap (one bit per 2^k words, <= 32 KB)
+// is staged in LDS; an index whose summary bit is clear is dropped without touching the bitmap in global memory (late in a
+// run the changed nodes are the cold ones, while most edges come from hot nodes: most indices end there).  Real sources only.
+template <bool REAL, bool FUSED, bool STATS, int W, bool SUMMARY>
 __global__ __launch_bounds__(256) void frontier_kernel(const PassParams p)
 {
     __shared__ double s_raw[FUSED ? kTableLen : 1];
     __shared__ double s_bias[FUSED ? kTableLen : 1];
     __shared__ uint8_t s_lc[68];
+    __shared__ uint32_t s_sum[SUMMARY ? kSummaryWords : 1];
     if (FUSED) {
         for (int i = threadIdx.x; i < kTableLen; i += 256) {
             s_raw[i] = p.raw[i];
             s_bias[i] = p.bias[i];
         }
         if (threadIdx.x < 65) s_lc[threadIdx.x] = p.lc[threadIdx.x];
-        __syncthreads();
     }
+    if (SUMMARY) {
+        for (uint32_t i = threadIdx.x; i < p.summary_words; i += 256) s_sum[i] = p.summary[i];
+    }
+    if (FUSED || SUMMARY) __syncthreads();
+    const uint32_t sum_shift = SUMMARY ? p.summary_shift + 5u : 0u; // node index -> summary bit
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int g = lane >> 2, q = lane & 3;
@@ -687,6 +740,15 @@ __global__ __launch_bounds__(256) void frontier_kernel(const PassParams p)
             const uint32_t first = quad_bcast<0>(idx[0]);
             const bool real_src = first < p.n_pad;
             const uint4 *base = real_src ? p.rd : (const uint4 *)(p.part - p.n_pad * 4);
+            if (SUMMARY && real_src) { // quad-uniform: the row's sources are nodes
+#pragma unroll
+                for (int j = 0; j < W; j++) {
+                    if (idx[j] != kNone) {
+                        const uint32_t sb = idx[j] >> sum_shift;
+                        if (!((s_sum[sb >> 5] >> (sb & 31u)) & 1u)) idx[j] = kNone;
+                    }
+                }
+            }
             // ---- round trip 2: the changed bits of all of them
             uint32_t wb[W];
 #pragma unroll
@@ -814,7 +876,8 @@ struct SweepParams {
     uint32_t *touch;           // 1 bit per work row: has an active source / must be revisited
     uint32_t *seeds;           // nodes changed in the previous pass (capacity n_pad)
     uint32_t *heavy;           // seeds with very long reader lists (expanded by the whole grid)
-    unsigned int *counts;      // [0] seeds, [1] heavy seeds
+    unsigned int *counts;      // this pass' slot: [0] seeds, [1] heavy seeds
+    unsigned int *counts_next; // the other slot (zeroed by this pass' first kernel for the next sweep pass)
 };
 
 __device__ __forceinline__ void touch_set(uint32_t *touch, uint32_t r)
@@ -830,6 +893,7 @@ __device__ __forceinline__ void touch_set(uint32_t *touch, uint32_t r)
 // cheap path of sweep_rows_kernel<true>, which reads those two bitmaps next to the touch bitmap.
 __global__ __launch_bounds__(256) void sweep_collect_kernel(const SweepParams sp)
 {
+    if (blockIdx.x == 0 && threadIdx.x < 2) sp.counts_next[threadIdx.x] = 0; // last used two passes ago
     const uint64_t words = sp.p.n_pad >> 5;
     const int lane = threadIdx.x & 63;
     const uint64_t stride = (uint64_t)gridDim.x * 256;
@@ -912,6 +976,45 @@ __global__ __launch_bounds__(256) void sweep_expand_kernel(const SweepParams sp)
             const uint32_t oex = __shfl(excl, lo);
             const uint64_t ob = ((uint64_t)__shfl(bhi, lo) << 32) | __shfl(blo, lo);
             if (item < total) touch_set(sp.touch, sp.out_rows[ob + (item - oex)]);
+        }
+    }
+}
+
+// Convergence tail (a few thousand changed nodes at most): seed collection and expansion in ONE launch - every lane takes a
+// word of the changed bitmap and walks the reader lists of its set bits itself; lists longer than 64 entries are walked by
+// the whole wave (a hub that still changes this late is rare but must not serialise on one lane).  No seed list, no counts.
+__global__ __launch_bounds__(256) void sweep_seed_small_kernel(const SweepParams sp)
+{
+    if (blockIdx.x == 0 && threadIdx.x < 2) { // unused here: both slots are left clean for whichever pass collects seeds next
+        sp.counts[threadIdx.x] = 0;
+        sp.counts_next[threadIdx.x] = 0;
+    }
+    const uint64_t words = sp.p.n_pad >> 5;
+    const int lane = threadIdx.x & 63;
+    const uint64_t stride = (uint64_t)gridDim.x * 256;
+    for (uint64_t w0 = (uint64_t)blockIdx.x * 256; w0 < words; w0 += stride) { // wave-uniform trip count
+        const uint64_t w = w0 + threadIdx.x;
+        uint32_t ch = (w < words) ? sp.p.bits_rd[w] : 0u;
+        if (!__ballot(ch != 0)) continue;
+        uint32_t lng = 0; // this lane's seeds with long reader lists
+        while (ch) {
+            const int b = __ffs((int)ch) - 1;
+            ch &= ch - 1;
+            const uint64_t u = (w << 5) + (uint64_t)b;
+            const uint64_t kb = sp.out_ptr[u], ke = sp.out_ptr[u + 1];
+            if (ke - kb > 64) lng |= 1u << b;
+            else
+                for (uint64_t k = kb; k < ke; k++) touch_set(sp.touch, sp.out_rows[k]);
+        }
+        uint64_t owners;
+        while ((owners = __ballot(lng != 0)) != 0) {
+            const int src = __ffsll((long long)owners) - 1;
+            const uint32_t m = __shfl(lng, src);
+            const int b = __ffs((int)m) - 1;
+            if (lane == src) lng &= lng - 1;
+            const uint64_t u = ((w0 + (uint64_t)(threadIdx.x & ~63) + (uint64_t)src) << 5) + (uint64_t)b;
+            const uint64_t kb = sp.out_ptr[u], ke = sp.out_ptr[u + 1];
+            for (uint64_t k = kb + lane; k < ke; k += 64) touch_set(sp.touch, sp.out_rows[k]);
         }
     }
 }

@@ -152,6 +152,9 @@ VARIANTS = {
     "old_frontier_loop": dict(chunk=8, tune=(0, 0x200, 101, 0, 0, 0, 1000000)),      # bitmap passes through pass_kernel<.., FRONTIER>
     "frontier_always_chunk128": dict(chunk=128, tune=(0, 0, 101, 0, 0, 0, 1000000)), # rows with > 64 sources: two batches per hub chunk
     "frontier_always_pass_stats": dict(flags=_lib.HB_FLAG_PASS_STATS, tune=(0, 0, 101, 0, 0, 0, 1000000)),
+    "sweep_general_seed_path": dict(chunk=8, tune=(0, 0x800, 101, 0, 0, 0, 1)),        # collect + expand + heavy also in the tail
+    "frontier_no_summary": dict(tune=(0, 0x400, 101, 0, 0, 0, 1000000)),             # one-level changed test
+    "frontier_coarse_summary": dict(tune=(0, 2 << 16, 101, 0, 0, 0, 1000000)),       # 4 summary words: one bit covers several bitmap words
 }
 
 
