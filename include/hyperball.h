@@ -84,7 +84,10 @@ typedef struct hb_edge {
 #define HB_FLAG_CHANGED_ONLY  0x1000u /* with HB_FLAG_DEST_PARTITION: after the changed bits (all-gather) only the counters that
                                          changed in the pass travel (one ncclBroadcast of its packed run per rank) instead of
                                          the all-gather of whole slices: ~18 % fewer bytes in the dense passes of the R-MAT
-                                         configs, ~100 % fewer in the tail; same results */
+                                         configs, ~100 % fewer in the tail; same results.
+                                         With the edge partition: the ranks' "my local merge changed this row" bitmaps are
+                                         all-gathered and OR-ed, and the ncclAllReduce(max, u8) runs over the rows of that union
+                                         only (packed in the same order on every rank) instead of all n counters */
 #define HB_FLAG_REFERENCE_TAIL 0x2000u /* reproduce the reference's changed-node machinery AS WRITTEN instead of its host-level
                                           meaning: the bloom filter of changed nodes with its false
                                           positives (harmonic.rs:221-225,133; bloom/src/lib.rs:85-123), the exact-counting
@@ -112,11 +115,11 @@ typedef struct hb_options {
                              *  [0] workgroups per CU of the pass launches: low byte = node rows (dense 64, bitmap 32),
                              *      second byte = hub chunks (dense 2, bitmap 4)
                              *  [1] low byte: gather unroll 1|2|4 (hub chunks 4, node rows 2); bit 8: dense fused node rows with the
-                             *      old per-tile estimator/Kahan epilogue instead of the once-per-row one; bit 9: bitmap passes with
-                             *      the older per-16-sources loop instead of the batched frontier kernel; bit 10: batched frontier kernel without
-                             *      the LDS-staged summary of the changed bitmap; bit 11: sweep passes always with the three-launch seed
-                             *      collection / expansion, also in the convergence tail (measurement switches); bits 16..23: log2 of the
-                             *      summary capacity in words (tests)
+                             *      old per-tile estimator/Kahan epilogue instead of the once-per-row one; bit 10: experiment - bitmap passes test an
+                             *      LDS-staged summary of the changed bitmap first (measured slower); bit 11: sweep passes always with the three-launch seed
+                             *      collection / expansion, also in the convergence tail (measurement switches); bit 12: edge partition without the
+                             *      merge / all-reduce / epilogue pipeline over row ranges; bits 16..23: log2 of the summary capacity in
+                             *      words (tests)
                              *  [2] frontier mode when A_t < tune[2] % of the edges (50; > 100 = always)
                              *  [3] log2 of the hotness slice width in counters (16 = 4 MiB; 1 = no slices)
                              *  [4] min sources of a chunk at a slice cut (8)
@@ -152,8 +155,8 @@ typedef struct hb_stats {
     uint64_t level1_rows;   /* hub-chunk rows of level 1 (padding rows excluded)            */
     uint64_t direct_edges;  /* REAL edges gathered directly by the node-row launch          */
     uint64_t rows_with_in_edges; /* nodes with >= 1 in-edge: V_t of a dense pass t >= 1      */
-    uint64_t wire_bytes;    /* destination partition: counter + changed-bit bytes this rank received in
-                               the collectives of the last run (what HB_FLAG_CHANGED_ONLY reduces)   */
+    uint64_t wire_bytes;    /* counter + changed-bit bytes this rank received in the collectives of the last run
+                               (what HB_FLAG_CHANGED_ONLY reduces), both decompositions               */
     uint64_t ingest_peak_bytes; /* high-water mark of the device memory the GPU ingest held (record chunks + work
                                    arrays; 0 = host ingest / hb_load_dense)                            */
 } hb_stats;

@@ -114,6 +114,10 @@ struct PassParams {
     // kSummaryWords words, staged in LDS by frontier_kernel so that most indices are rejected without a global load
     const uint32_t *summary;
     uint32_t summary_shift, summary_words;
+    // edge partition + HB_FLAG_CHANGED_ONLY: the unfused node-row launch records which rows its LOCAL merge changed
+    // (lbits); after the union over the ranks only those rows are exchanged, and the epilogue visits only them (ubits)
+    uint32_t *lbits;
+    const uint32_t *ubits;
 };
 constexpr uint32_t kSummaryWords = 8192; // 32 KB of LDS: 256 Ki summary bits
 
@@ -279,11 +283,12 @@ __device__ __forceinline__ bool kahan_update(double &sum, double &err, uint64_t 
     return moved;
 }
 
-// ---- the pass kernel --------------------------------------------------------------------
+// ---- the dense pass kernel ---------------------------------------------------------------
+// Every source of every row is gathered and every row is written (passes in which most sources changed; the bitmap
+// passes - gather only the sources whose changed bit is set - are frontier_kernel below, the data-driven tail the
+// sweep kernels).
 // REAL      rows are nodes (self = rd[row], output = wr[row]); else virtual hub-chunk rows
-//           (self/output = part[row - n_pad], accumulating across passes)
-// FRONTIER  skip sources whose changed bit is clear (results-inert) and
-//           skip rows nothing happened to; else every source is gathered, every row written
+//           (output = part[row - n_pad]: the maximum over all current sources dominates the stored partial)
 // FUSED     REAL only: estimator + Kahan in the same kernel (single GPU)
 // STATS     count active edges / processed rows
 // INIT      pass 0, dense only: every real source's counter is still HyperLogLog::default() + add(id) - ONE register
@@ -293,7 +298,7 @@ __device__ __forceinline__ bool kahan_update(double &sum, double &err, uint64_t 
 // EPI4      dense fused node rows only: the estimator's f64 half and the Kahan update are deferred until four tiles
 //           (64 rows) are merged and then run ONCE PER ROW, lane (g, q) taking row g of the q-th pending tile, instead
 //           of four times redundantly per quad; same arithmetic per row, same bits.
-template <bool REAL, bool FRONTIER, bool FUSED, bool STATS, int UNROLL, bool INIT = false, bool EPI4 = false>
+template <bool REAL, bool FUSED, bool STATS, int UNROLL, bool INIT = false, bool EPI4 = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((REAL && UNROLL >= 4) ? 3 : 4))) void pass_kernel(const PassParams p)
 {
     __shared__ double s_raw[FUSED ? kTableLen : 1];
@@ -328,7 +333,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((REAL && UN
     // rows are requested at the top of the iteration - the per-tile chain of dependent memory round trips
     // (row_ptr -> index -> gather -> self -> size/ksum/kerr) shrinks to (index -> gather); node rows have ~5
     // sources each, so that chain, not bandwidth, bounded the node-row kernel.
-    constexpr bool kDenseReal = REAL && !FRONTIER;
+    constexpr bool kDenseReal = REAL;
     constexpr bool kEpi4 = EPI4 && kDenseReal && FUSED;
     // pass 0 (INIT): per wave 16 scratch counters of 64 x u32 (one per row of the tile), register r of row g at word
     // (r + 4 g) & 63 of the row - the rotation spreads the lanes' 16-byte read-backs over all LDS banks
@@ -420,14 +425,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((REAL && UN
                 }
             }
         }
-        const uint4 *selfp = REAL ? (p.rd + row * 4 + q) : (p.part + (row - p.n_pad) * 4 + q);
         Acc acc;
         acc_zero(acc);
-        // dense mode, node rows: self (prefetched) is always merged.  Dense mode, hub chunks: the maximum
-        // over ALL current sources already dominates the stored partial (counters only grow), so the partial
-        // is overwritten without being read, and no changed bit is kept (nobody tests it in a dense pass).
+        // node rows: self (prefetched) is always merged.  Hub chunks: the maximum over ALL current sources already
+        // dominates the stored partial (counters only grow), so the partial is overwritten without being read, and no
+        // changed bit is kept (nobody tests it in a dense pass).
         if (kDenseReal && valid) acc_merge(acc, selfv);
-        bool lane_act = false;
         if (beg < end) {
             // all sources of one row are of one kind: real nodes (read rd) or virtual rows (read part)
             const uint32_t first = p.src[beg];
@@ -457,38 +460,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((REAL && UN
                     uint64_t ee = e + 4 * u + q;
                     idx[u] = (ee < end) ? ld_stream(&p.src[ee]) : kNone;
                 }
-                if (FRONTIER) {
-#pragma unroll
-                    for (int u = 0; u < UNROLL; u++) {
-                        if (idx[u] != kNone) {
-                            uint32_t wbits = p.bits_rd[idx[u] >> 5];
-                            if (!((wbits >> (idx[u] & 31u)) & 1u)) idx[u] = kNone;
-                        }
-                    }
-                }
 #pragma unroll
                 for (int u = 0; u < UNROLL; u++) {
-                    lane_act |= (idx[u] != kNone);
                     if (STATS && real_src) cnt_active += (idx[u] != kNone);
                 }
-                if (FRONTIER) {
-#pragma unroll
-                    for (int u = 0; u < UNROLL; u++) {
-                        const uint32_t s0 = quad_bcast<0>(idx[u]), s1 = quad_bcast<1>(idx[u]);
-                        const uint32_t s2 = quad_bcast<2>(idx[u]), s3 = quad_bcast<3>(idx[u]);
-                        // max with an all-zero block is the identity: skipped sources stay 0
-                        uint4 r0 = make_uint4(0, 0, 0, 0), r1 = r0, r2 = r0, r3 = r0;
-                        if (s0 != kNone) r0 = base[(uint64_t)s0 * 4 + q];
-                        if (s1 != kNone) r1 = base[(uint64_t)s1 * 4 + q];
-                        if (s2 != kNone) r2 = base[(uint64_t)s2 * 4 + q];
-                        if (s3 != kNone) r3 = base[(uint64_t)s3 * 4 + q];
-                        acc_merge(acc, r0);
-                        acc_merge(acc, r1);
-                        acc_merge(acc, r2);
-                        acc_merge(acc, r3);
-                    }
-                } else {
-                    // dense: branch-free, out-of-row slots re-read the row's first source
+                {
+                    // branch-free: out-of-row slots re-read the row's first source
                     uint4 r[UNROLL][4];
 #pragma unroll
                     for (int u = 0; u < UNROLL; u++) {
@@ -536,33 +513,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((REAL && UN
         const uint32_t kd16 = (REAL && FUSED) ? (uint32_t)((const uint16_t *)p.kdirty)[row16 >> 4] : 0u;
         const bool self_prev = (prev16 >> g) & 1u;
         const bool kd = (kd16 >> g) & 1u;
-        bool need = valid;
-        if (FRONTIER) {
-            const bool touched = ((__ballot(lane_act) >> qshift) & 0xFull) != 0;
-            if (REAL) cnt_rows += (valid && touched && q == 0); // V_t (hb_pass_stats.touched)
-            need = valid && (touched || (REAL && (self_prev || kd)));
-            if (need) {
-                selfv = *selfp;
-                acc_merge(acc, selfv);
-            }
-        }
+        const bool need = valid;
+        (void)self_prev;
         const uint4 accv = acc_value(acc);
-        const bool lane_diff = need && ((!REAL && !FRONTIER) || u4_ne(accv, selfv));
+        const bool lane_diff = need && (!REAL || u4_ne(accv, selfv));
         const uint64_t bal = __ballot(lane_diff);
         const bool changed = ((bal >> qshift) & 0xFull) != 0;
         if (REAL) {
             // lazy double buffer: wr[row] already holds the right value unless the row changed
             // in this or in the previous pass
-            if (need && (!FRONTIER || changed || self_prev)) st_stream(&p.wr[row * 4 + q], accv);
+            if (need) st_stream(&p.wr[row * 4 + q], accv);
         } else {
             if (changed) st_stream(&p.part[(row - p.n_pad) * 4 + q], accv);
         }
         const uint32_t ch16 = pack16(bal);
-        if (FUSED || (!REAL && FRONTIER)) {
-            // changed bits: real rows -> next frontier; virtual rows -> this pass' bits
-            uint16_t *dst = REAL ? (uint16_t *)p.bits_wr : (uint16_t *)p.bits_rd;
-            if (lane == 0 && row16 < row_hi) dst[row16 >> 4] = (uint16_t)ch16;
+        if (FUSED) { // changed bits of the node rows -> next frontier (nobody tests a virtual row's bit in a dense pass)
+            if (lane == 0 && row16 < row_hi) ((uint16_t *)p.bits_wr)[row16 >> 4] = (uint16_t)ch16;
         }
+        if (REAL && !FUSED && p.lbits && lane == 0 && row16 < row_hi) ((uint16_t *)p.lbits)[row16 >> 4] = (uint16_t)ch16;
         if (REAL && FUSED) {
             cnt_changed += __popc(ch16);
             if (changed && q == 0) cnt_out += od;
@@ -615,11 +583,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((REAL && UN
         for (int off = 32; off > 0; off >>= 1) {
             cnt_out += __shfl_down(cnt_out, off);
             if (STATS) cnt_active += __shfl_down(cnt_active, off);
-            if (REAL && FRONTIER) cnt_rows += __shfl_down(cnt_rows, off);
         }
         // cnt_changed is identical in all lanes of the wave (derived from a ballot)
         const unsigned long long v[4] = {cnt_changed, cnt_active, cnt_rows, cnt_out};
-        block_add_counters(p.counters, v, (REAL ? 0x9u : 0u) | (STATS ? 0x2u : 0u) | ((REAL && FRONTIER) ? 0x4u : 0u));
+        block_add_counters(p.counters, v, (REAL ? 0x9u : 0u) | (STATS ? 0x2u : 0u));
     }
 }
 
@@ -638,8 +605,8 @@ __global__ __launch_bounds__(256) void summary_kernel(const uint32_t *bits, uint
 }
 
 // ---- the bitmap (frontier) pass, restructured ------------------------------------------------------------------------
-// Same rows, same semantics and same bits as pass_kernel<REAL, FRONTIER = true, ...> (a source is gathered only if its
-// changed bit is set; rows nothing happened to are left alone), but built for what bounds that pass: with few active
+// A source is gathered only if its changed bit is set (results-inert); rows nothing happened to are
+// left alone (lazy double buffer).  Built for what bounds that pass: with few active
 // sources it is a chain of DEPENDENT round trips per row - index -> changed-bit word -> counter gather, repeated for every
 // 16 sources, then the row's own counter - at a handful of waves per SIMD, not bytes.  Here a quad takes ALL (<= 64)
 // indices of its row in one go (16 per lane), then all their bit words, then issues only the gathers that are needed,
@@ -818,6 +785,7 @@ __global__ __launch_bounds__(256) void frontier_kernel(const PassParams p)
             uint16_t *dst = REAL ? (uint16_t *)p.bits_wr : (uint16_t *)p.bits_rd;
             if (lane == 0 && row16 < row_hi) dst[row16 >> 4] = (uint16_t)ch16;
         }
+        if (REAL && !FUSED && p.lbits && lane == 0 && row16 < row_hi) ((uint16_t *)p.lbits)[row16 >> 4] = (uint16_t)ch16;
         if (REAL && FUSED) {
             cnt_changed += __popc(ch16);
             if (changed && q == 0) cnt_out += p.outdeg[row];
@@ -1304,62 +1272,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void s
     }
 }
 
-// ---- experiment (north-star "LDS-staged counter tiles"; off by default, hb_options.tune[7]) -----------
-// Dense pull over the level-1 hub chunks with the `tile` hottest counters (device rows [0, tile)) staged in
-// LDS once per workgroup: gathers of those sources are served from LDS instead of L2.  Same results as
-// pass_kernel<false,false,false,false,4>; measured against it in profiles/r02*_lds_tile*.txt.
-__global__ __launch_bounds__(256) void hub_lds_tile_kernel(const PassParams p, uint32_t tile)
-{
-    extern __shared__ uint4 s_tile[]; // tile * 4 uint4
-    for (uint32_t i = threadIdx.x; i < tile * 4; i += 256) s_tile[i] = p.rd[i];
-    __syncthreads();
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int g = lane >> 2, q = lane & 3;
-    uint64_t row_lo = p.row_lo, row_hi = p.row_hi, tile0 = blockIdx.x, tstride = gridDim.x;
-    if (p.xcd_map) {
-        const int x = blockIdx.x & 7;
-        row_lo = p.xcd_lo[x];
-        row_hi = p.xcd_hi[x];
-        tile0 = blockIdx.x >> 3;
-        tstride = gridDim.x >> 3;
-    }
-    const uint64_t ntiles = (row_hi - row_lo + 63) >> 6;
-    for (uint64_t t = tile0; t < ntiles; t += tstride) {
-        const uint64_t row = row_lo + (t << 6) + ((uint64_t)wave << 4) + (uint64_t)g;
-        if (row >= row_hi) continue;
-        const uint64_t beg = p.row_ptr[row], end = p.row_ptr[row + 1];
-        Acc acc;
-        acc_zero(acc);
-        if (beg < end) {
-            const uint32_t first = p.src[beg];
-            for (uint64_t e = beg; e < end; e += 16) {
-                uint32_t idx[4];
-#pragma unroll
-                for (int u = 0; u < 4; u++) {
-                    const uint64_t ee = e + 4 * u + q;
-                    idx[u] = (ee < end) ? p.src[ee] : first;
-                }
-                uint4 r[4][4];
-#pragma unroll
-                for (int u = 0; u < 4; u++) {
-                    const uint32_t sv[4] = {quad_bcast<0>(idx[u]), quad_bcast<1>(idx[u]), quad_bcast<2>(idx[u]), quad_bcast<3>(idx[u])};
-#pragma unroll
-                    for (int j = 0; j < 4; j++) {
-                        if (sv[j] < tile) r[u][j] = s_tile[sv[j] * 4 + q];
-                        else r[u][j] = p.rd[(uint64_t)sv[j] * 4 + q];
-                    }
-                }
-#pragma unroll
-                for (int u = 0; u < 4; u++) {
-#pragma unroll
-                    for (int j = 0; j < 4; j++) acc_merge(acc, r[u][j]);
-                }
-            }
-        }
-        p.part[(row - p.n_pad) * 4 + q] = acc_value(acc); // dense: the partial is overwritten unread (see pass_kernel)
-    }
-}
-
 // out-degree histogram of a source list (load time)
 __global__ __launch_bounds__(256) void histogram_kernel(const uint32_t *src, uint64_t m, uint32_t *count)
 {
@@ -1420,8 +1332,14 @@ __global__ __launch_bounds__(256) void epilogue_kernel(const PassParams p)
         const uint32_t kd16 = (uint32_t)((const uint16_t *)p.kdirty)[row16 >> 4];
         const bool self_prev = (prev16 >> g) & 1u;
         const bool kd = (kd16 >> g) & 1u;
+        // changed-only exchange: rows outside the union of the ranks' locally changed rows cannot have changed
+        const uint32_t u16 = p.ubits ? (uint32_t)((const uint16_t *)p.ubits)[row16 >> 4] : 0xFFFFu;
+        if (!(u16 | kd16)) { // wave-uniform: nothing to look at in these 16 rows
+            if (lane == 0 && row16 < p.row_hi) ((uint16_t *)p.bits_wr)[row16 >> 4] = 0;
+            continue;
+        }
         uint4 oldv = make_uint4(0, 0, 0, 0), newv = oldv;
-        if (valid) {
+        if (valid && (((u16 >> g) & 1u) || !p.ubits)) {
             oldv = p.rd[row * 4 + q];
             newv = p.wr[row * 4 + q];
         }
@@ -1502,7 +1420,7 @@ __global__ __launch_bounds__(256) void init_kernel(const uint64_t *id_low, const
         }
     }
     a[row * 4 + q] = v;
-    b[row * 4 + q] = v;
+    (void)b; // `new = old.clone()` (harmonic.rs:67) needs no copy: pass 0 is always dense and writes every row of the other buffer
     // size() of a counter with exactly one register set: 63 zero registers -> the linear-counting branch
     // (hyperloglog.rs:4504-4515) -> lc[63]; the general estimator gives the same value by construction
     // (tests/test_gpu.py compares the cached sizes with the oracle's after hb_begin)
@@ -1548,6 +1466,23 @@ __global__ __launch_bounds__(256) void merge_max_kernel(uint4 *dst, const uint4 
         acc_merge(acc, b);
         dst[i] = acc_value(acc);
     }
+}
+
+// dst |= src word-wise (union of the ranks' locally-changed bitmaps)
+__global__ __launch_bounds__(256) void or_words_kernel(uint32_t *dst, const uint32_t *src, uint64_t words)
+{
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < words; i += (uint64_t)gridDim.x * 256) dst[i] |= src[i];
+}
+// edge partition, changed-only: the all-reduced packed rows go back to their places (quad per row of [0, n_pad))
+__global__ __launch_bounds__(256) void unpack_rows_kernel(uint4 *wr, const uint32_t *bits, const uint64_t *prefix, uint64_t n_pad, const uint4 *pack)
+{
+    const uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    const uint64_t row = t >> 2;
+    if (row >= n_pad) return;
+    const uint32_t w = bits[row >> 5], b = (uint32_t)(row & 31u);
+    if (!((w >> b) & 1u)) return;
+    const uint64_t pos = prefix[row >> 5] + (uint64_t)__popc(w & ((1u << b) - 1u));
+    wr[row * 4 + (t & 3)] = pack[pos * 4 + (t & 3)];
 }
 
 // ---- changed-only exchange (destination partition, HB_FLAG_CHANGED_ONLY) --------------------------------------

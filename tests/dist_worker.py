@@ -47,6 +47,20 @@ def main():
                 if r != rank:
                     pend[rows_r] = old[rows_r]
                     pend[rows_r[ch]] = packed
+        elif mode == "edge_changed":
+            # HB_FLAG_CHANGED_ONLY with the edge partition: every rank marks the rows its LOCAL merge changed, the marks are
+            # all-gathered and OR-ed, and the all-reduce(max) runs over the rows of that union only, packed in ascending
+            # row order (the same on every rank); all other rows keep the old value
+            old = torch.from_numpy(o.registers())
+            mine = (pend != old).any(dim=1).to(torch.uint8)
+            marks = [torch.zeros_like(mine) for _ in range(world)]
+            td.all_gather(marks, mine)
+            union = torch.stack(marks).max(dim=0).values.bool()
+            packed = pend[union].clone()
+            if packed.numel():
+                td.all_reduce(packed, op=td.ReduceOp.MAX)
+            pend[:] = old
+            pend[union] = packed
         elif mode == "dest":
 
             # all-gather of the owned rows (rank r owns the rows r, r + world, ...), padded to equal length

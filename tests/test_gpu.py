@@ -149,12 +149,11 @@ VARIANTS = {
     "banded_frontier_small_direct": dict(chunk=32, tune=(0, 0, 101, 5, 8, 8)),
     # measurement switches of round 3: the older kernels stay bit-identical
     "old_per_tile_epilogue": dict(tune=(0, 0x100)),                                  # dense node rows: estimator/Kahan per quad, not once per row
-    "old_frontier_loop": dict(chunk=8, tune=(0, 0x200, 101, 0, 0, 0, 1000000)),      # bitmap passes through pass_kernel<.., FRONTIER>
     "frontier_always_chunk128": dict(chunk=128, tune=(0, 0, 101, 0, 0, 0, 1000000)), # rows with > 64 sources: two batches per hub chunk
     "frontier_always_pass_stats": dict(flags=_lib.HB_FLAG_PASS_STATS, tune=(0, 0, 101, 0, 0, 0, 1000000)),
     "sweep_general_seed_path": dict(chunk=8, tune=(0, 0x800, 101, 0, 0, 0, 1)),        # collect + expand + heavy also in the tail
-    "frontier_no_summary": dict(tune=(0, 0x400, 101, 0, 0, 0, 1000000)),             # one-level changed test
-    "frontier_coarse_summary": dict(tune=(0, 2 << 16, 101, 0, 0, 0, 1000000)),       # 4 summary words: one bit covers several bitmap words
+    "frontier_summary_experiment": dict(tune=(0, 0x400, 101, 0, 0, 0, 1000000)),     # two-level changed test (LDS summary), off by default
+    "frontier_coarse_summary_experiment": dict(tune=(0, 0x400 | (2 << 16), 101, 0, 0, 0, 1000000)),  # 4 summary words: one bit covers several bitmap words
 }
 
 
@@ -478,7 +477,8 @@ def test_device_plan_equals_host_plan(gpu_ctx_factory):
 
 
 # ---- edge-partition mode ------------------------------------------------------------------------
-@pytest.mark.parametrize("world,mode", [(2, "edge"), (3, "edge"), (2, "dest"), (3, "dest"), (4, "dest"), (2, "dest_changed"), (4, "dest_changed")])
+@pytest.mark.parametrize("world,mode", [(2, "edge"), (3, "edge"), (2, "edge_changed"), (4, "edge_changed"), (2, "dest"), (3, "dest"), (4, "dest"),
+                                        (2, "dest_changed"), (4, "dest_changed")])
 def test_logical_ranks_on_one_device(gpu_ctx_factory, world, mode):
     """SURVEY.md §8(e) caveat: R logical ranks on one device, the collective emulated by
     hb_debug_exchange (edge partition: all-reduce(max); destination partition: all-gather of the
@@ -486,7 +486,7 @@ def test_logical_ranks_on_one_device(gpu_ctx_factory, world, mode):
     g = synth.RmatGraph(12, 40_000)
     o, T, vals, keep, k = _oracle_dense(g.ids, g.row_ptr, g.src)
     flags = _lib.HB_FLAG_NO_RCCL | (_lib.HB_FLAG_DEST_PARTITION if mode.startswith("dest") else 0)
-    flags |= _lib.HB_FLAG_CHANGED_ONLY if mode == "dest_changed" else 0  # packed changed counters instead of whole slices
+    flags |= _lib.HB_FLAG_CHANGED_ONLY if mode.endswith("_changed") else 0  # packed changed counters instead of whole slices / all rows
     split = dist.partition_dense_by_dest if mode.startswith("dest") else dist.partition_dense
     ctxs = []
     try:
@@ -513,6 +513,13 @@ def test_logical_ranks_on_one_device(gpu_ctx_factory, world, mode):
         for c in ctxs:
             c.finish()
             _check_final(c, g.ids, T, vals, keep, c.stats())
+        if mode.startswith("edge"):
+            # bytes a rank receives over the run: the full all-reduce moves 2 (w-1)/w n 64 B in each of the T passes; the
+            # changed-only form only the union of the locally changed rows (+ the ranks' bitmaps): fewer bytes in every pass
+            n_pad = (g.n + 63) // 64 * 64
+            full = T * 2 * (world - 1) * n_pad * 64 // world
+            wb = ctxs[0].stats()["wire_bytes"]
+            assert (wb == 0) if mode == "edge" else (0 < wb < 0.8 * full), (mode, wb, full)
     finally:
         for c in ctxs:
             c.close()
@@ -550,7 +557,7 @@ def test_dest_partition_ignores_foreign_records(gpu_ctx_factory):
             c.close()
 
 
-@pytest.mark.parametrize("dest", [False, True, "changed"])
+@pytest.mark.parametrize("dest", [False, True, "changed", "edge_changed"])
 def test_rccl_call_path_single_rank(gpu_ctx_factory, dest):
     """A 1-rank RCCL communicator: the collectives of both decompositions run for real -
     ncclAllReduce(max, u8) + epilogue (edge partition), grouped ncclAllGather of the counter / changed-bit
@@ -558,7 +565,8 @@ def test_rccl_call_path_single_rank(gpu_ctx_factory, dest):
     g = synth.RmatGraph(12, 40_000)
     o, T, vals, keep, k = _oracle_dense(g.ids, g.row_ptr, g.src)
     uid = _lib.rccl_unique_id()
-    flags = _lib.HB_FLAG_RCCL_SELF | (_lib.HB_FLAG_DEST_PARTITION if dest else 0) | (_lib.HB_FLAG_CHANGED_ONLY if dest == "changed" else 0)
+    flags = _lib.HB_FLAG_RCCL_SELF | (_lib.HB_FLAG_DEST_PARTITION if dest and dest != "edge_changed" else 0)
+    flags |= _lib.HB_FLAG_CHANGED_ONLY if dest in ("changed", "edge_changed") else 0
     with gpu_ctx_factory(flags=flags, rccl_id=uid) as ctx:
         ctx.load_dense(g.ids, g.row_ptr, g.src)
         st = ctx.run()
