@@ -118,7 +118,7 @@ typedef struct hb_options {
                              *      old per-tile estimator/Kahan epilogue instead of the once-per-row one; bit 10: experiment - bitmap passes test an
                              *      LDS-staged summary of the changed bitmap first (measured slower); bit 11: sweep passes always with the three-launch seed
                              *      collection / expansion, also in the convergence tail (measurement switches); bit 12: edge partition without the
-                             *      merge / all-reduce / epilogue pipeline over row ranges; bits 16..23: log2 of the summary capacity in
+                             *      merge / all-reduce / epilogue pipeline over row ranges; bit 13: bitmap passes without the hot-prefix shortcut; bits 16..23: log2 of the summary capacity in
                              *      words (tests)
                              *  [2] frontier mode when A_t < tune[2] % of the edges (50; > 100 = always)
                              *  [3] log2 of the hotness slice width in counters (16 = 4 MiB; 1 = no slices)

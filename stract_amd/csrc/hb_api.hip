@@ -59,6 +59,7 @@ struct hb_ctx {
     uint32_t *d_bits[2] = {nullptr, nullptr};
     uint32_t *d_kdirty = nullptr;
     uint32_t *d_summary = nullptr; // bitmap passes: coarse summary of the changed bitmap (hb_kernels.hip.h frontier_kernel)
+    uint32_t *d_hot = nullptr, *d_hot_seg = nullptr; // bitmap passes: hot-prefix shortcut (bound + short list), per-segment counts
     double *d_ksum = nullptr, *d_kerr = nullptr;
     uint64_t *d_size = nullptr;
     uint64_t *d_idlow = nullptr;
@@ -186,6 +187,7 @@ void free_graph_buffers(hb_ctx *c)
     c->d_bits[0] = c->d_bits[1] = nullptr;
     c->d_kdirty = nullptr;
     c->d_summary = nullptr;
+    c->d_hot = c->d_hot_seg = nullptr;
     c->d_ksum = c->d_kerr = nullptr;
     c->d_size = nullptr;
     c->d_idlow = nullptr;
@@ -456,6 +458,8 @@ int plan_and_upload(hb_ctx *c, DeviceCsr *csr_in, uint64_t m_eff)
     if ((rc = dev_alloc(c, &c->d_bits[1], c->bits_words))) return rc;
     if ((rc = dev_alloc(c, &c->d_kdirty, p.n_pad / 32 + 2))) return rc;
     if ((rc = dev_alloc(c, &c->d_summary, hbk::kSummaryWords + 2))) return rc;
+    if ((rc = dev_alloc(c, &c->d_hot, 2 + hbk::kHotList + 6))) return rc;
+    if ((rc = dev_alloc(c, &c->d_hot_seg, hbk::kHotMaxSegs + 2))) return rc;
     // Kahan ownership: one contiguous slice of rows per rank (multiple of 64 rows)
     const uint64_t world = c->comm ? (uint64_t)c->opt.world_size : 1;
     c->slice_rows = dest_mode(c) ? p.slice : ((p.n_pad + world - 1) / world + 63) / 64 * 64;
@@ -930,6 +934,15 @@ int step_local(hb_ctx *c)
                                (const uint64_t *)c->d_idlow, (const uint32_t *)c->d_sid_of, p.n_pad, c->bloom_bits, c->d_bits[c->cur]);
             HB_HIP(hipGetLastError());
         }
+    }
+    if (frontier && !sparse && !(c->opt.tune[1] & 0x2000u) && p.n_pad) {
+        // bitmap pass: hot-prefix shortcut - below which node row did (almost) nothing change?  (tune[1] bit 13 = off)
+        const uint64_t words = p.n_pad / 32;
+        const uint32_t nseg = (uint32_t)std::min<uint64_t>((words + hbk::kHotSegWords - 1) / hbk::kHotSegWords, hbk::kHotMaxSegs);
+        hipLaunchKernelGGL(hbk::hot_count_kernel, dim3(nseg), dim3(256), 0, c->stream, (const uint32_t *)c->d_bits[c->cur], words, c->d_hot_seg);
+        hipLaunchKernelGGL(hbk::hot_find_kernel, dim3(1), dim3(64), 0, c->stream, (const uint32_t *)c->d_bits[c->cur], words, (const uint32_t *)c->d_hot_seg, nseg,
+                           c->d_hot);
+        pp.hot = c->d_hot;
     }
     if (frontier && !sparse && (c->opt.tune[1] & 0x400u) && !(c->opt.flags & HB_FLAG_PASS_STATS) && p.n_pad) {
         // experiment (tune[1] bit 10; measured SLOWER, profiles/r03c_*: the bitmap pass 1.64 -> 1.97 ms at C3): a coarse summary

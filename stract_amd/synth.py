@@ -130,11 +130,43 @@ CONFIGS = {
 }
 
 
+class CachedGraph:
+    """The reduced form of a generated graph (ids, row_ptr, src) read back from .npy files: for profiling scripts that run
+    the same big config several times in one session (HB_SYNTH_CACHE=<dir>); no record-stream export."""
+
+    def __init__(self, prefix):
+        self.ids = np.load(prefix + "_ids.npy", mmap_mode="r").view(U128).reshape(-1)
+        self.row_ptr = np.load(prefix + "_row_ptr.npy", mmap_mode="r")
+        self.src = np.load(prefix + "_src.npy", mmap_mode="r")
+        self.n, self.m = len(self.ids), len(self.src)
+
+    @staticmethod
+    def save(g, prefix):
+        np.save(prefix + "_ids.npy", np.ascontiguousarray(g.ids).view(np.uint64).reshape(-1, 2))
+        np.save(prefix + "_row_ptr.npy", g.row_ptr)
+        np.save(prefix + "_src.npy", g.src)
+
+    def id_low64(self):
+        return np.ascontiguousarray(self.ids["lo"])
+
+    def close(self):
+        pass
+
+
 def make_config(name):
     """(graph, scale, label) of a named BASELINE config, or of 'scale:m' / 'scale:m:tail_permille:ratio_permille:fanin'."""
     if name in CONFIGS:
         cfg = CONFIGS[name]
+        label = "%s (R-MAT scale %d, a,b,c,d=.57,.19,.19,.05, seed 0x5712AC7)" % (cfg["label"], cfg["scale"])
+        cache = os.environ.get("HB_SYNTH_CACHE")
+        if cache:
+            prefix = os.path.join(cache, "hb_synth_%s" % name)
+            if os.path.exists(prefix + "_src.npy"):
+                return CachedGraph(prefix), cfg["scale"], label
         g = RmatGraph(cfg["scale"], cfg["m"], tail=cfg.get("tail"))
+        if cache:
+            os.makedirs(cache, exist_ok=True)
+            CachedGraph.save(g, prefix)
         label = "%s (R-MAT scale %d, a,b,c,d=.57,.19,.19,.05, seed 0x5712AC7)" % (cfg["label"], cfg["scale"])
         return g, cfg["scale"], label
     parts = [int(x) for x in name.split(":")]

@@ -135,5 +135,8 @@ fn main() {
         let to = if k % 3 == 0 { format!("tail{}.com/about", k + 1) } else { format!("tail{}.com", k + 1) };
         mixed.push((from, to, none));
     }
-    dump_with_pages("mixed_pages", &build(&out.join("g_mixed"), &mixed, 700), out, true);
+    // ONE commit = one segment: what a ForwardlinksQuery returns depends on the documents' order inside a segment (its
+    // LinksScorer de-duplicates neighbouring documents per segment, query/raw/links.rs:115-232), and the consumers of this
+    // file take `pages` as one segment in doc order (hb_load_tail_edges / hbo.faithful_run(.., pages))
+    dump_with_pages("mixed_pages", &build(&out.join("g_mixed"), &mixed, usize::MAX), out, true);
 }
