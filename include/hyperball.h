@@ -114,12 +114,10 @@ typedef struct hb_options {
     uint32_t tune[8];       /* tuning knobs, 0 = default:
                              *  [0] workgroups per CU of the pass launches: low byte = node rows (dense 64, bitmap 32),
                              *      second byte = hub chunks (dense 2, bitmap 4)
-                             *  [1] low byte: gather unroll 1|2|4 (hub chunks 4, node rows 2); bit 8: dense fused node rows with the
-                             *      old per-tile estimator/Kahan epilogue instead of the once-per-row one; bit 10: experiment - bitmap passes test an
-                             *      LDS-staged summary of the changed bitmap first (measured slower); bit 11: sweep passes always with the three-launch seed
-                             *      collection / expansion, also in the convergence tail (measurement switches); bit 12: edge partition without the
-                             *      merge / all-reduce / epilogue pipeline over row ranges; bit 13: bitmap passes without the hot-prefix shortcut; bits 16..23: log2 of the summary capacity in
-                             *      words (tests)
+                             *  [1] low byte: gather unroll 1|2|4 (hub chunks 4, node rows 2); measurement switches: bit 8 = dense fused node
+                             *      rows with the per-tile estimator/Kahan epilogue instead of the once-per-row one; bit 11 = sweep passes
+                             *      always with the three-launch seed collection / expansion, also in the convergence tail; bit 12 = edge
+                             *      partition without the merge / all-reduce / epilogue pipeline over row ranges
                              *  [2] frontier mode when A_t < tune[2] % of the edges (50; > 100 = always)
                              *  [3] log2 of the hotness slice width in counters (16 = 4 MiB; 1 = no slices)
                              *  [4] min sources of a chunk at a slice cut (8)

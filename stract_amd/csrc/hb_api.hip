@@ -58,8 +58,6 @@ struct hb_ctx {
     uint4 *d_part = nullptr;
     uint32_t *d_bits[2] = {nullptr, nullptr};
     uint32_t *d_kdirty = nullptr;
-    uint32_t *d_summary = nullptr; // bitmap passes: coarse summary of the changed bitmap (hb_kernels.hip.h frontier_kernel)
-    uint32_t *d_hot = nullptr, *d_hot_seg = nullptr; // bitmap passes: hot-prefix shortcut (bound + short list), per-segment counts
     double *d_ksum = nullptr, *d_kerr = nullptr;
     uint64_t *d_size = nullptr;
     uint64_t *d_idlow = nullptr;
@@ -186,8 +184,6 @@ void free_graph_buffers(hb_ctx *c)
     c->d_part = nullptr;
     c->d_bits[0] = c->d_bits[1] = nullptr;
     c->d_kdirty = nullptr;
-    c->d_summary = nullptr;
-    c->d_hot = c->d_hot_seg = nullptr;
     c->d_ksum = c->d_kerr = nullptr;
     c->d_size = nullptr;
     c->d_idlow = nullptr;
@@ -457,9 +453,6 @@ int plan_and_upload(hb_ctx *c, DeviceCsr *csr_in, uint64_t m_eff)
     if ((rc = dev_alloc(c, &c->d_bits[0], c->bits_words))) return rc;
     if ((rc = dev_alloc(c, &c->d_bits[1], c->bits_words))) return rc;
     if ((rc = dev_alloc(c, &c->d_kdirty, p.n_pad / 32 + 2))) return rc;
-    if ((rc = dev_alloc(c, &c->d_summary, hbk::kSummaryWords + 2))) return rc;
-    if ((rc = dev_alloc(c, &c->d_hot, 2 + hbk::kHotList + 6))) return rc;
-    if ((rc = dev_alloc(c, &c->d_hot_seg, hbk::kHotMaxSegs + 2))) return rc;
     // Kahan ownership: one contiguous slice of rows per rank (multiple of 64 rows)
     const uint64_t world = c->comm ? (uint64_t)c->opt.world_size : 1;
     c->slice_rows = dest_mode(c) ? p.slice : ((p.n_pad + world - 1) / world + 63) / 64 * 64;
@@ -614,19 +607,14 @@ void launch_pass(hb_ctx *c, const hbk::PassParams &pp, bool real, bool frontier,
         blocks = std::min<uint64_t>(ntiles, (uint64_t)c->num_cu * 8);
         if (pp.xcd_map) blocks = std::max<uint64_t>((blocks + 7) / 8 * 8, 8);
     }
-    if (frontier && real && pp.summary && !(c->opt.tune[0] & 0xFFu)) {
-        // (experiment) every workgroup stages the 32 KB summary in LDS: a few per CU (its LDS holds 5), not dozens
-        blocks = std::min<uint64_t>(ntiles, (uint64_t)c->num_cu * 5);
-    }
     dim3 grid((unsigned)blocks);
     if (frontier) {
         // the bitmap pass: all indices / all bit words / needed gathers of a row as three batched round trips
         hipStream_t st = c->stream;
 #define HB_FRONT(R, F) \
     do { \
-        if (stats) hipLaunchKernelGGL((hbk::frontier_kernel<R, F, true, (R ? 4 : 16), false>), grid, dim3(256), 0, st, pp); \
-        else if (pp.summary) hipLaunchKernelGGL((hbk::frontier_kernel<R, F, false, (R ? 4 : 16), true>), grid, dim3(256), 0, st, pp); \
-        else hipLaunchKernelGGL((hbk::frontier_kernel<R, F, false, (R ? 4 : 16), false>), grid, dim3(256), 0, st, pp); \
+        if (stats) hipLaunchKernelGGL((hbk::frontier_kernel<R, F, true, (R ? 4 : 16)>), grid, dim3(256), 0, st, pp); \
+        else hipLaunchKernelGGL((hbk::frontier_kernel<R, F, false, (R ? 4 : 16)>), grid, dim3(256), 0, st, pp); \
     } while (0)
         if (real && fused) HB_FRONT(true, true);
         else if (real) HB_FRONT(true, false);
@@ -934,32 +922,6 @@ int step_local(hb_ctx *c)
                                (const uint64_t *)c->d_idlow, (const uint32_t *)c->d_sid_of, p.n_pad, c->bloom_bits, c->d_bits[c->cur]);
             HB_HIP(hipGetLastError());
         }
-    }
-    if (frontier && !sparse && !(c->opt.tune[1] & 0x2000u) && p.n_pad) {
-        // bitmap pass: hot-prefix shortcut - below which node row did (almost) nothing change?  (tune[1] bit 13 = off)
-        const uint64_t words = p.n_pad / 32;
-        const uint32_t nseg = (uint32_t)std::min<uint64_t>((words + hbk::kHotSegWords - 1) / hbk::kHotSegWords, hbk::kHotMaxSegs);
-        hipLaunchKernelGGL(hbk::hot_count_kernel, dim3(nseg), dim3(256), 0, c->stream, (const uint32_t *)c->d_bits[c->cur], words, c->d_hot_seg);
-        hipLaunchKernelGGL(hbk::hot_find_kernel, dim3(1), dim3(64), 0, c->stream, (const uint32_t *)c->d_bits[c->cur], words, (const uint32_t *)c->d_hot_seg, nseg,
-                           c->d_hot);
-        pp.hot = c->d_hot;
-    }
-    if (frontier && !sparse && (c->opt.tune[1] & 0x400u) && !(c->opt.flags & HB_FLAG_PASS_STATS) && p.n_pad) {
-        // experiment (tune[1] bit 10; measured SLOWER, profiles/r03c_*: the bitmap pass 1.64 -> 1.97 ms at C3): a coarse summary
-        // of the changed bitmap staged in LDS, tested before the bitmap in global memory
-        const uint64_t words = p.n_pad / 32;
-        uint32_t shift = 0;
-        // tune[1] bits 16..23: log2 of the summary capacity in words (0 = the 8192 words that fit LDS; tests shrink it)
-        const uint32_t cap_log2 = (c->opt.tune[1] >> 16) & 0xFFu;
-        const uint64_t cap_words = (cap_log2 >= 1 && cap_log2 < 13) ? (1ull << cap_log2) : (uint64_t)hbk::kSummaryWords;
-        while (((words + (1ull << shift) - 1) >> shift) > cap_words * 32) shift++;
-        const uint64_t sbits = (words + (1ull << shift) - 1) >> shift;
-        const uint32_t swords = (uint32_t)((sbits + 63) / 64 * 2); // whole 64-bit ballots
-        hipLaunchKernelGGL(hbk::summary_kernel, dim3(swords * 32 / 256 + 1), dim3(256), 0, c->stream, (const uint32_t *)c->d_bits[c->cur], words, shift,
-                           c->d_summary, swords);
-        pp.summary = c->d_summary;
-        pp.summary_shift = shift;
-        pp.summary_words = swords;
     }
     if (sparse) {
         // sweep mode: changed nodes -> touch bits of their readers; then the levels, then the node rows

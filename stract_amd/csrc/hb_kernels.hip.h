@@ -110,21 +110,11 @@ struct PassParams {
     uint64_t n, n_pad;
     uint64_t slice_lo, slice_hi; // rows whose Kahan state this rank owns
     double t_plus_1;          // (t + 1) as f64, harmonic.rs:174
-    // bitmap passes: one bit per 2^summary_shift words of bits_rd (node rows) = "some node of that range changed", at most
-    // kSummaryWords words, staged in LDS by frontier_kernel so that most indices are rejected without a global load
-    const uint32_t *summary;
-    uint32_t summary_shift, summary_words;
     // edge partition + HB_FLAG_CHANGED_ONLY: the unfused node-row launch records which rows its LOCAL merge changed
     // (lbits); after the union over the ranks only those rows are exchanged, and the epilogue visits only them (ubits)
     uint32_t *lbits;
     const uint32_t *ubits;
-    // bitmap passes: hot-prefix shortcut (hot_find_kernel): below node row hot[0] only the hot[1] <= 8 rows hot[2..] changed
-    const uint32_t *hot;
 };
-constexpr uint32_t kHotSegWords = 128;  // 4096 node rows per segment of the hot-prefix scan
-constexpr uint32_t kHotMaxSegs = 8192;  // the scan stops after this many segments (the bound is capped at 32 Mi rows)
-constexpr uint32_t kHotList = 8;
-constexpr uint32_t kSummaryWords = 8192; // 32 KB of LDS: 256 Ki summary bits
 
 // ---- HyperLogLog<64>::size(), one quad per counter -------------------------------------
 // slice::binary_search_by of Rust >= 1.82 (see oracle/hb_oracle.c)
@@ -595,90 +585,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((REAL && UN
     }
 }
 
-// ---- hot-prefix shortcut of the bitmap pass --------------------------------------------------------------------------
-// When the iteration leaves the dense passes, the nodes that still change are the cold ones, while most edges come from
-// the hottest nodes - in device order (descending out-degree) a long PREFIX of the changed bitmap is all zero but for a
-// handful of bits.  hot_count_kernel / hot_find_kernel find R = the first row of the 32 Ki-row segment in which the
-// 9th changed node lies (segments of 4096 rows; at most the first 32 Mi rows are scanned), and the list of the <= 8 changed nodes below R; frontier_kernel then decides every source
-// index below R with <= 8 register compares instead of one bitmap load per index (an L2 request each: their rate, not
-// bytes, bounds that pass).  Exactly the same sources are gathered.
-__global__ __launch_bounds__(256) void hot_count_kernel(const uint32_t *bits, uint64_t words, uint32_t *seg_count)
-{
-    const uint64_t w0 = (uint64_t)blockIdx.x * kHotSegWords;
-    uint32_t c = 0;
-    for (uint32_t i = threadIdx.x; i < kHotSegWords; i += 256)
-        if (w0 + i < words) c += __popc(bits[w0 + i]);
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off);
-    __shared__ uint32_t s_c[4];
-    if ((threadIdx.x & 63) == 0) s_c[threadIdx.x >> 6] = c;
-    __syncthreads();
-    if (threadIdx.x == 0) seg_count[blockIdx.x] = s_c[0] + s_c[1] + s_c[2] + s_c[3];
-}
-// one wave: out[0] = R, out[1] = number of listed rows, out[2 .. 2 + kHotList) = the changed rows below R (kNone padded)
-__global__ __launch_bounds__(64) void hot_find_kernel(const uint32_t *bits, uint64_t words, const uint32_t *seg_count, uint32_t nseg, uint32_t *out)
-{
-    const int lane = threadIdx.x;
-    uint32_t total = 0, stop = nseg; // segments [0, stop) hold <= kHotList changed rows together
-    for (uint32_t s0 = 0; s0 < nseg && stop == nseg; s0 += 64) { // wave-uniform
-        const uint32_t c = (s0 + lane < nseg) ? seg_count[s0 + lane] : 0u;
-        uint32_t incl = c;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const uint32_t a = __shfl_up(incl, off);
-            if (lane >= off) incl += a;
-        }
-        const uint64_t over = __ballot(total + incl > kHotList);
-        if (over) {
-            const int first = __ffsll((long long)over) - 1;
-            stop = s0 + (uint32_t)first;
-            total += __shfl(incl, first) - __shfl(c, first); // changed rows in the segments before `stop`
-        } else {
-            total += __shfl(incl, 63);
-        }
-    }
-    if (lane < (int)kHotList) out[2 + lane] = kNone;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    // collect the (<= kHotList) changed rows of the segments before `stop`
-    uint32_t found = 0;
-    for (uint32_t s = 0; s < stop && found < total; s++) {
-        if (seg_count[s] == 0) continue; // wave-uniform
-        for (uint32_t i0 = 0; i0 < kHotSegWords; i0 += 64) {
-            const uint64_t w = (uint64_t)s * kHotSegWords + i0 + lane;
-            uint32_t v = (w < words) ? bits[w] : 0u;
-            uint64_t owners;
-            while ((owners = __ballot(v != 0)) != 0) { // one set bit per round, lowest lane first
-                const int src = __ffsll((long long)owners) - 1;
-                const uint32_t m = __shfl(v, src);
-                const int b = __ffs((int)m) - 1;
-                if (lane == src) v &= v - 1;
-                if (lane == 0 && found < kHotList) out[2 + found] = (uint32_t)((((uint64_t)s * kHotSegWords + i0 + (uint32_t)src) << 5) + (uint32_t)b);
-                found++;
-            }
-        }
-    }
-    if (lane == 0) {
-        const uint64_t r = (uint64_t)stop * kHotSegWords * 32;
-        out[0] = (uint32_t)(r > 0xFFFFFFFFull ? 0xFFFFFFFFull : r);
-        out[1] = total;
-    }
-}
-
-// summary bit j = OR of the words [j << shift, (j + 1) << shift) of the node rows' changed bitmap (`words` words)
-__global__ __launch_bounds__(256) void summary_kernel(const uint32_t *bits, uint64_t words, uint32_t shift, uint32_t *summary, uint32_t summary_words)
-{
-    const uint64_t j = (uint64_t)blockIdx.x * 256 + threadIdx.x; // summary bit; the grid covers summary_words * 32 bits exactly
-    uint32_t any = 0;
-    const uint64_t w0 = j << shift, w1 = (j + 1) << shift;
-    for (uint64_t w = w0; w < w1 && w < words; w++) any |= bits[w];
-    const uint64_t bal = __ballot(any != 0);
-    if ((threadIdx.x & 63) == 0 && (j >> 5) + 1 < (uint64_t)summary_words + 1) {
-        summary[j >> 5] = (uint32_t)bal;
-        if ((j >> 5) + 1 < summary_words) summary[(j >> 5) + 1] = (uint32_t)(bal >> 32);
-    }
-}
-
 // ---- the bitmap (frontier) pass, restructured ------------------------------------------------------------------------
 // A source is gathered only if its changed bit is set (results-inert); rows nothing happened to are
 // left alone (lazy double buffer).  Built for what bounds that pass: with few active
@@ -688,16 +594,15 @@ __global__ __launch_bounds__(256) void summary_kernel(const uint32_t *bits, uint
 // together with the row's own counter: three round trips per row instead of up to fourteen.  Gather slots in which no
 // quad of the wave has an active source are skipped altogether (wave-uniform test on a ballot).
 // W = index slots per lane and batch: 16 (64 sources per quad: hub chunks) or 4 (16 sources: node rows have ~5)
-// SUMMARY: a two-level changed test - a coarse summary of the node rows' changed bitmap (one bit per 2^k words, <= 32 KB)
-// is staged in LDS; an index whose summary bit is clear is dropped without touching the bitmap in global memory (late in a
-// run the changed nodes are the cold ones, while most edges come from hot nodes: most indices end there).  Real sources only.
-template <bool REAL, bool FUSED, bool STATS, int W, bool SUMMARY>
+// Two filters in front of the bitmap test were built and measured SLOWER (DESIGN.md "tried and rejected", round 3): an
+// LDS-staged coarse summary of the bitmap, and a "hot prefix" shortcut (sources below the first changed segment decided by
+// <= 8 register compares): the bit tests they save are L1/L2 hits that overlap with the rest of the row.
+template <bool REAL, bool FUSED, bool STATS, int W>
 __global__ __launch_bounds__(256) void frontier_kernel(const PassParams p)
 {
     __shared__ double s_raw[FUSED ? kTableLen : 1];
     __shared__ double s_bias[FUSED ? kTableLen : 1];
     __shared__ uint8_t s_lc[68];
-    __shared__ uint32_t s_sum[SUMMARY ? kSummaryWords : 1];
     if (FUSED) {
         for (int i = threadIdx.x; i < kTableLen; i += 256) {
             s_raw[i] = p.raw[i];
@@ -705,21 +610,7 @@ __global__ __launch_bounds__(256) void frontier_kernel(const PassParams p)
         }
         if (threadIdx.x < 65) s_lc[threadIdx.x] = p.lc[threadIdx.x];
     }
-    if (SUMMARY) {
-        for (uint32_t i = threadIdx.x; i < p.summary_words; i += 256) s_sum[i] = p.summary[i];
-    }
-    if (FUSED || SUMMARY) __syncthreads();
-    const uint32_t sum_shift = SUMMARY ? p.summary_shift + 5u : 0u; // node index -> summary bit
-    // hot-prefix shortcut (uniform loads: scalars)
-    uint32_t hot_r = 0, hot_n = 0, hot_id[kHotList];
-#pragma unroll
-    for (int k = 0; k < (int)kHotList; k++) hot_id[k] = kNone;
-    if (p.hot) {
-        hot_r = p.hot[0];
-        hot_n = p.hot[1];
-#pragma unroll
-        for (int k = 0; k < (int)kHotList; k++) hot_id[k] = p.hot[2 + k];
-    }
+    if (FUSED) __syncthreads();
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int g = lane >> 2, q = lane & 3;
@@ -792,39 +683,13 @@ __global__ __launch_bounds__(256) void frontier_kernel(const PassParams p)
             const uint32_t first = quad_bcast<0>(idx[0]);
             const bool real_src = first < p.n_pad;
             const uint4 *base = real_src ? p.rd : (const uint4 *)(p.part - p.n_pad * 4);
-            if (SUMMARY && real_src) { // quad-uniform: the row's sources are nodes
-#pragma unroll
-                for (int j = 0; j < W; j++) {
-                    if (idx[j] != kNone) {
-                        const uint32_t sb = idx[j] >> sum_shift;
-                        if (!((s_sum[sb >> 5] >> (sb & 31u)) & 1u)) idx[j] = kNone;
-                    }
-                }
-            }
-            // sources below the hot-prefix bound: changed iff listed (<= 8 compares, no bitmap load); marked by bit 31 of `hotm`
-            uint32_t hotm = 0; // bit j: idx[j] is decided (kept = listed)
-            if (hot_r && real_src) {
-#pragma unroll
-                for (int j = 0; j < W; j++) {
-                    if (idx[j] < hot_r) { // (kNone is not below any bound)
-                        bool listed = false;
-                        if (hot_n) {
-#pragma unroll
-                            for (int k = 0; k < (int)kHotList; k++) listed |= (idx[j] == hot_id[k]);
-                        }
-                        if (listed) hotm |= 1u << j;
-                        else idx[j] = kNone;
-                    }
-                }
-            }
             // ---- round trip 2: the changed bits of all of them
             uint32_t wb[W];
 #pragma unroll
             for (int b = 0; b < W / 4; b++) {
                 if (bal4[b]) {
 #pragma unroll
-                    for (int j = 4 * b; j < 4 * b + 4; j++)
-                        wb[j] = ((hotm >> j) & 1u) ? 0xFFFFFFFFu : (idx[j] != kNone) ? p.bits_rd[idx[j] >> 5] : 0u;
+                    for (int j = 4 * b; j < 4 * b + 4; j++) wb[j] = (idx[j] != kNone) ? p.bits_rd[idx[j] >> 5] : 0u;
                 } else {
 #pragma unroll
                     for (int j = 4 * b; j < 4 * b + 4; j++) wb[j] = 0u;

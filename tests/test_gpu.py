@@ -151,10 +151,7 @@ VARIANTS = {
     "old_per_tile_epilogue": dict(tune=(0, 0x100)),                                  # dense node rows: estimator/Kahan per quad, not once per row
     "frontier_always_chunk128": dict(chunk=128, tune=(0, 0, 101, 0, 0, 0, 1000000)), # rows with > 64 sources: two batches per hub chunk
     "frontier_always_pass_stats": dict(flags=_lib.HB_FLAG_PASS_STATS, tune=(0, 0, 101, 0, 0, 0, 1000000)),
-    "frontier_no_hot_shortcut": dict(chunk=8, tune=(0, 0x2000, 101, 0, 0, 0, 1000000)),  # every index through the bitmap
     "sweep_general_seed_path": dict(chunk=8, tune=(0, 0x800, 101, 0, 0, 0, 1)),        # collect + expand + heavy also in the tail
-    "frontier_summary_experiment": dict(tune=(0, 0x400, 101, 0, 0, 0, 1000000)),     # two-level changed test (LDS summary), off by default
-    "frontier_coarse_summary_experiment": dict(tune=(0, 0x400 | (2 << 16), 101, 0, 0, 0, 1000000)),  # 4 summary words: one bit covers several bitmap words
 }
 
 
