@@ -80,7 +80,7 @@ typedef struct hb_edge {
 #define HB_FLAG_HOST_INGEST   0x400u /* hb_load_edges: reduce the records on the host (hb_host.cpp) instead of
                                         on the GPU (hb_ingest.hip); same result                      */
 #define HB_FLAG_HOST_PLAN     0x800u /* build the device work layout on the host (hb_host.cpp) instead of on the GPU
-                                        (hb_plan.hip); same layout.  The destination partition always uses the host planner */
+                                        (hb_plan.hip); same layout, also for the destination partition                     */
 #define HB_FLAG_CHANGED_ONLY  0x1000u /* with HB_FLAG_DEST_PARTITION: after the changed bits (all-gather) only the counters that
                                          changed in the pass travel (one ncclBroadcast of its packed run per rank) instead of
                                          the all-gather of whole slices: ~18 % fewer bytes in the dense passes of the R-MAT

@@ -292,7 +292,21 @@ int build_sparse_support(hb_ctx *c)
 // The reduced graph arrives either on the host (c->g.row_ptr / c->g.src) or already on the device (csr, e.g. from
 // the GPU ingest).  Default: everything from here on happens on the device (hb_plan.hip); HB_FLAG_HOST_PLAN and the
 // destination partition use the host planner (hb_host.cpp), which produces the same layout.
-bool device_plan(const hb_ctx *c) { return !(c->opt.flags & HB_FLAG_HOST_PLAN) && !dest_mode(c); }
+bool device_plan(const hb_ctx *c) { return !(c->opt.flags & HB_FLAG_HOST_PLAN); }
+
+// destination partition: this rank keeps the in-edges of the rows it owns - in the host copy of the reduced graph (if one
+// is kept) and in the device CSR (if the graph lives there)
+int keep_owned(hb_ctx *c, DeviceCsr *csr)
+{
+    if (!dest_mode(c)) return HB_OK;
+    const uint64_t world = (uint64_t)std::max(c->opt.world_size, 1), rank = (uint64_t)c->opt.rank, n = c->g.ids.size();
+    if (c->g.row_ptr.size() == n + 1 && n) keep_owned_rows(&c->g, world, rank);
+    if (csr && csr->d_row_ptr) {
+        const std::string e = gpu_keep_owned_rows((void *)c->stream, csr, n, world, rank);
+        if (!e.empty()) return fail(c, e.find("memory") != std::string::npos ? HB_ERR_NOMEM : HB_ERR_HIP, e);
+    }
+    return HB_OK;
+}
 
 __global__ __launch_bounds__(256) void idlow_kernel(const uint64_t *lo_by_sid, const uint32_t *order, uint64_t n_pad, uint64_t *idlow)
 {
@@ -1383,7 +1397,11 @@ int hb_load_edges(hb_ctx *c, const hb_u128 *node_ids, uint64_t n, const hb_edge 
         }
         if (!e.empty())
             return fail(c, e.find("memory") != std::string::npos ? HB_ERR_NOMEM : (e.find("hip") != std::string::npos ? HB_ERR_HIP : HB_ERR_LIMIT), e);
-        if (dest_mode(c)) keep_owned_rows(&c->g, (uint64_t)std::max(c->opt.world_size, 1), (uint64_t)c->opt.rank);
+        if ((rc = keep_owned(c, &csr))) {
+            if (csr.d_row_ptr) (void)hipFree(csr.d_row_ptr);
+            if (csr.d_src) (void)hipFree(csr.d_src);
+            return rc;
+        }
         const uint64_t nn = c->g.ids.size();
         const uint64_t m_eff = csr.d_row_ptr ? csr.m : (nn && c->g.row_ptr.size() == nn + 1 ? c->g.row_ptr[nn] : 0);
         c->stats.ms_ingest = now_ms() - t0;
@@ -1445,7 +1463,11 @@ int hb_finalize(hb_ctx *c, const hb_u128 *node_ids, uint64_t n)
         const std::string e = gpu_ingest_reduce((void *)c->stream, node_ids, n, &c->app, &c->g, keep_on_device ? &csr : nullptr, &peak);
         if (!e.empty())
             return fail(c, e.find("memory") != std::string::npos ? HB_ERR_NOMEM : (e.find("hip") != std::string::npos ? HB_ERR_HIP : HB_ERR_LIMIT), e);
-        if (dest_mode(c)) keep_owned_rows(&c->g, (uint64_t)std::max(c->opt.world_size, 1), (uint64_t)c->opt.rank);
+        if ((rc = keep_owned(c, &csr))) {
+            if (csr.d_row_ptr) (void)hipFree(csr.d_row_ptr);
+            if (csr.d_src) (void)hipFree(csr.d_src);
+            return rc;
+        }
         const uint64_t nn = c->g.ids.size();
         const uint64_t m_eff = csr.d_row_ptr ? csr.m : (nn && c->g.row_ptr.size() == nn + 1 ? c->g.row_ptr[nn] : 0);
         const double ing = now_ms() - t0;
@@ -1539,7 +1561,6 @@ int hb_load_dense(hb_ctx *c, const hb_u128 *sorted_ids, uint64_t n, const uint64
         }
         c->g.m_input = m_eff;
         c->g.m_unique = m_eff;
-        if (dest_mode(c)) keep_owned_rows(&c->g, (uint64_t)std::max(c->opt.world_size, 1), (uint64_t)c->opt.rank);
         DeviceCsr csr;
         if (on_device && n) { // straight from the caller's arrays to the device: no host copy of a multi-GB CSR
             HB_HIP(hipMalloc((void **)&csr.d_row_ptr, (n + 1) * sizeof(uint64_t)));
@@ -1554,7 +1575,12 @@ int hb_load_dense(hb_ctx *c, const hb_u128 *sorted_ids, uint64_t n, const uint64
             }
             csr.m = m_eff;
         }
-        const uint64_t m_local = (dest_mode(c) && n) ? c->g.row_ptr[n] : m_eff;
+        if ((rc = keep_owned(c, &csr))) {
+            if (csr.d_row_ptr) (void)hipFree(csr.d_row_ptr);
+            if (csr.d_src) (void)hipFree(csr.d_src);
+            return rc;
+        }
+        const uint64_t m_local = csr.d_row_ptr ? csr.m : ((dest_mode(c) && n) ? c->g.row_ptr[n] : m_eff);
         double ing = now_ms() - t0;
         rc = plan_and_upload(c, csr.d_row_ptr ? &csr : nullptr, m_local);
         if (csr.d_row_ptr) (void)hipFree(csr.d_row_ptr);

@@ -238,6 +238,8 @@ struct DevicePlan {
 std::string device_offsets(void *stream, uint32_t *d_counts, uint64_t count, uint64_t *d_offsets, uint64_t expect);
 // d_offsets[0 .. count]: exclusive prefix sums of d_counts (count + 1 outputs)
 std::string device_prefix(void *stream, const uint32_t *d_counts, uint64_t count, uint64_t *d_offsets);
+// destination partition: drop the in-edges of the rows other ranks own from a device CSR (the device form of keep_owned_rows)
+std::string gpu_keep_owned_rows(void *stream, DeviceCsr *csr, uint64_t n, uint64_t world, uint64_t rank);
 std::string gpu_build_plan(void *stream, uint64_t n, const uint64_t *d_row_ptr, const uint32_t *d_src, const uint32_t *d_outdeg_sid,
                            bool reorder, const PlanTune &tune, Plan *plan, DevicePlan *out);
 

@@ -541,6 +541,64 @@ std::string device_prefix(void *stream_v, const uint32_t *d_counts, uint64_t cou
     return "";
 }
 
+// ---- destination partition: keep the in-edges of the owned rows only (the device form of hb_host.cpp keep_owned_rows) -----
+static __global__ __launch_bounds__(256) void owned_counts_kernel(const uint64_t *row_ptr, uint64_t n, uint64_t world, uint64_t rank, uint32_t *cnt)
+{
+    const uint64_t v = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (v < n) cnt[v] = (v % world == rank) ? (uint32_t)(row_ptr[v + 1] - row_ptr[v]) : 0u;
+}
+// one thread per kept edge: its row by binary search in the new row pointers, its source from the old list
+static __global__ __launch_bounds__(256) void owned_copy_kernel(const uint64_t *old_ptr, const uint32_t *old_src, const uint64_t *new_ptr, uint64_t n, uint64_t m_new,
+                                                          uint32_t *new_src)
+{
+    for (uint64_t j = (uint64_t)blockIdx.x * 256 + threadIdx.x; j < m_new; j += (uint64_t)gridDim.x * 256) {
+        uint64_t lo = 0, hi = n; // last row with new_ptr[row] <= j
+        while (hi - lo > 1) {
+            const uint64_t mid = (lo + hi) >> 1;
+            if (new_ptr[mid] <= j) lo = mid;
+            else hi = mid;
+        }
+        new_src[j] = old_src[old_ptr[lo] + (j - new_ptr[lo])];
+    }
+}
+std::string gpu_keep_owned_rows(void *stream_v, DeviceCsr *csr, uint64_t n, uint64_t world, uint64_t rank)
+{
+    hipStream_t stream = (hipStream_t)stream_v;
+    if (world <= 1 || n == 0 || !csr->d_row_ptr) return "";
+    uint32_t *d_cnt = nullptr;
+    uint64_t *d_new_ptr = nullptr;
+    uint32_t *d_new_src = nullptr;
+    auto bail = [&](const std::string &m) {
+        for (void *q : {(void *)d_cnt, (void *)d_new_ptr, (void *)d_new_src})
+            if (q) (void)hipFree(q);
+        return m;
+    };
+    if (hipMalloc((void **)&d_cnt, (n + 1) * sizeof(uint32_t)) != hipSuccess || hipMalloc((void **)&d_new_ptr, (n + 1) * sizeof(uint64_t)) != hipSuccess)
+        return bail("gpu_keep_owned_rows: out of device memory");
+    hipLaunchKernelGGL(owned_counts_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, (const uint64_t *)csr->d_row_ptr, n, world, rank, d_cnt);
+    if (hipGetLastError() != hipSuccess) return bail("gpu_keep_owned_rows: launch failed");
+    std::string e = device_prefix(stream_v, d_cnt, n, d_new_ptr);
+    if (!e.empty()) return bail(e);
+    uint64_t m_new = 0;
+    if (hipMemcpyAsync(&m_new, d_new_ptr + n, sizeof(uint64_t), hipMemcpyDeviceToHost, stream) != hipSuccess || hipStreamSynchronize(stream) != hipSuccess)
+        return bail("gpu_keep_owned_rows: read-back failed");
+    if (m_new == csr->m) return bail(""); // the caller handed over the owned rows only: nothing to drop
+    if (hipMalloc((void **)&d_new_src, std::max<uint64_t>(m_new, 1) * sizeof(uint32_t)) != hipSuccess) return bail("gpu_keep_owned_rows: out of device memory");
+    if (m_new) {
+        const unsigned blocks = (unsigned)std::min<uint64_t>((m_new + 255) / 256, 65536);
+        hipLaunchKernelGGL(owned_copy_kernel, dim3(blocks), dim3(256), 0, stream, (const uint64_t *)csr->d_row_ptr, (const uint32_t *)csr->d_src,
+                           (const uint64_t *)d_new_ptr, n, m_new, d_new_src);
+        if (hipGetLastError() != hipSuccess || hipStreamSynchronize(stream) != hipSuccess) return bail("gpu_keep_owned_rows: copy failed");
+    }
+    (void)hipFree(csr->d_row_ptr);
+    (void)hipFree(csr->d_src);
+    (void)hipFree(d_cnt);
+    csr->d_row_ptr = d_new_ptr;
+    csr->d_src = d_new_src;
+    csr->m = m_new;
+    return "";
+}
+
 std::string gpu_build_plan(void *stream_v, uint64_t n, const uint64_t *d_row_ptr_in, const uint32_t *d_src_in, const uint32_t *d_outdeg_sid,
                            bool reorder, const PlanTune &tune_in, Plan *p, DevicePlan *out)
 {

@@ -472,6 +472,25 @@ def test_device_plan_equals_host_plan(gpu_ctx_factory):
             assert np.array_equal(dev["row_ptr"], host["row_ptr"]), what
             assert np.array_equal(dev["src"], host["src"]), what
             assert st["level1_edges"] + st["direct_edges"] == len(src), what
+    # destination partition: the device planner lays the rows out as `world` owner slices like the host planner does
+    # (hb_host_plan with tune[7] = world); logical ranks without a communicator keep the id order inside a slice.
+    # The rank is handed ALL in-edges and keeps its own rows' (gpu_keep_owned_rows), or only its own to begin with.
+    g = graphs_[0]
+    for world in (2, 3):
+        for rank in range(world):
+            rp_own, src_own = dist.partition_dense_by_dest(g.row_ptr, g.src, rank, world)
+            host = _lib.host_plan(rp_own, src_own, flags=_lib.HB_FLAG_NO_REORDER, chunk=16, tune=(0, 0, 0, 7, 4, 0, 0, world))
+            for rp_in, src_in in ((rp_own, src_own), (g.row_ptr, g.src)):
+                with gpu_ctx_factory(rank=rank, world_size=world, flags=_lib.HB_FLAG_NO_RCCL | _lib.HB_FLAG_DEST_PARTITION, chunk=16,
+                                     tune=(0, 0, 0, 7, 4)) as ctx:
+                    ctx.load_dense(g.ids, rp_in, src_in)
+                    dev = ctx.plan()
+                    assert ctx.stats()["m_eff"] == len(src_own)
+                what = (world, rank, len(src_in))
+                assert dev["n_pad"] == host["n_pad"] and dev["nv"] == host["nv"], what
+                assert np.array_equal(dev["level_begin"], host["level_begin"]), what
+                assert np.array_equal(dev["order"], host["order"]), what
+                assert np.array_equal(dev["row_ptr"], host["row_ptr"]) and np.array_equal(dev["src"], host["src"]), what
 
 
 # ---- edge-partition mode ------------------------------------------------------------------------
