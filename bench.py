@@ -18,8 +18,8 @@ torch.distributed.run, one rank per GPU).  Prints ONE JSON line on rank 0.
               link rate, peak device bytes); --input dense = the bench-only hb_load_dense export.
   N > 1     = the same graph partitioned over the ranks (strong scaling), one RCCL collective of
               the counters per pass.  `value` = the north-star decomposition: edge
-              partition + ncclAllReduce(max, u8); with --partition both (default) the destination
-              partition (+ ncclAllGather) and its changed-only variant run as extra legs under
+              partition + ncclAllReduce(max, u8); with --partition both (default) its changed-only form, the
+              destination partition (+ ncclAllGather) and its changed-only variant run as extra legs under
               detail.partitions, each with GTEPS, ms_collective, wire bytes and a same-result field.
   c4 leg    = with the default config at N = 1 the line also carries detail.c4: BASELINE configs[3]
               (100M hosts / 2B edges) on one GPU - GTEPS, roofline fractions, parity (~2-3 min).
@@ -71,7 +71,8 @@ def parse():
                          "destination partition + ncclAllGather per pass; both (default) = edge first, then dest and dest+changed-only "
                          "as extra legs under detail.partitions")
     ap.add_argument("--changed-only", action="store_true",
-                    help="N > 1, --partition dest: exchange only the counters that changed (HB_FLAG_CHANGED_ONLY)")
+                    help="N > 1: the main leg exchanges only the counters that changed (HB_FLAG_CHANGED_ONLY; edge partition: all-reduce over "
+                         "the union of the locally changed rows)")
     ap.add_argument("--c4-leg", default="auto", choices=["auto", "on", "off"],
                     help="append a BASELINE configs[3] (100M-host / 2B-edge) leg under detail.c4 (auto: with the default config at N = 1)")
     ap.add_argument("--flags", type=int, default=0)
@@ -309,7 +310,9 @@ def main():
         if world > 1:
             rccl_id = dist.torch_unique_id(rank, world)
             if partition == "dest":
-                flags |= _lib.HB_FLAG_DEST_PARTITION | (_lib.HB_FLAG_CHANGED_ONLY if changed_only else 0)
+                flags |= _lib.HB_FLAG_DEST_PARTITION
+            if changed_only:
+                flags |= _lib.HB_FLAG_CHANGED_ONLY
         ctx = _lib.Context(device=local_rank, flags=flags, chunk=a.chunk, rank=rank, world_size=world, rccl_id=rccl_id, tune=tune)
         t0 = time.perf_counter()
         info = {"path": "hb_load_dense (bench-only export: pre-reduced CSR)"}
@@ -331,7 +334,7 @@ def main():
         return ctx, measure(ctx, a.steps, a.warmup, barrier, td, torch), info
 
     main_part = "single" if world == 1 else ("dest" if a.partition == "dest" else "edge")
-    ctx, ms, load = run_leg(main_part, a.changed_only and main_part == "dest")
+    ctx, ms, load = run_leg(main_part, a.changed_only and world > 1)
     ids, vals = ctx.results()
     stats = ms["stats"]
     passes = ms["passes"]
@@ -380,7 +383,7 @@ def main():
                        "loop_gteps": round(m_eff * passes / (loop_ms / steps * 1e-3) / 1e9, 4) if loop_ms else None,
                        "gathered_edges_per_run": gathered,
                        "gathered_gteps": round(gathered / (loop_ms / steps * 1e-3) / 1e9, 4) if loop_ms else None,
-                       "collective": wire_info(world, main_part, a.changed_only and main_part == "dest", stats, n, ms, steps) if world > 1 else None,
+                       "collective": wire_info(world, main_part, a.changed_only, stats, n, ms, steps) if world > 1 else None,
                        "results": int(len(vals)), "s_generate": round(t_gen, 2), "s_load": load["s_load"],
                        "ms_plan": round(stats["ms_plan"], 1), "ms_h2d": round(stats["ms_h2d"], 1),
                        "device_bytes": int(stats["device_bytes"]), "virtual_rows": int(stats["virtual_rows"]),
@@ -395,7 +398,7 @@ def main():
     # ---- N > 1: the other decompositions, same graph, same K / W (extra legs; `value` stays the edge partition)
     if world > 1 and a.partition == "both":
         legs = {}
-        for name, part, co in (("dest_allgather", "dest", False), ("dest_changed_only", "dest", True)):
+        for name, part, co in (("edge_changed_only", "edge", True), ("dest_allgather", "dest", False), ("dest_changed_only", "dest", True)):
             c2, m2, _ = run_leg(part, co)
             i2, v2 = c2.results()
             same = (len(v2), int(v2.view(np.uint64).sum() & 0xFFFFFFFFFFFFFFFF) if len(v2) else 0) == ref_sig

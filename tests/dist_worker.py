@@ -73,6 +73,16 @@ def main():
             for r in range(world):
                 cnt = len(range(r, g.n, world))
                 pend[r::world] = parts[r][:cnt]
+        elif mode == "edge_ranges":
+            # the pipelined form of the edge partition (hb_api.hip edge_overlap): the node rows are all-reduced in four row
+            # ranges, one collective per range, in order - the library issues range k while it still merges range k + 1
+            tiles = (g.n + 63) // 64
+            bounds = [min(g.n, tiles * k // 4 * 64) for k in range(5)]
+            for lo, hi in zip(bounds, bounds[1:]):
+                if hi > lo:
+                    part = pend[lo:hi].clone()
+                    td.all_reduce(part, op=td.ReduceOp.MAX)
+                    pend[lo:hi] = part
         else:
             td.all_reduce(pend, op=td.ReduceOp.MAX)  # in place on the oracle's pending counters
         has, _ = o.step_finish(hbo.FRONTIER)

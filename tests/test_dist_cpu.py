@@ -26,7 +26,7 @@ def _free_port():
 import pytest
 
 
-@pytest.mark.parametrize("mode", ["edge", "edge_changed", "dest", "dest_changed"])
+@pytest.mark.parametrize("mode", ["edge", "edge_ranges", "edge_changed", "dest", "dest_changed"])
 def test_partitioned_pass_is_exact(tmp_path, mode):
     from oracle import hbo
     from stract_amd import synth
