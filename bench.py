@@ -415,8 +415,9 @@ def main():
     if want_c4 and world == 1:
         g.close()
         del g
+        torch.cuda.empty_cache()
         try:
-            c4 = c4_leg(a, torch, barrier, cores_used[0])
+            c4 = c4_leg(a)
         except Exception as e:  # the main line must survive a failing leg
             c4 = {"error": str(e)[:400]}
         out["detail"]["c4"] = c4
@@ -436,44 +437,32 @@ def wire_info(world, part, changed_only, stats, n, ms, steps):
             "ms_collective_per_pass": round(ms["coll_ms"] / steps / max(ms["passes"], 1), 4)}
 
 
-def c4_leg(a, torch, barrier, cores):
+def c4_leg(a):
     """BASELINE.json configs[3] (100M-host / 2B-edge R-MAT scale 28) on one GPU, appended to the default line so that the
     north-star graph is measured under the driver's clock: GTEPS (1 warm-up + 2 timed runs), whole-dense-pass and dominant-kernel
-    fractions, and parity (state checksum after the passes the CPU oracle finishes in its budget; final list with --verify)."""
-    from stract_amd import _lib, synth
+    fractions, and parity (state checksum after the passes the CPU oracle finishes in its budget; final list with --verify).
+    Runs as a CHILD process (this script with --config C4): generating the 2 B-edge graph takes tens of GB of host memory, and a
+    child that is killed for it must not take the main line down with it."""
+    import subprocess
 
-    t0 = time.perf_counter()
-    g, scale, label = synth.make_config("C4")
-    t_gen = time.perf_counter() - t0
-    n, m_eff = int(g.n), int(g.m)
-    ctx = _lib.Context()
-    t0 = time.perf_counter()
-    info = {"path": "hb_load_dense (bench-only export: pre-reduced CSR)"}
-    if a.input == "records":
-        try:
-            info = load_records(ctx, g)
-        except Exception as e:
-            ctx.close()
-            ctx = _lib.Context()
-            ctx.load_dense(g.ids, g.row_ptr, g.src)
-            info = {"path": "hb_load_dense (the record path FAILED: %s)" % (str(e)[:300],)}
-    else:
-        ctx.load_dense(g.ids, g.row_ptr, g.src)
-    info["s_load"] = round(time.perf_counter() - t0, 2)
-    steps = 2
-    ms = measure(ctx, steps, 1, barrier, None, torch)
-    stats = ms["stats"]
-    ids, vals = ctx.results()
-    avg = per_pass_avg(ms["pass_stats"], n, m_eff, int(stats["rows_with_in_edges"]), int(stats["work_rows"]), True)
-    roof = roofline_of(avg, stats, steps, n, m_eff, True, "C4")
-    cpu, parity = cpu_and_parity(a, g, ctx, None, 0, 1, ms["passes"], ids, vals, ms["pass_stats"][-1], cores=cores, faithful=False)
-    ctx.close()
+    cmd = [sys.executable, os.path.abspath(__file__), "--config", "C4", "--steps", "2", "--warmup", "1", "--c4-leg", "off",
+           "--cpu-seconds", str(a.cpu_seconds), "--input", a.input] + (["--verify"] if a.verify else [])
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=3000, env=env)
+    line = next((ln for ln in reversed(r.stdout.splitlines()) if ln.startswith("{")), None)
+    if r.returncode != 0 or line is None:
+        return {"error": "child exited with %d: %s" % (r.returncode, (r.stderr or "")[-300:])}
+    d = json.loads(line)
+    roof = d.get("roofline") or {}
     keep = ("frac", "achieved", "frac_of_measured_copy_6.29TBs", "pass0", "dominant_kernel", "kernels", "whole_loop", "per_pass")
-    return {"workload": "C4 %s" % label, "n_hosts": n, "m_eff": m_eff, "passes_T": ms["passes"],
-            "value": round(m_eff * ms["passes"] * steps / ms["dt"] / 1e9, 4), "unit": "GTEPS", "steps": steps, "warmup": 1,
-            "ms_per_step": round(ms["dt"] * 1e3 / steps, 3), "parity_bit_exact": None if parity is None else parity["bit_exact"], "parity": parity,
-            "roofline": {k: roof[k] for k in keep if roof and k in roof}, "cpu_baseline": cpu, "input": info,
-            "s_generate": round(t_gen, 1), "device_bytes": int(stats["device_bytes"]), "results": int(len(vals))}
+    det = d.get("detail", {})
+    return {"workload": d["config"]["workload"], "n_hosts": d["config"]["n_hosts"], "m_eff": d["config"]["m_eff"], "passes_T": d["config"]["passes_T"],
+            "value": d["value"], "unit": d["unit"], "steps": d["steps"], "warmup": d["warmup"], "ms_per_step": d["ms_per_step"],
+            "parity_bit_exact": d["parity_bit_exact"], "parity": d["parity"], "roofline": {k: roof[k] for k in keep if k in roof},
+            "cpu_baseline": d["cpu_baseline"], "input": det.get("input"), "s_generate": det.get("s_generate"),
+            "device_bytes": det.get("device_bytes"), "results": det.get("results")}
 
 
 def _pmc(config):

@@ -1,0 +1,247 @@
+// hb_aux.hip.h - helpers, the changed-only exchanges, the reference-tail mode, normalisation and state checksums.
+// Part of the device code of stract_amd/csrc/hb_kernels.hip.h (included from there).
+#pragma once
+
+namespace hbk {
+
+// ---- helpers ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void hll_size_kernel(const uint4 *regs, uint64_t count, uint64_t *out,
+                                                       const double *raw, const double *bias, const uint8_t *lc)
+{
+    const uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    const uint64_t row = t >> 2;
+    const uint64_t rows_pad = (count + 15) & ~15ull;
+    if (row >= rows_pad) return;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (row < count) v = regs[t];
+    const uint64_t sz = hll_size_quad(v, raw, bias, lc);
+    if (row < count && (t & 3) == 0) out[row] = sz;
+}
+
+// wr = max(wr, other) byte-wise: all-reduce(max) between logical ranks on one device
+__global__ __launch_bounds__(256) void merge_max_kernel(uint4 *dst, const uint4 *other, uint64_t count4)
+{
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < count4; i += (uint64_t)gridDim.x * 256) {
+        uint4 a = dst[i];
+        const uint4 b = other[i];
+        Acc acc;
+        acc_zero(acc);
+        acc_merge(acc, a);
+        acc_merge(acc, b);
+        dst[i] = acc_value(acc);
+    }
+}
+
+// dst |= src word-wise (union of the ranks' locally-changed bitmaps)
+__global__ __launch_bounds__(256) void or_words_kernel(uint32_t *dst, const uint32_t *src, uint64_t words)
+{
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < words; i += (uint64_t)gridDim.x * 256) dst[i] |= src[i];
+}
+// edge partition, changed-only: the all-reduced packed rows go back to their places (quad per row of [0, n_pad))
+__global__ __launch_bounds__(256) void unpack_rows_kernel(uint4 *wr, const uint32_t *bits, const uint64_t *prefix, uint64_t n_pad, const uint4 *pack)
+{
+    const uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    const uint64_t row = t >> 2;
+    if (row >= n_pad) return;
+    const uint32_t w = bits[row >> 5], b = (uint32_t)(row & 31u);
+    if (!((w >> b) & 1u)) return;
+    const uint64_t pos = prefix[row >> 5] + (uint64_t)__popc(w & ((1u << b) - 1u));
+    wr[row * 4 + (t & 3)] = pack[pos * 4 + (t & 3)];
+}
+
+// ---- changed-only exchange (destination partition, HB_FLAG_CHANGED_ONLY) --------------------------------------
+// After the changed bits of all slices are known everywhere, only the counters that changed travel: every rank
+// packs the changed rows of its slice (ascending row order; position = rank of the row's bit among all set bits,
+// from a prefix sum over the bitmap words), the packed runs are broadcast, and the receivers scatter them.
+__global__ __launch_bounds__(256) void popcount_words_kernel(const uint32_t *bits, uint64_t words, uint32_t *out)
+{
+    for (uint64_t w = (uint64_t)blockIdx.x * 256 + threadIdx.x; w < words; w += (uint64_t)gridDim.x * 256) out[w] = __popc(bits[w]);
+}
+// quad per row of [row_lo, row_hi)
+__global__ __launch_bounds__(256) void pack_changed_kernel(const uint4 *wr, const uint32_t *bits, const uint64_t *prefix, uint64_t row_lo,
+                                                           uint64_t row_hi, uint4 *pack)
+{
+    const uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    const uint64_t row = row_lo + (t >> 2);
+    if (row >= row_hi) return;
+    const uint32_t w = bits[row >> 5], b = (uint32_t)(row & 31u);
+    if (!((w >> b) & 1u)) return;
+    const uint64_t pos = prefix[row >> 5] + (uint64_t)__popc(w & ((1u << b) - 1u));
+    pack[pos * 4 + (t & 3)] = wr[row * 4 + (t & 3)];
+}
+// foreign rows [row_lo, row_hi): changed now -> take the packed counter; changed in the previous pass only -> the
+// other buffer is two passes old, carry the current value over (lazy double buffer, see pass_kernel)
+__global__ __launch_bounds__(256) void unpack_changed_kernel(uint4 *wr, const uint4 *rd, const uint32_t *bits_now, const uint32_t *bits_prev,
+                                                             const uint64_t *prefix, uint64_t row_lo, uint64_t row_hi, const uint4 *pack)
+{
+    const uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    const uint64_t row = row_lo + (t >> 2);
+    if (row >= row_hi) return;
+    const uint32_t w = bits_now[row >> 5], b = (uint32_t)(row & 31u);
+    if ((w >> b) & 1u) {
+        const uint64_t pos = prefix[row >> 5] + (uint64_t)__popc(w & ((1u << b) - 1u));
+        wr[row * 4 + (t & 3)] = pack[pos * 4 + (t & 3)];
+    } else if ((bits_prev[row >> 5] >> b) & 1u) {
+        wr[row * 4 + (t & 3)] = rd[row * 4 + (t & 3)];
+    }
+}
+
+// ---- reference-tail mode (HB_FLAG_REFERENCE_TAIL): the changed-node machinery of the reference as written -----------
+// U64BloomFilter::insert_u128 (bloom/src/lib.rs:85-98): slot = (low 64 bits of the id * LARGE_PRIME) % num_bits.
+constexpr unsigned long long kBloomPrime = 11400714819323198549ull;
+__device__ __forceinline__ uint64_t bloom_slot(uint64_t id_low, uint64_t num_bits) { return (id_low * kBloomPrime) % num_bits; }
+
+// new_changed_nodes of one pass: a bit per slot of every changed node (harmonic.rs:145,103)
+__global__ __launch_bounds__(256) void bloom_insert_kernel(const uint32_t *bits, const uint64_t *id_low, uint64_t n_pad, uint64_t num_bits,
+                                                           uint32_t *bloom)
+{
+    for (uint64_t row = (uint64_t)blockIdx.x * 256 + threadIdx.x; row < n_pad; row += (uint64_t)gridDim.x * 256) {
+        if (!((bits[row >> 5] >> (row & 31u)) & 1u)) continue;
+        const uint64_t s = bloom_slot(id_low[row], num_bits);
+        atomicOr(&bloom[s >> 5], 1u << (s & 31u));
+    }
+}
+// bit_vec.count_ones() (bloom/src/lib.rs:109)
+__global__ __launch_bounds__(256) void bloom_count_kernel(const uint32_t *bloom, uint64_t words, unsigned long long *out)
+{
+    unsigned long long c = 0;
+    for (uint64_t w = (uint64_t)blockIdx.x * 256 + threadIdx.x; w < words; w += (uint64_t)gridDim.x * 256) c += __popc(bloom[w]);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off);
+    if ((threadIdx.x & 63) == 0 && c) atomicAdd(out, c);
+}
+// changed_nodes.contains_u128(edge.from) (harmonic.rs:133) for every node: the frontier WITH the filter's false
+// positives - they are results-inert only as long as no tail pass has skipped host-level edges (hb_api.hip)
+__global__ __launch_bounds__(256) void bloom_frontier_kernel(const uint32_t *bloom, const uint64_t *id_low, const uint32_t *sid_of,
+                                                             uint64_t n_pad, uint64_t num_bits, uint32_t *bits)
+{
+    const uint64_t row = (uint64_t)blockIdx.x * 256 + threadIdx.x; // n_pad is a multiple of 64: whole waves
+    if (row >= n_pad) return;
+    bool in = false;
+    if (sid_of[row] != kNone) {
+        const uint64_t s = bloom_slot(id_low[row], num_bits);
+        in = (bloom[s >> 5] >> (s & 31u)) & 1u;
+    }
+    const uint64_t bal = __ballot(in);
+    if ((threadIdx.x & 63) == 0) {
+        bits[row >> 5] = (uint32_t)bal;
+        bits[(row >> 5) + 1] = (uint32_t)(bal >> 32);
+    }
+}
+// exact_changed_nodes (harmonic.rs:146-148,105) as a list of device rows; order is irrelevant (max is commutative)
+__global__ __launch_bounds__(256) void changed_list_kernel(const uint32_t *bits, uint64_t n_pad, uint32_t *list, unsigned int *count, uint32_t cap)
+{
+    for (uint64_t row = (uint64_t)blockIdx.x * 256 + threadIdx.x; row < n_pad; row += (uint64_t)gridDim.x * 256) {
+        if (!((bits[row >> 5] >> (row & 31u)) & 1u)) continue;
+        const unsigned int k = atomicAdd(count, 1u);
+        if (k < cap) list[k] = (uint32_t)row;
+    }
+}
+__device__ __forceinline__ uint32_t bytes_max(uint32_t a, uint32_t b)
+{
+    uint32_t r = 0;
+#pragma unroll
+    for (int k = 0; k < 32; k += 8) {
+        const uint32_t x = (a >> k) & 0xFFu, y = (b >> k) & 0xFFu;
+        r |= (x > y ? x : y) << k;
+    }
+    return r;
+}
+// update_changed_counters (harmonic.rs:75-114): for every changed node u and every record (u -> v) the forward-links
+// query returns: counters.new[v] = max(counters.new[v], counters.old[u]) register-wise.  One wave per changed node,
+// 4 records x 16 words at a time; targets are shared between nodes, hence the compare-and-swap.  wr = copy of rd.
+__global__ __launch_bounds__(256) void tail_merge_kernel(const uint32_t *list, const unsigned int *count, const uint64_t *tail_ptr,
+                                                         const uint32_t *tail_to, const uint32_t *rd, uint32_t *wr)
+{
+    const uint32_t lane = threadIdx.x & 63u, k = lane >> 4, w = lane & 15u;
+    const uint32_t total = *count;
+    for (uint32_t i = blockIdx.x * 4 + (threadIdx.x >> 6); i < total; i += gridDim.x * 4) {
+        const uint64_t u = list[i];
+        const uint32_t from = rd[u * 16 + w];
+        const uint64_t e = tail_ptr[u + 1];
+        for (uint64_t j = tail_ptr[u] + k; j < e; j += 4) {
+            uint32_t *dst = &wr[(uint64_t)tail_to[j] * 16 + w];
+            uint32_t old = __hip_atomic_load(dst, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (;;) {
+                const uint32_t nw = bytes_max(old, from);
+                if (nw == old) break;
+                const uint32_t prev = atomicCAS(dst, old, nw);
+                if (prev == old) break;
+                old = prev;
+            }
+        }
+    }
+}
+
+// ---- normalize_centralities (harmonic.rs:178-195) -----------------------------------------
+// out[sid] for sid in ascending-NodeID order: f64::from(KahanSum) = sum (kahan_sum.rs:35-39);
+// kept iff > 0.0, then / norm, non-finite -> 0.0; absent nodes are marked -1.0.
+__global__ __launch_bounds__(256) void finish_kernel(const double *ksum, const uint32_t *dev_of, uint64_t n,
+                                                     double norm, double *out, unsigned long long *count)
+{
+    unsigned long long kept = 0;
+    for (uint64_t sid = (uint64_t)blockIdx.x * 256 + threadIdx.x; sid < n; sid += (uint64_t)gridDim.x * 256) {
+        const double s = ksum[dev_of[sid]];
+        double v = -1.0;
+        if (s > 0.0) {
+            v = s / norm;
+            if (!(fabs(v) <= 1.7976931348623157e308)) v = 0.0; // is_finite
+            kept++;
+        }
+        out[sid] = v;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) kept += __shfl_down(kept, off);
+    const unsigned long long v[4] = {kept, 0, 0, 0};
+    block_add_counters(count, v, 0x1u); // striped: the host sums word 0 of every stripe
+}
+
+// Order-independent checksums of the state (hb_debug_state_hash; same function as
+// oracle/hb_oracle.c hbo_dense_state_hash): node sid contributes mixes of (sid, its 8 register
+// words) and of (sid, sum bits, err bits); contributions are added mod 2^64.
+__device__ __forceinline__ uint64_t hash_mix64(uint64_t x)
+{
+    x ^= x >> 33;
+    x *= 0xff51afd7ed558ccdull;
+    x ^= x >> 33;
+    x *= 0xc4ceb9fe1a85ec53ull;
+    x ^= x >> 33;
+    return x;
+}
+__global__ __launch_bounds__(256) void state_hash_kernel(const uint4 *regs, const double *ksum, const double *kerr,
+                                                         const uint32_t *dev_of, uint64_t n, unsigned long long *out)
+{
+    unsigned long long hr = 0, hk = 0;
+    for (uint64_t sid = (uint64_t)blockIdx.x * 256 + threadIdx.x; sid < n; sid += (uint64_t)gridDim.x * 256) {
+        const uint64_t row = dev_of[sid];
+        uint64_t r = sid * 0x9E3779B97F4A7C15ull + 1ull;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const uint4 v = regs[row * 4 + k];
+            r = hash_mix64(r ^ (((uint64_t)v.y << 32) | v.x));
+            r = hash_mix64(r ^ (((uint64_t)v.w << 32) | v.z));
+        }
+        hr += r;
+        const uint64_t a = (uint64_t)__double_as_longlong(ksum[row]), b = (uint64_t)__double_as_longlong(kerr[row]);
+        hk += hash_mix64(hash_mix64((sid + 0x632BE59BD9B4E019ull) ^ a) ^ b);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        hr += __shfl_down(hr, off);
+        hk += __shfl_down(hk, off);
+    }
+    const unsigned long long v[4] = {hr, hk, 0, 0};
+    block_add_counters(out, v, 0x3u);
+}
+
+// scatter/gather between device order and ascending-NodeID order (debug exports)
+__global__ __launch_bounds__(256) void gather_rows_kernel(const uint4 *regs, const uint32_t *dev_of, uint64_t n,
+                                                          uint4 *out)
+{
+    const uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    const uint64_t sid = t >> 2;
+    if (sid >= n) return;
+    out[t] = regs[(uint64_t)dev_of[sid] * 4 + (t & 3)];
+}
+
+} // namespace hbk
