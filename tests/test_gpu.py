@@ -112,6 +112,46 @@ def test_empty_and_singleton_graphs(gpu_ctx_factory):
             ctx.results()
 
 
+def test_error_behaviour_of_the_boundary(gpu_ctx_factory):
+    """Call-order and argument errors come back as negative codes with a message (include/hyperball.h: nothing unwinds, nothing
+    computes on bad input) and leave the context usable."""
+    lib = _lib.load()
+    g = synth.RmatGraph(10, 5000)
+    e = g.edges(salt=0)
+    with gpu_ctx_factory() as ctx:
+        assert lib.hb_append_edges(ctx.h, None, 5) == _lib.HB_ERR_INVALID        # NULL records with a count
+        assert lib.hb_append_edges(ctx.h, None, 0) == _lib.HB_OK                 # an empty batch is fine
+        for call in (lambda: ctx.begin(), lambda: ctx.step(), lambda: ctx.finish(), lambda: ctx.run()):
+            with pytest.raises(_lib.HyperballError):
+                call()                                                           # nothing loaded yet
+        with pytest.raises(_lib.HyperballError):
+            ctx.tail_segment_end()                                               # not a reference-tail context
+        with pytest.raises(_lib.HyperballError):
+            ctx.append_tail_edges(e[:3])
+        with pytest.raises(_lib.HyperballError):
+            ctx.load_dense(g.ids[::-1], g.row_ptr, g.src)                        # ids not ascending
+        bad_rp = g.row_ptr.copy()
+        bad_rp[-1] -= 1
+        with pytest.raises(_lib.HyperballError):
+            ctx.load_dense(g.ids, bad_rp, g.src)                                 # row_ptr[n] != m
+        assert b"" != (lib.hb_last_error(ctx.h) or b"")
+        ctx.load_edges(e)                                                        # ... and the context still works
+        with pytest.raises(_lib.HyperballError):
+            ctx.step_finish()                                                    # no hb_step_local before
+        st = ctx.run()
+        ids, vals = ctx.results()
+        o, T, ov, keep, k = _oracle_dense(g.ids, g.row_ptr, g.src)
+        assert st["passes"] == T and len(vals) == k and np.array_equal(vals.view(np.uint64), ov[keep].view(np.uint64))
+        small = np.zeros(1, dtype=np.uint64)
+        assert lib.hb_result_ranks(ctx.h, small.ctypes.data, 1) < 0              # result buffer too small
+    with gpu_ctx_factory(flags=_lib.HB_FLAG_REFERENCE_TAIL) as ctx:
+        with pytest.raises(_lib.HyperballError):
+            ctx.append_tail_edges(e[:3])                                         # tail records before the graph
+        ctx.tail_segment_end()                                                   # nothing open: a no-op
+    with pytest.raises(_lib.HyperballError):
+        gpu_ctx_factory(device=99)                                               # no such device
+
+
 def test_golden_graphs(gpu_ctx_factory):
     gold = json.load(open(GOLD))
     for case in gold["graphs"]:
@@ -491,6 +531,32 @@ def test_device_plan_equals_host_plan(gpu_ctx_factory):
                 assert np.array_equal(dev["level_begin"], host["level_begin"]), what
                 assert np.array_equal(dev["order"], host["order"]), what
                 assert np.array_equal(dev["row_ptr"], host["row_ptr"]) and np.array_equal(dev["src"], host["src"]), what
+
+
+def test_c2_device_ingest_and_plan_equal_host(gpu_ctx_factory):
+    """The two ingests and the two planners must stay entry-for-entry equal (hb_ingest.hip / hb_plan.hip vs hb_host.cpp) - also
+    at BASELINE configs[1] size (1.1 M hosts / 20.7 M edges; 24.9 M raw records with flagged-first pairs and duplicates), where
+    64-bit offsets, multi-chunk streams and every planner stage see real sizes."""
+    cfg = synth.CONFIGS["C2"]
+    g = synth.RmatGraph(cfg["scale"], cfg["m"])
+    recs = np.zeros(g.stream_len(2), dtype=_lib.EDGE)
+    assert g.stream_fill(recs, 0, 2) == len(recs)
+    hi, hrp, hsrc, hmu = _lib.host_ingest(recs)
+    assert np.array_equal(hi, g.ids) and np.array_equal(hrp, g.row_ptr) and np.array_equal(hsrc, g.src)
+    with gpu_ctx_factory() as ctx:
+        ctx.set_ingest_limits(chunk_records=1 << 22)          # six chunks
+        for part in np.array_split(recs, 5):
+            ctx.append_edges(part)
+        ctx.finalize()
+        st = ctx.stats()
+        gi, grp, gsrc = ctx.graph()
+        dev = ctx.plan()
+    assert (st["n"], st["m_unique"], st["m_eff"]) == (g.n, hmu, g.m) and st["ingest_peak_bytes"] > 0
+    assert np.array_equal(gi, hi) and np.array_equal(grp, hrp) and np.array_equal(gsrc, hsrc)
+    host = _lib.host_plan(g.row_ptr, g.src)
+    assert dev["n_pad"] == host["n_pad"] and dev["nv"] == host["nv"] and np.array_equal(dev["level_begin"], host["level_begin"])
+    assert np.array_equal(dev["order"][:g.n], host["order"][:g.n])
+    assert np.array_equal(dev["row_ptr"], host["row_ptr"]) and np.array_equal(dev["src"], host["src"])
 
 
 # ---- edge-partition mode ------------------------------------------------------------------------
