@@ -75,6 +75,8 @@ def parse():
                          "the union of the locally changed rows)")
     ap.add_argument("--c4-leg", default="auto", choices=["auto", "on", "off"],
                     help="append a BASELINE configs[3] (100M-host / 2B-edge) leg under detail.c4 (auto: with the default config at N = 1)")
+    ap.add_argument("--legs-timeout", type=int, default=300,
+                    help="N > 1, --partition both: seconds the extra partition legs may take before the line is printed without them")
     ap.add_argument("--flags", type=int, default=0)
     ap.add_argument("--chunk", type=int, default=0)
     ap.add_argument("--tune", default="", help="comma separated hb_options.tune values")
@@ -205,7 +207,7 @@ def roofline_of(avg, stats, steps, n, m_eff, init_streamed, config):
     if l1_edges and l1_ms > 0:
         dom_b = 68.0 * l1_edges
         tr = pmc.get("hub_level1_dense", {})
-        dom = {"kernel": "hbk::pass_kernel<false,false,false,false,4,false>, level-1 launch (dense pull over the hub chunks)",
+        dom = {"kernel": "hbk::pass_kernel<REAL=false,FUSED=false,STATS=false,UNROLL=4,INIT=false,EPI4=false>, level-1 launch (dense pull over the hub chunks)",
                "alg_bytes_per_launch": dom_b, "alg_bytes_def": "68 B x real edges gathered by the launch (%d)" % l1_edges,
                "avg_launch_ms": round(l1_ms, 4), "launches": len(dense) * steps,
                "achieved": round(gbs(dom_b, l1_ms), 1), "frac": round(gbs(dom_b, l1_ms) / HBM_PEAK_GBS, 4),
@@ -215,14 +217,14 @@ def roofline_of(avg, stats, steps, n, m_eff, init_streamed, config):
     if node_ms > 0:
         nb = 68.0 * direct + 192.25 * n
         tr = pmc.get("node_rows_dense", {})
-        kernels.append({"name": "node_rows_dense", "kernel": "hbk::pass_kernel<true,false,true,false,2,false> (node rows: direct gathers + partials, "
+        kernels.append({"name": "node_rows_dense", "kernel": "hbk::pass_kernel<REAL=true,FUSED=true,STATS=false,UNROLL=2,INIT=false,EPI4=true> (node rows: direct gathers + partials, "
                         "merge, changed bits, fused estimator + Kahan)", "alg_bytes_per_launch": nb,
                         "alg_bytes_def": "68 B x direct real edges (%d) + 192.25 B x nodes (%d)" % (direct, n), "avg_launch_ms": round(node_ms, 4),
                         "achieved": round(gbs(nb, node_ms), 1), "frac": round(gbs(nb, node_ms) / HBM_PEAK_GBS, 4),
                         "traffic": tr.get("hbm_bytes_per_dispatch"), "l2_hit_rate": tr.get("l2_hit_rate")})
     for d in avg:
         if d["mode"] == 1:
-            kernels.append({"name": "bitmap_pass_t%d" % d["pass"], "kernel": "whole pass, pass_kernel<*,FRONTIER=true,...> launches",
+            kernels.append({"name": "bitmap_pass_t%d" % d["pass"], "kernel": "whole pass, frontier_kernel<...> launches (hub levels, then node rows)",
                             "A_t_pct": round(100.0 * d["active_edges"] / m_eff, 2), "alg_bytes": d["alg_bytes"], "ms": round(d["ms_gpu"], 4),
                             "achieved": round(gbs(d["alg_bytes"], d["ms_gpu"]), 1), "frac": round(gbs(d["alg_bytes"], d["ms_gpu"]) / HBM_PEAK_GBS, 4)})
     sweeps = [d for d in avg if d["mode"] == 2]
@@ -397,18 +399,44 @@ def main():
 
     # ---- N > 1: the other decompositions, same graph, same K / W (extra legs; `value` stays the edge partition)
     if world > 1 and a.partition == "both":
+        # The main line must survive the extra legs: a rank that fails inside one leaves the others waiting in a collective,
+        # and a blocked ctypes call cannot be interrupted from Python.  A watchdog THREAD prints the line as it stands and ends
+        # every rank once the legs exceed their allowance.
+        import threading
         legs = {}
-        for name, part, co in (("edge_changed_only", "edge", True), ("dest_allgather", "dest", False), ("dest_changed_only", "dest", True)):
-            c2, m2, _ = run_leg(part, co)
-            i2, v2 = c2.results()
-            same = (len(v2), int(v2.view(np.uint64).sum() & 0xFFFFFFFFFFFFFFFF) if len(v2) else 0) == ref_sig
+
+        def give_up():
             if rank == 0:
-                legs[name] = {"value": round(m_eff * m2["passes"] * steps / m2["dt"] / 1e9, 4), "unit": "GTEPS",
-                              "ms_per_step": round(m2["dt"] * 1e3 / steps, 3), "same_result_as_edge_partition": bool(same),
-                              "collective": wire_info(world, part, co, m2["stats"], n, m2, steps)}
-            c2.close()
+                legs.setdefault("error", "extra legs exceeded %d s and were abandoned; `value` (edge partition) is unaffected" % a.legs_timeout)
+                out["detail"]["partitions"] = legs
+                print(json.dumps(out), flush=True)
+            sys.stderr.write("bench.py rank %d: extra partition legs timed out\n" % rank)
+            sys.stderr.flush()
+            os._exit(0)
+
+        dog = threading.Timer(a.legs_timeout, give_up)
+        dog.daemon = True
+        dog.start()
+        for name, part, co in (("edge_changed_only", "edge", True), ("dest_allgather", "dest", False), ("dest_changed_only", "dest", True)):
+            try:
+                c2, m2, _ = run_leg(part, co)
+                i2, v2 = c2.results()
+                same = (len(v2), int(v2.view(np.uint64).sum() & 0xFFFFFFFFFFFFFFFF) if len(v2) else 0) == ref_sig
+                if rank == 0:
+                    legs[name] = {"value": round(m_eff * m2["passes"] * steps / m2["dt"] / 1e9, 4), "unit": "GTEPS",
+                                  "ms_per_step": round(m2["dt"] * 1e3 / steps, 3), "same_result_as_edge_partition": bool(same),
+                                  "collective": wire_info(world, part, co, m2["stats"], n, m2, steps)}
+                c2.close()
+            except Exception as e:  # the other ranks are now alone in a collective: the watchdog ends the run
+                legs[name] = {"error": str(e)[:300]}
+                sys.stderr.write("bench.py rank %d: leg %s failed: %s\n" % (rank, name, e))
+                break
+        else:
+            dog.cancel()
         if rank == 0:
             out["detail"]["partitions"] = legs
+        if dog.is_alive() and any("error" in v for v in legs.values() if isinstance(v, dict)):
+            dog.join()  # a leg failed here: wait for the watchdog (it prints on rank 0 and ends the process)
 
     # ---- the north-star graph as an extra leg (BASELINE configs[3], 1 GPU): driver-visible C4 numbers + parity
     want_c4 = a.c4_leg == "on" or (a.c4_leg == "auto" and world == 1 and a.config == "C3" and not a.flags and not a.tune and not a.chunk)
@@ -479,10 +507,16 @@ def _pmc(config):
     for k, v in d.items():
         if not isinstance(v, dict):
             continue
-        if k.startswith("hbk::pass_kernel<false, false, false, false, 4, false>") and k.endswith("#L1"):
-            out["hub_level1_dense"] = v
-        if k.startswith("hbk::pass_kernel<true, false, true, false, 2, false>"):
-            out["node_rows_dense"] = v
+        if not k.startswith("hbk::pass_kernel<"):
+            continue
+        # template arguments: <REAL, FUSED, STATS, UNROLL, INIT, EPI4>; "#L<level>" = launch class of the hub-chunk kernel
+        targs = [x.strip() for x in k[len("hbk::pass_kernel<"):k.index(">")].split(",")]
+        if len(targs) != 6 or targs[2] != "false" or targs[4] != "false":
+            continue  # pass-statistics builds and the pass-0 (INIT) instantiations are other launches
+        if targs[0] == "false" and k.endswith("#L1"):
+            out["hub_level1_dense"] = dict(v, _kernel=k)
+        if targs[0] == "true" and targs[1] == "true":
+            out["node_rows_dense"] = dict(v, _kernel=k)
     return out
 
 

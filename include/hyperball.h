@@ -117,7 +117,8 @@ typedef struct hb_options {
                              *  [1] low byte: gather unroll 1|2|4 (hub chunks 4, node rows 2); measurement switches: bit 8 = dense fused node
                              *      rows with the per-tile estimator/Kahan epilogue instead of the once-per-row one; bit 11 = sweep passes
                              *      always with the three-launch seed collection / expansion, also in the convergence tail; bit 12 = edge
-                             *      partition without the merge / all-reduce / epilogue pipeline over row ranges
+                             *      partition without the merge / all-reduce / epilogue pipeline over row ranges; bit 13 = bitmap passes
+                             *      gather slot by slot instead of packing each row's surviving sources first
                              *  [2] frontier mode when A_t < tune[2] % of the edges (50; > 100 = always)
                              *  [3] log2 of the hotness slice width in counters (16 = 4 MiB; 1 = no slices)
                              *  [4] min sources of a chunk at a slice cut (8)

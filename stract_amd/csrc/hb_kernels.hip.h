@@ -433,15 +433,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((REAL && UN
 // sources it is a chain of DEPENDENT round trips per row - index -> changed-bit word -> counter gather, repeated for every
 // 16 sources, then the row's own counter - at a handful of waves per SIMD, not bytes.  Here a quad takes ALL (<= 64)
 // indices of its row in one go (16 per lane), then all their bit words, then issues only the gathers that are needed,
-// together with the row's own counter: three round trips per row instead of up to fourteen.  Gather slots in which no
-// quad of the wave has an active source are skipped altogether (wave-uniform test on a ballot).
+// together with the row's own counter: three round trips per row instead of up to fourteen.  COMPACT (default): every quad
+// first packs the sources that passed the bit test to the front of an LDS strip, so the wave runs only as many gather rounds as
+// its fullest quad needs; !COMPACT (tune[1] bit 13) walks the slots in place and skips a pair only if no quad of the wave uses it.
 // W = index slots per lane and batch: 16 (64 sources per quad: hub chunks) or 4 (16 sources: node rows have ~5)
 // Two filters in front of the bitmap test were built and measured SLOWER (DESIGN.md "tried and rejected", round 3): an
 // LDS-staged coarse summary of the bitmap, and a "hot prefix" shortcut (sources below the first changed segment decided by
-// <= 8 register compares): the bit tests they save are L1/L2 hits that overlap with the rest of the row.
-template <bool REAL, bool FUSED, bool STATS, int W>
+// <= 8 register compares): the bit tests they save are L1/L2 hits that overlap with the rest of the row.  A software pipeline over
+// the tiles (row pointers / indices / bit words of the next tiles requested ahead) was slower too: it costs a wave per SIMD.
+template <bool REAL, bool FUSED, bool STATS, int W, bool COMPACT>
 __global__ __launch_bounds__(256) void frontier_kernel(const PassParams p)
 {
+    __shared__ uint32_t s_cmp[COMPACT ? 64 * (4 * W + 1) : 1]; // per quad: its surviving source indices, packed
     __shared__ double s_raw[FUSED ? kTableLen : 1];
     __shared__ double s_bias[FUSED ? kTableLen : 1];
     __shared__ uint8_t s_lc[68];
@@ -548,25 +551,78 @@ __global__ __launch_bounds__(256) void frontier_kernel(const PassParams p)
                 const bool t0 = ((__ballot(lane_act) >> qshift) & 0xFull) != 0;
                 if (valid && t0) selfv = *selfp;
             }
-            // ---- round trip 3: the gathers that are needed, two slots (8 sources per quad) at a time
+            // ---- round trip 3: the gathers that are needed
+            if (COMPACT) {
+                // Few slots survive the bit test (C3 bitmap passes: ~10 % of a hub chunk's sources, ~1 of a node row's),
+                // but which ones differs per quad, so a wave-uniform "skip this slot" rarely fires.  Each quad therefore
+                // packs its surviving indices to the front of a 4W-entry LDS strip (prefix over the quad's 4 lanes by DPP;
+                // strips are padded to an odd stride so 16 quads do not share a bank) and the wave runs only as many
+                // gather rounds as its fullest quad needs.  The order of the sources changes; max does not care.
+                uint32_t mine = 0;
 #pragma unroll
-            for (int j = 0; j < W; j += 2) {
-                if (!__ballot((idx[j] != kNone) | (idx[j + 1] != kNone))) continue; // no quad of the wave has work in these slots
-                uint4 r[2][4];
-#pragma unroll
-                for (int u = 0; u < 2; u++) {
-                    const uint32_t s0 = quad_bcast<0>(idx[j + u]), s1 = quad_bcast<1>(idx[j + u]);
-                    const uint32_t s2 = quad_bcast<2>(idx[j + u]), s3 = quad_bcast<3>(idx[j + u]);
-                    r[u][0] = r[u][1] = r[u][2] = r[u][3] = make_uint4(0, 0, 0, 0); // max with 0 = identity
-                    if (s0 != kNone) r[u][0] = base[(uint64_t)s0 * 4 + q];
-                    if (s1 != kNone) r[u][1] = base[(uint64_t)s1 * 4 + q];
-                    if (s2 != kNone) r[u][2] = base[(uint64_t)s2 * 4 + q];
-                    if (s3 != kNone) r[u][3] = base[(uint64_t)s3 * 4 + q];
+                for (int j = 0; j < W; j++) mine += (idx[j] != kNone);
+                uint32_t incl = mine;
+                {
+                    const uint32_t t1 = quad_perm<0x90>(incl); // lane q reads lane q-1
+                    if (q >= 1) incl += t1;
+                    const uint32_t t2 = quad_perm<0x44>(incl); // lane q reads lane q-2
+                    if (q >= 2) incl += t2;
                 }
+                const uint32_t total = quad_bcast<3>(incl);
+                uint32_t *strip = &s_cmp[(wave * 16 + g) * (4 * W + 1)];
+                uint32_t pos = incl - mine;
 #pragma unroll
-                for (int u = 0; u < 2; u++) {
+                for (int j = 0; j < W; j++) {
+                    if (idx[j] != kNone) strip[pos++] = idx[j];
+                }
+                // same wave writes and reads the strip: LDS operations of one wave complete in order
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll 1
+                for (uint32_t j = 0; j < (uint32_t)(4 * W); j += 8) {
+                    if (!__ballot(j < total)) break; // no quad of the wave has an entry left
+                    uint4 r[2][4];
 #pragma unroll
-                    for (int k = 0; k < 4; k++) acc_merge(acc, r[u][k]);
+                    for (int u = 0; u < 2; u++) {
+                        const uint32_t e = j + 4 * u + q;
+                        const uint32_t my = (e < total) ? strip[e] : kNone;
+                        const uint32_t s0 = quad_bcast<0>(my), s1 = quad_bcast<1>(my);
+                        const uint32_t s2 = quad_bcast<2>(my), s3 = quad_bcast<3>(my);
+                        r[u][0] = r[u][1] = r[u][2] = r[u][3] = make_uint4(0, 0, 0, 0); // max with 0 = identity
+                        if (s0 != kNone) r[u][0] = base[(uint64_t)s0 * 4 + q];
+                        if (s1 != kNone) r[u][1] = base[(uint64_t)s1 * 4 + q];
+                        if (s2 != kNone) r[u][2] = base[(uint64_t)s2 * 4 + q];
+                        if (s3 != kNone) r[u][3] = base[(uint64_t)s3 * 4 + q];
+                    }
+#pragma unroll
+                    for (int k = 0; k < 4; k++) acc_merge(acc, r[0][k]);
+                    if (__ballot(j + 4 < total)) {
+#pragma unroll
+                        for (int k = 0; k < 4; k++) acc_merge(acc, r[1][k]);
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); // the strip is rewritten by the next chunk / tile
+            } else {
+                // two slots (8 sources per quad) at a time, skipping a pair only if no quad of the wave uses it
+#pragma unroll
+                for (int j = 0; j < W; j += 2) {
+                    if (!__ballot((idx[j] != kNone) | (idx[j + 1] != kNone))) continue;
+                    uint4 r[2][4];
+#pragma unroll
+                    for (int u = 0; u < 2; u++) {
+                        const uint32_t s0 = quad_bcast<0>(idx[j + u]), s1 = quad_bcast<1>(idx[j + u]);
+                        const uint32_t s2 = quad_bcast<2>(idx[j + u]), s3 = quad_bcast<3>(idx[j + u]);
+                        r[u][0] = r[u][1] = r[u][2] = r[u][3] = make_uint4(0, 0, 0, 0); // max with 0 = identity
+                        if (s0 != kNone) r[u][0] = base[(uint64_t)s0 * 4 + q];
+                        if (s1 != kNone) r[u][1] = base[(uint64_t)s1 * 4 + q];
+                        if (s2 != kNone) r[u][2] = base[(uint64_t)s2 * 4 + q];
+                        if (s3 != kNone) r[u][3] = base[(uint64_t)s3 * 4 + q];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 2; u++) {
+#pragma unroll
+                        for (int k = 0; k < 4; k++) acc_merge(acc, r[u][k]);
+                    }
                 }
             }
         }

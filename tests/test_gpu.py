@@ -192,10 +192,12 @@ VARIANTS = {
     "frontier_always_chunk128": dict(chunk=128, tune=(0, 0, 101, 0, 0, 0, 1000000)), # rows with > 64 sources: two batches per hub chunk
     "frontier_always_pass_stats": dict(flags=_lib.HB_FLAG_PASS_STATS, tune=(0, 0, 101, 0, 0, 0, 1000000)),
     "sweep_general_seed_path": dict(chunk=8, tune=(0, 0x800, 101, 0, 0, 0, 1)),        # collect + expand + heavy also in the tail
+    "frontier_always_slot_by_slot": dict(chunk=8, tune=(0, 0x2000, 101, 0, 0, 0, 1000000)),  # bitmap passes without packing the surviving sources
+    "frontier_always_slot_by_slot_chunk128": dict(chunk=128, flags=_lib.HB_FLAG_PASS_STATS, tune=(0, 0x2000, 101, 0, 0, 0, 1000000)),
 }
 
 
-EXPECT_MODES = {"frontier_always": {0, 1}, "frontier_always_multilevel": {0, 1}, "sparse_always_multilevel": {0, 2},
+EXPECT_MODES = {"frontier_always": {0, 1}, "frontier_always_slot_by_slot": {0, 1}, "frontier_always_multilevel": {0, 1}, "sparse_always_multilevel": {0, 2},
                 "long_tail_default": {0, 2}}
 VARIANTS["long_tail_default"] = dict()
 VARIANTS["long_tail_chunk8"] = dict(chunk=8)

@@ -362,3 +362,19 @@ def test_tail_index_filter_and_mapping():
     assert got == sorted(want)
     rc = lib.hb_debug_tail_index(n, ids.ctypes.data, dev_of.ctypes.data, n_pad, None, 0, ptr.ctypes.data, to.ctypes.data, m, ctypes.byref(k))
     assert rc == 0 and k.value == 0 and not ptr.any()
+
+
+def test_bench_finds_the_committed_pmc_launch_classes():
+    """bench.py's roofline.traffic is read from profiles/current_<config>_pmc.json by kernel NAME: a renamed template
+    argument list silently turns it into null.  Every committed summary must resolve both dense launch classes."""
+    import glob
+    import bench
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "current_*_pmc.json")))
+    assert files, "no committed PMC summary"
+    for f in files:
+        config = os.path.basename(f)[len("current_"):-len("_pmc.json")]
+        pmc = bench._pmc(config)
+        for cls in ("hub_level1_dense", "node_rows_dense"):
+            assert cls in pmc, (config, cls, "not matched: kernel names changed?")
+            assert pmc[cls]["hbm_bytes_per_dispatch"] > 0 and 0 < pmc[cls]["l2_hit_rate"] < 1
+            assert pmc[cls]["_kernel"].startswith("hbk::pass_kernel<")
