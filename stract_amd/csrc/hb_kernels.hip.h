@@ -442,7 +442,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((REAL && UN
 // <= 8 register compares): the bit tests they save are L1/L2 hits that overlap with the rest of the row.  A software pipeline over
 // the tiles (row pointers / indices / bit words of the next tiles requested ahead) was slower too: it costs a wave per SIMD.
 template <bool REAL, bool FUSED, bool STATS, int W, bool COMPACT>
-__global__ __launch_bounds__(256) void frontier_kernel(const PassParams p)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void frontier_kernel(const PassParams p)
 {
     __shared__ uint32_t s_cmp[COMPACT ? 64 * (4 * W + 1) : 1]; // per quad: its surviving source indices, packed
     __shared__ double s_raw[FUSED ? kTableLen : 1];
