@@ -190,13 +190,15 @@ def roofline_of(avg, stats, steps, n, m_eff, init_streamed, config):
     """roofline object of the JSON line: headline = the whole generic dense pass; kernels[] = the launches /
     passes the review tracks, each with its own algorithmic bytes and event-timed duration."""
     dense = [d for d in avg if d["mode"] == 0 and (d["pass"] > 0 or not init_streamed)]
-    if not dense:
+    only_pass0 = False
+    if not dense:  # forced bitmap / sweep configurations: pass 0 is the only dense pass; it is booked with what it moves
         dense = [d for d in avg if d["mode"] == 0]
+        only_pass0 = init_streamed
     if not dense:
         return None
     rows_in = int(stats["rows_with_in_edges"])
     gbs = lambda b, ms: b / (max(ms, 1e-9) * 1e-3) / 1e9
-    b_dense = sum(d["alg_bytes"] for d in dense)
+    b_dense = sum(d["moved_bytes" if only_pass0 else "alg_bytes"] for d in dense)
     ms_dense = sum(d["ms_gpu"] - d["ms_collective"] for d in dense)
     achieved = gbs(b_dense, ms_dense)
     l1_edges, direct = int(stats["level1_edges"]), int(stats["direct_edges"])
