@@ -1,3 +1,9 @@
 set -x
 mkdir -p gpurun_out
-( time python bench.py --config C5 --verify --input dense --steps 1 --warmup 0 --c4-leg off --tune 0,0,101,0,0,0,1000000 --pass-log gpurun_out/r03q_passes_C5_frontier_always.json ) > gpurun_out/r03q_bench_C5_frontier_always_verify.json 2> gpurun_out/r03q_bench_C5.err; tail -5 gpurun_out/r03q_bench_C5.err; cut -c1-900 gpurun_out/r03q_bench_C5_frontier_always_verify.json
+: > gpurun_out/r03r_sweep_nt_gathers_C3.txt
+for T in off 0 4 16 64 128; do
+  if [ "$T" = off ]; then unset HB_NT_FROM; else export HB_NT_FROM=$T; fi
+  echo "HB_NT_FROM=$T" >> gpurun_out/r03r_sweep_nt_gathers_C3.txt
+  python tools/sweep.py C3 "0:0:" >> gpurun_out/r03r_sweep_nt_gathers_C3.txt 2>&1
+done
+cut -c1-175 gpurun_out/r03r_sweep_nt_gathers_C3.txt
