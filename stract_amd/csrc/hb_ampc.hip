@@ -11,6 +11,7 @@
 
 #include "../../include/hb_ampc.h"
 #include "hb_regs.hip.h"
+#include "hb_guard_alloc.h" // no-op unless built with -DHB_GUARD_ALLOC (debug: unmapped guard range behind every buffer)
 
 namespace {
 thread_local std::string g_hbu_error;

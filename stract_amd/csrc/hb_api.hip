@@ -18,6 +18,7 @@
 #include "hb_kernels.hip.h"
 #include "hb_experiments.hip.h"
 #include "hll64_tables.inc"
+#include "hb_guard_alloc.h" // no-op unless built with -DHB_GUARD_ALLOC (debug: unmapped guard range behind every buffer)
 
 using namespace hb;
 

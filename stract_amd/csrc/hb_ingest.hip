@@ -22,6 +22,7 @@
 #include <rocprim/rocprim.hpp>
 
 #include "hb_internal.h"
+#include "hb_guard_alloc.h" // no-op unless built with -DHB_GUARD_ALLOC (debug: unmapped guard range behind every buffer)
 
 namespace {
 

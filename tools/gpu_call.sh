@@ -1,3 +1,3 @@
-set -x
 mkdir -p gpurun_out
-( time python bench.py --config C4 --verify --steps 2 --warmup 1 --c4-leg off --pass-log gpurun_out/r03s_passes_C4.json ) > gpurun_out/r03s_bench_C4_records_verify.json 2> gpurun_out/r03s_bench_C4.err; tail -5 gpurun_out/r03s_bench_C4.err; cut -c1-800 gpurun_out/r03s_bench_C4_records_verify.json
+timeout 70 python bench.py --steps 1 --warmup 0 --c4-leg off --cpu-seconds 4 > gpurun_out/r03x_poison_bench_C3.json 2> gpurun_out/r03x_poison_bench_C3.err; echo "rc=$? C3"; grep -v amdgpu.ids gpurun_out/r03x_poison_bench_C3.err | tail -3 | cut -c1-300
+timeout 60 python bench.py --config LT --steps 1 --warmup 0 --c4-leg off --cpu-seconds 6 > gpurun_out/r03x_poison_bench_LT.json 2> gpurun_out/r03x_poison_bench_LT.err; echo "rc=$? LT"; grep -v amdgpu.ids gpurun_out/r03x_poison_bench_LT.err | tail -3 | cut -c1-300
