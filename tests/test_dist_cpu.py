@@ -1,4 +1,4 @@
-"""world_size-2 CPU tests of the two multi-GPU decompositions (edge partition + all-reduce(max);
+"""world_size-2 (and two world_size-3) CPU tests of the two multi-GPU decompositions (edge partition + all-reduce(max);
 destination partition + all-gather of the owned rows).  Edge-partitioned algorithm with the
 `gloo` backend: each rank pulls over its own edge subset (oracle arithmetic), the pending
 counters are all-reduced with MAX, every rank finishes the pass; the result must be
@@ -26,12 +26,13 @@ def _free_port():
 import pytest
 
 
-@pytest.mark.parametrize("mode", ["edge", "edge_ranges", "edge_changed", "dest", "dest_changed"])
-def test_partitioned_pass_is_exact(tmp_path, mode):
+@pytest.mark.parametrize("mode,world", [("edge", 2), ("edge_ranges", 2), ("edge_changed", 2), ("dest", 2), ("dest_changed", 2),
+                                        ("edge_changed", 3), ("dest_changed", 3)])  # 3 ranks: uneven slices, a rank with a short last range
+def test_partitioned_pass_is_exact(tmp_path, mode, world):
     from oracle import hbo
     from stract_amd import synth
 
-    scale, m, world = 11, 15_000, 2
+    scale, m = 11, 15_000
     env = dict(os.environ, OMP_NUM_THREADS="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
