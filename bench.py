@@ -42,6 +42,7 @@ torch.distributed.run, one rank per GPU).  Prints ONE JSON line on rank 0.
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -75,6 +76,8 @@ def parse():
                          "the union of the locally changed rows)")
     ap.add_argument("--c4-leg", default="auto", choices=["auto", "on", "off"],
                     help="append a BASELINE configs[3] (100M-host / 2B-edge) leg under detail.c4 (auto: with the default config at N = 1)")
+    ap.add_argument("--no-supervisor", action="store_true",
+                    help="N = 1: measure in this process (default: in a child that is restarted once if a signal kills it)")
     ap.add_argument("--legs-timeout", type=int, default=300,
                     help="N > 1, --partition both: seconds the extra partition legs may take before the line is printed without them")
     ap.add_argument("--flags", type=int, default=0)
@@ -271,11 +274,57 @@ def roofline_of(avg, stats, steps, n, m_eff, init_streamed, config):
                           "frac_8d": round(gbs(d["alg_bytes"], d["ms_gpu"]) / HBM_PEAK_GBS, 4)} for d in avg]}
 
 
+def _die_with_parent():
+    """preexec_fn of the child processes: a child must not keep the GPU when this process is killed (PR_SET_PDEATHSIG)."""
+    import ctypes
+    import signal
+    try:
+        ctypes.CDLL("libc.so.6").prctl(1, signal.SIGKILL)
+    except Exception:
+        pass
+
+
+def supervise(argv, run=subprocess.run, attempts=2):
+    """N = 1 only: the measurement runs in a child process; if the child is KILLED BY A SIGNAL (a GPU memory access fault aborts the
+    process: seen once on one box in round 3 and never reproduced, profiles/r03t_to_r03x_fault_investigation.txt) it is started
+    once more.  Nothing is hidden: the line then carries `attempts` and what happened to the first one; any ordinary failure
+    (non-zero exit code) is passed on unchanged.  Returns the exit code."""
+    env = dict(os.environ, HB_BENCH_CHILD="1")
+    first = None
+    rc = 1
+    for k in range(1, attempts + 1):
+        r = run([sys.executable, os.path.abspath(__file__)] + list(argv), env=env, stdout=subprocess.PIPE, text=True, preexec_fn=_die_with_parent)
+        rc = r.returncode
+        lines = [l for l in (r.stdout or "").splitlines() if l.strip()]
+        if rc == 0:
+            for l in lines[:-1]:
+                print(l, flush=True)
+            last = lines[-1] if lines else ""
+            if k > 1 and last.startswith("{"):
+                d = json.loads(last)
+                d["attempts"] = k
+                d["first_attempt"] = first
+                last = json.dumps(d)
+            if last:
+                print(last, flush=True)
+            return 0
+        for l in lines:
+            print(l, flush=True)
+        if rc > 0 and rc not in (134, 139):  # an ordinary error exit: not retried (134 / 139 = shells' view of SIGABRT / SIGSEGV)
+            return rc
+        first = "child ended with return code %d (killed by a signal)" % rc
+        sys.stderr.write("bench.py: %s; attempt %d of %d\n" % (first, k, attempts))
+        sys.stderr.flush()
+    return rc if rc > 0 else 128 - rc
+
+
 def main():
     a = parse()
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world == 1 and a.gpus <= 1 and not a.no_supervisor and not os.environ.get("HB_BENCH_CHILD"):
+        sys.exit(supervise(sys.argv[1:]))
     if world != max(a.gpus, 1):
         if world == 1 and a.gpus > 1:
             sys.exit("bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)" % a.gpus)
@@ -473,14 +522,12 @@ def c4_leg(a):
     fractions, and parity (state checksum after the passes the CPU oracle finishes in its budget; final list with --verify).
     Runs as a CHILD process (this script with --config C4): generating the 2 B-edge graph takes tens of GB of host memory, and a
     child that is killed for it must not take the main line down with it."""
-    import subprocess
-
     cmd = [sys.executable, os.path.abspath(__file__), "--config", "C4", "--steps", "2", "--warmup", "1", "--c4-leg", "off",
            "--cpu-seconds", str(a.cpu_seconds), "--input", a.input] + (["--verify"] if a.verify else [])
-    env = dict(os.environ)
+    env = dict(os.environ, HB_BENCH_CHILD="1")  # measured in the child itself, not under another supervisor
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
         env.pop(k, None)
-    r = subprocess.run(cmd, capture_output=True, text=True, timeout=3000, env=env)
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=3000, env=env, preexec_fn=_die_with_parent)
     line = next((ln for ln in reversed(r.stdout.splitlines()) if ln.startswith("{")), None)
     if r.returncode != 0 or line is None:
         return {"error": "child exited with %d: %s" % (r.returncode, (r.stderr or "")[-300:])}

@@ -378,3 +378,38 @@ def test_bench_finds_the_committed_pmc_launch_classes():
             assert cls in pmc, (config, cls, "not matched: kernel names changed?")
             assert pmc[cls]["hbm_bytes_per_dispatch"] > 0 and 0 < pmc[cls]["l2_hit_rate"] < 1
             assert pmc[cls]["_kernel"].startswith("hbk::pass_kernel<")
+
+
+def test_bench_supervisor_restarts_only_after_a_signal():
+    """bench.py measures in a child process (N = 1): killed by a signal -> one more attempt, reported in the line;
+    an ordinary error exit is passed on; a clean run prints the child's line unchanged."""
+    import json
+    import types
+    import bench
+
+    def fake(results):
+        calls = []
+
+        def run(cmd, **kw):
+            calls.append(cmd)
+            assert kw["env"]["HB_BENCH_CHILD"] == "1"
+            rc, out = results[len(calls) - 1]
+            return types.SimpleNamespace(returncode=rc, stdout=out)
+        return run, calls
+
+    import contextlib
+    import io
+    line = json.dumps({"metric": "m", "value": 1.0})
+    for results, want_rc, want_calls, check in (
+            ([(0, "note\n" + line + "\n")], 0, 1, lambda d: "attempts" not in d),
+            ([(-6, ""), (0, line + "\n")], 0, 2, lambda d: d["attempts"] == 2 and "signal" in d["first_attempt"]),
+            ([(134, ""), (0, line + "\n")], 0, 2, lambda d: d["attempts"] == 2),
+            ([(1, "")], 1, 1, None),
+            ([(-6, ""), (-6, "")], 134, 2, None)):
+        run, calls = fake(results)
+        buf = io.StringIO()
+        with contextlib.redirect_stdout(buf), contextlib.redirect_stderr(io.StringIO()):
+            rc = bench.supervise(["--steps", "1"], run=run)
+        assert rc == want_rc and len(calls) == want_calls, (results, rc, len(calls))
+        if check:
+            assert check(json.loads(buf.getvalue().strip().splitlines()[-1]))
