@@ -34,6 +34,10 @@ torch.distributed.run, one rank per GPU).  Prints ONE JSON line on rank 0.
   parity    = every line carries `parity_bit_exact`: final (NodeID, f64) list vs the oracle when the
               CPU run converges inside its budget (always with --verify), else an order-independent
               checksum of all registers + Kahan state after the last pass the CPU finished.
+  process   = N = 1: the measurement runs in a child process of this script (and the C4 leg in another); a child that a
+              SIGNAL kills (a GPU fault aborts the process) is started once more and the line then says `attempts: 2`;
+              ordinary error exits are passed on; --no-supervisor measures in this process.  N > 1: a watchdog thread
+              around the extra partition legs (--legs-timeout) keeps the main line.
   cpu_baseline = the CPU oracle's dense OpenMP port of the reference arithmetic, timed on
               this box's host cores on the same graph for a bounded number of passes; the GPU time
               of the SAME passes is reported next to it (like for like); `cpu_faithful` = the
