@@ -40,6 +40,7 @@ extern "C" {
 #define HB_ERR_NOMEM     (-4) /* host or device allocation failed                  */
 #define HB_ERR_RCCL      (-5) /* an RCCL call failed                               */
 #define HB_ERR_LIMIT     (-6) /* n >= 2^32-2^20 nodes, or max_passes exceeded       */
+#define HB_ERR_IO        (-7) /* a file could not be created / written (hb_store.h) */
 
 /* ---- plain data ---------------------------------------------------------------- */
 

@@ -13,7 +13,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("HB_LIB_PATH") or os.path.join(_HERE, "lib", "libhyperball.so")  # HB_LIB_PATH: experiment builds
 
 HB_OK = 0
-HB_ERR_INVALID, HB_ERR_NO_DEVICE, HB_ERR_HIP, HB_ERR_NOMEM, HB_ERR_RCCL, HB_ERR_LIMIT = -1, -2, -3, -4, -5, -6
+HB_ERR_INVALID, HB_ERR_NO_DEVICE, HB_ERR_HIP, HB_ERR_NOMEM, HB_ERR_RCCL, HB_ERR_LIMIT, HB_ERR_IO = -1, -2, -3, -4, -5, -6, -7
+HB_STORE_F64, HB_STORE_U64 = 0, 1
 HB_SKIPPED_REL_MASK = 0x6FED00
 
 HB_FLAG_NO_FRONTIER = 0x01
@@ -172,6 +173,11 @@ _SIGNATURES += [
     ("hbu_batch_get", ctypes.c_int, [_P, _P, _U64, _P, _P]),
     ("hbu_batch_upsert", ctypes.c_int, [_P, _P, _P, _U64, _P]),
 ]
+# include/hb_store.h
+_SIGNATURES += [
+    ("hb_store_write", ctypes.c_int, [ctypes.c_char_p, _P, _P, ctypes.c_int, _U64, ctypes.c_char_p, ctypes.c_size_t]),
+    ("hb_store_harmonic", ctypes.c_int, [ctypes.c_char_p, _P, _P, _P, _U64, ctypes.c_char_p, ctypes.c_size_t]),
+]
 SYMBOLS = [s[0] for s in _SIGNATURES]
 
 _lib = None
@@ -209,6 +215,38 @@ def device_count():
 
 def _ptr(a):
     return None if a is None else a.ctypes.data_as(ctypes.c_void_p)
+
+
+def store_write(path, ids, values):
+    """One speedy_kv database directory (include/hb_store.h): ids = U128 array, values = float64 (Db<NodeID, f64>) or
+    uint64 (Db<NodeID, u64>) array of the same length.  Host only."""
+    ids = np.ascontiguousarray(ids, dtype=U128)
+    values = np.ascontiguousarray(values)
+    if values.dtype == np.float64:
+        kind = HB_STORE_F64
+    elif values.dtype == np.uint64:
+        kind = HB_STORE_U64
+    else:
+        raise TypeError("values must be float64 or uint64, not %s" % values.dtype)
+    if len(ids) != len(values):
+        raise ValueError("ids and values differ in length")
+    err = ctypes.create_string_buffer(512)
+    rc = load().hb_store_write(os.fsencode(path), _ptr(ids), _ptr(values), kind, len(ids), err, len(err))
+    if rc != HB_OK:
+        raise HyperballError(rc, err.value.decode(errors="replace"))
+
+
+def store_harmonic(output, ids, centralities, ranks):
+    """`<output>/harmonic` + `<output>/harmonic_rank`: what store_harmonic (centrality/mod.rs:72-114) leaves on disk."""
+    ids = np.ascontiguousarray(ids, dtype=U128)
+    centralities = np.ascontiguousarray(centralities, dtype=np.float64)
+    ranks = np.ascontiguousarray(ranks, dtype=np.uint64)
+    if not (len(ids) == len(centralities) == len(ranks)):
+        raise ValueError("ids, centralities and ranks differ in length")
+    err = ctypes.create_string_buffer(512)
+    rc = load().hb_store_harmonic(os.fsencode(output), _ptr(ids), _ptr(centralities), _ptr(ranks), len(ids), err, len(err))
+    if rc != HB_OK:
+        raise HyperballError(rc, err.value.decode(errors="replace"))
 
 
 class Context:

@@ -72,9 +72,10 @@ class EdgeListGraph:
 
 
 class HarmonicCentrality:
-    def __init__(self, ids, vals, stats=None, pass_stats=None):
+    def __init__(self, ids, vals, stats=None, pass_stats=None, ranks=None):
         self._ids = ids
         self._vals = vals
+        self._ranks = ranks  # harmonic_rank of every result (hb_result_ranks), filled by calculate()
         self._map = None
         self.stats = stats or {}
         self.pass_stats = pass_stats or []
@@ -86,7 +87,7 @@ class HarmonicCentrality:
             ctx.load_edges(graph.host_edges(), graph.host_nodes())
             st = ctx.run()
             ids, vals = ctx.results()
-            return cls(ids, vals, st, ctx.pass_stats())
+            return cls(ids, vals, st, ctx.pass_stats(), ctx.ranks())
 
     @classmethod
     def calculate_dense(cls, sorted_ids, row_ptr, src, **ctx_kwargs):
@@ -95,7 +96,7 @@ class HarmonicCentrality:
             ctx.load_dense(sorted_ids, row_ptr, src)
             st = ctx.run()
             ids, vals = ctx.results()
-            return cls(ids, vals, st, ctx.pass_stats())
+            return cls(ids, vals, st, ctx.pass_stats(), ctx.ranks())
 
     def _ensure_map(self):
         if self._map is None:
@@ -115,6 +116,11 @@ class HarmonicCentrality:
     def arrays(self):
         return self._ids, self._vals
 
+    def ranks(self):
+        """Position of every result in the order store_harmonic ranks by (centrality descending by f64::total_cmp, then
+        NodeID ascending; centrality/mod.rs:92-103), aligned with arrays()."""
+        return self._ranks
+
     def len(self):
         return len(self._vals)
 
@@ -122,3 +128,15 @@ class HarmonicCentrality:
 
     def is_empty(self):
         return self.len() == 0
+
+
+def store_harmonic(centralities, output):
+    """centrality/mod.rs:72-114 `store_harmonic(centralities, output)`: the `harmonic` (NodeID -> f64) and `harmonic_rank`
+    (NodeID -> u64) speedy_kv databases under `output`, written natively (include/hb_store.h; format unpinned) from the arrays
+    the library returned - ranks come from hb_result_ranks (GPU radix sort), nothing is recomputed on the host.
+    `centralities`: a HarmonicCentrality from calculate() / calculate_dense()."""
+    ids, vals = centralities.arrays()
+    ranks = centralities.ranks()
+    if ranks is None:
+        raise ValueError("this HarmonicCentrality carries no ranks (it was not produced by calculate())")
+    _lib.store_harmonic(output, ids, vals, ranks)

@@ -332,6 +332,32 @@ def test_load_webgraph_from_edge_store(gpu_ctx_factory, tmp_path):
             webgraph.load_webgraph(ctx, str(tmp_path / "nothing_here"))
 
 
+def test_store_harmonic_writes_readable_stores(gpu_ctx_factory, tmp_path):
+    """centrality/mod.rs:72-114 through the operator mirror: calculate -> store_harmonic -> both speedy_kv databases read
+    back by the independent reader (tests/speedy_kv_reader.py) hold the library's results and the reference's rank order"""
+    from stract_amd.harmonic import store_harmonic
+    from tests import speedy_kv_reader as kv
+    g = synth.RmatGraph(12, 30_000)
+    hc = HarmonicCentrality.calculate_dense(g.ids, g.row_ptr, g.src)
+    ids, vals = hc.arrays()
+    assert np.array_equal(hc.ranks(), hbo.rank_results(vals))
+    store_harmonic(hc, str(tmp_path))
+    cen = kv.Db(str(tmp_path / "harmonic"), "f64", str(tmp_path))
+    rnk = kv.Db(str(tmp_path / "harmonic_rank"), "u64", str(tmp_path))
+    assert len(cen) == len(rnk) == hc.len()
+    ints = kv.ids_to_ints(ids)
+    got = dict(cen.items())
+    assert all(np.float64(got[i]).view(np.uint64) == np.float64(v).view(np.uint64) for i, v in zip(ints, vals.tolist()))
+    assert dict(rnk.items()) == dict(zip(ints, hc.ranks().tolist()))
+    # top_nodes (centrality/mod.rs:33-52) from the stored ranks = the library's top()
+    by_rank = sorted(rnk.items(), key=lambda kv_: kv_[1])[:10]
+    assert [i for i, _ in by_rank] == [ints[j] for j in np.argsort(hc.ranks(), kind="stable")[:10].tolist()]
+    fixture = HarmonicCentrality.calculate(graphs.fixture_graph())
+    store_harmonic(fixture, str(tmp_path / "fixture"))
+    r = kv.Db(str(tmp_path / "fixture" / "harmonic_rank"), "u64", str(tmp_path))
+    assert (r.get(graphs.C), r.get(graphs.A), r.get(graphs.B), r.get(graphs.D)) == (0, 1, 2, None)  # harmonic.rs:465-473
+
+
 def test_result_ranks_match_store_harmonic_order(gpu_ctx_factory):
     # centrality/mod.rs:92-103: harmonic_rank = position by (Reverse(total_cmp(centrality)), NodeID)
     g = synth.RmatGraph(13, 60_000)

@@ -9,6 +9,16 @@
 //!     cp /tmp/ref_out/reference_*.json <this repo>/tests/golden/
 //!     cp -r /tmp/ref_out/store_fixture <this repo>/tests/golden/reference_store      # whole edge store, for the column reader
 //!
+//! Second use - pinning the native centrality-store writer (include/hb_store.h): write a store with this repository
+//! (`python -c "from stract_amd import _lib; ..."` or hb_store_harmonic from C), then let the REFERENCE's reader open it:
+//!
+//!     cargo run --release -p stract --example ref_golden -- --check-store /path/to/output
+//!
+//! opens <output>/harmonic and <output>/harmonic_rank with speedy_kv::Db::open_or_create (crates/speedy-kv/src/lib.rs:234),
+//! walks `iter()`, looks every key up again with `get()` (bloom filter + fst + blob index + blob file) and writes
+//! <output>/reference_read_back.txt ("id_hex32 f64_bits_hex16 rank" per line, iteration order) for comparison with the arrays
+//! the library returned.  It also writes the reference's OWN stores of graph 2 under <out dir>/reference_centrality_store.
+//!
 //! and `pytest tests` then pins the oracle, the HIP path and the native column reader to the reference with no
 //! other change (tests/test_reference_golden.py).  Every graph goes through `Webgraph::insert`
 //! (crates/core/src/webgraph/mod.rs:106), is read back through the same `host_edges()` the algorithm uses
@@ -22,7 +32,7 @@ use std::fmt::Write as _;
 use std::path::Path;
 
 use stract::webgraph::centrality::harmonic::HarmonicCentrality;
-use stract::webgraph::{Edge, Node, Webgraph};
+use stract::webgraph::{Edge, Node, NodeID, Webgraph};
 use stract::webpage::html::links::RelFlags;
 
 fn build(path: &Path, edges: &[(String, String, RelFlags)], commit_every: usize) -> Webgraph {
@@ -81,8 +91,31 @@ fn dump_with_pages(name: &str, graph: &Webgraph, out_dir: &Path, pages: bool) {
     std::fs::write(out_dir.join(format!("reference_{name}.json")), s).unwrap();
 }
 
+/// A directory written by hb_store_harmonic, read with the reference's own reader (see the header).
+fn check_store(dir: &Path) {
+    let cen: speedy_kv::Db<NodeID, f64> = speedy_kv::Db::open_or_create(dir.join("harmonic")).unwrap();
+    let rank: speedy_kv::Db<NodeID, u64> = speedy_kv::Db::open_or_create(dir.join("harmonic_rank")).unwrap();
+    let mut s = String::new();
+    let mut n = 0usize;
+    for (id, c) in cen.iter() {
+        let again = cen.get(&id).unwrap().expect("key found by iter() but not by get(): bloom filter or fst map");
+        assert_eq!(c.to_bits(), again.to_bits());
+        let r = rank.get(&id).unwrap().expect("key missing from harmonic_rank");
+        writeln!(s, "{:032x} {:016x} {}", id.as_u128(), c.to_bits(), r).unwrap();
+        n += 1;
+    }
+    assert_eq!(n, cen.len());
+    assert_eq!(n, rank.len());
+    std::fs::write(dir.join("reference_read_back.txt"), s).unwrap();
+    println!("store ok: {n} entries readable by speedy_kv");
+}
+
 fn main() {
-    let out = std::env::args().nth(1).expect("usage: ref_golden <out dir>");
+    if std::env::args().nth(1).as_deref() == Some("--check-store") {
+        let dir = std::env::args().nth(2).expect("usage: ref_golden --check-store <output dir of hb_store_harmonic>");
+        return check_store(Path::new(&dir));
+    }
+    let out = std::env::args().nth(1).expect("usage: ref_golden <out dir> | ref_golden --check-store <dir>");
     let out = Path::new(&out);
     std::fs::create_dir_all(out).unwrap();
     let none = RelFlags::default();
@@ -108,7 +141,11 @@ fn main() {
         }
     }
     let lcg_edges: Vec<_> = seen.iter().map(|(f, t)| (format!("host{f}.com"), format!("host{t}.com"), none)).collect();
-    dump("lcg200", &build(&out.join("g_lcg"), &lcg_edges, 500), out);
+    let g_lcg = build(&out.join("g_lcg"), &lcg_edges, 500);
+    dump("lcg200", &g_lcg, out);
+    // the reference's own centrality stores of this graph (centrality/mod.rs:72-114): files to compare a native store with
+    let hc = HarmonicCentrality::calculate(&g_lcg);
+    stract::webgraph::centrality::store_harmonic(hc.iter().map(|(n, c)| (*n, c)), out.join("reference_centrality_store"));
 
     // 3. ingest semantics: flagged first occurrences, later clean copies, duplicates across commits, self links
     let mut salted = lcg_edges.clone();
