@@ -91,7 +91,12 @@ public:
         if (n > (1u << 20)) raw(p, n);
         else buf_.insert(buf_.end(), p, p + n);
     }
-    void u8(uint8_t v) { write(&v, 1); }
+    void u8(uint8_t v)
+    {
+        if (with_crc_ || buf_.size() + 1 > (1u << 20)) return write(&v, 1);
+        count_++;
+        buf_.push_back(v);
+    }
     void le(uint64_t v, int nbytes)
     {
         uint8_t t[8];
@@ -144,7 +149,7 @@ public:
     {
         w_.le(3, 8); // VERSION
         w_.le(0, 8); // FstType
-        stack_.push_back(Unfinished{});
+        push();
     }
     // keys strictly ascending (byte order); value >= every earlier value
     bool insert(const uint8_t *key, size_t len, uint64_t value)
@@ -155,7 +160,7 @@ public:
         // common prefix with the unfinished path, and the output already committed along it
         size_t p = 0;
         uint64_t committed = 0;
-        while (p < len && p + 1 < stack_.size() && stack_[p].last_inp == key[p]) {
+        while (p < len && p + 1 < depth_ && stack_[p].last_inp == key[p]) {
             committed += stack_[p].last_out;
             p++;
         }
@@ -169,15 +174,11 @@ public:
             stack_[p].last_inp = key[p];
             stack_[p].last_out = value - committed;
             for (size_t i = p + 1; i < len; i++) {
-                Unfinished u;
+                Unfinished &u = push();
                 u.has_last = true;
                 u.last_inp = key[i];
-                u.last_out = 0;
-                stack_.push_back(u);
             }
-            Unfinished leaf;
-            leaf.node.is_final = true;
-            stack_.push_back(leaf);
+            push().node.is_final = true; // the leaf
         }
         prev_.assign(key, key + len);
         len_++;
@@ -220,14 +221,26 @@ private:
     // keep the first `keep` + 1 unfinished nodes; compile the deeper ones bottom-up, each into its parent's last transition
     void freeze(size_t keep)
     {
-        while (stack_.size() > keep + 1) {
-            Unfinished u = std::move(stack_.back());
-            stack_.pop_back();
-            const uint64_t addr = compile(u.node);
-            Unfinished &parent = stack_.back();
+        while (depth_ > keep + 1) {
+            const uint64_t addr = compile(stack_[depth_ - 1].node);
+            depth_--;
+            Unfinished &parent = stack_[depth_ - 1];
             parent.node.trans.push_back(Trans{parent.last_inp, parent.last_out, addr});
             parent.has_last = false;
         }
+    }
+    // the unfinished path lives in a pool that only grows: a popped entry keeps its transition vector's capacity
+    Unfinished &push()
+    {
+        if (depth_ == stack_.size()) stack_.emplace_back();
+        Unfinished &u = stack_[depth_++];
+        u.node.is_final = false;
+        u.node.final_output = 0;
+        u.node.trans.clear();
+        u.has_last = false;
+        u.last_inp = 0;
+        u.last_out = 0;
+        return u;
     }
     // build.rs Builder::compile + node.rs Node::compile_to
     uint64_t compile(const Node &n)
@@ -280,6 +293,7 @@ private:
 
     OutFile &w_;
     std::vector<Unfinished> stack_;
+    size_t depth_ = 0;
     bytes prev_;
     uint64_t len_ = 0, last_addr_ = 1; // NONE_ADDRESS
 };
