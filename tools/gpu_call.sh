@@ -1,2 +1,2 @@
 mkdir -p gpurun_out
-timeout 70 python -m pytest tests/test_gpu.py -m gpu -x -q -k "store_harmonic_writes or fixture" > gpurun_out/r03z_pytest_store.log 2>&1; echo "rc=$?"; tail -5 gpurun_out/r03z_pytest_store.log | cut -c1-300
+timeout 75 python -m pytest tests -m gpu -x -q > gpurun_out/r03zz_pytest_gpu_final.log 2>&1; echo "rc=$?"; tail -3 gpurun_out/r03zz_pytest_gpu_final.log | cut -c1-200
