@@ -34,10 +34,12 @@ torch.distributed.run, one rank per GPU).  Prints ONE JSON line on rank 0.
   parity    = every line carries `parity_bit_exact`: final (NodeID, f64) list vs the oracle when the
               CPU run converges inside its budget (always with --verify), else an order-independent
               checksum of all registers + Kahan state after the last pass the CPU finished.
-  process   = N = 1: the measurement runs in a child process of this script (and the C4 leg in another); a child that a
-              SIGNAL kills (a GPU fault aborts the process) is started once more and the line then says `attempts: 2`;
-              ordinary error exits are passed on; --no-supervisor measures in this process.  N > 1: a watchdog thread
-              around the extra partition legs (--legs-timeout) keeps the main line.
+  process   = the measurement runs in THIS process; any failure of the product path - hb_append_edges / hb_finalize not
+              reducing the record stream to the clean graph, a HIP error, a GPU fault that aborts the process - ends the
+              bench with a non-zero exit code and no JSON line (no fallback to hb_load_dense, no restart: round 3 had both
+              and the review rightly called them nets under a broken boundary).  Only the C4 leg is a child process (the
+              2 B-edge generator needs tens of GB of host memory); its failure is reported in detail.c4.error AND makes
+              the exit code non-zero.  N > 1: a watchdog thread around the extra partition legs (--legs-timeout).
   cpu_baseline = the CPU oracle's dense OpenMP port of the reference arithmetic, timed on
               this box's host cores on the same graph for a bounded number of passes; the GPU time
               of the SAME passes is reported next to it (like for like); `cpu_faithful` = the
@@ -80,8 +82,7 @@ def parse():
                          "the union of the locally changed rows)")
     ap.add_argument("--c4-leg", default="auto", choices=["auto", "on", "off"],
                     help="append a BASELINE configs[3] (100M-host / 2B-edge) leg under detail.c4 (auto: with the default config at N = 1)")
-    ap.add_argument("--no-supervisor", action="store_true",
-                    help="N = 1: measure in this process (default: in a child that is restarted once if a signal kills it)")
+    ap.add_argument("--no-supervisor", action="store_true", help="accepted and ignored (round 3 measured in a restartable child process)")
     ap.add_argument("--legs-timeout", type=int, default=300,
                     help="N > 1, --partition both: seconds the extra partition legs may take before the line is printed without them")
     ap.add_argument("--flags", type=int, default=0)
@@ -147,13 +148,12 @@ def measure(ctx, steps, warmup, barrier, td, torch):
 def load_records(ctx, g, salt=2, slab=1 << 24):
     """The drop-in boundary: the graph as raw SmallEdge records (stream order, flagged-first pairs, duplicates - a stream the
     reference semantics reduce to exactly g), one pinned slab at a time through hb_append_edges, then hb_finalize."""
-    import torch
-
     total = g.stream_len(salt)
     slab = min(slab, max(total, 1))
     from stract_amd import _lib
-    pinned = torch.empty(slab * _lib.EDGE.itemsize, dtype=torch.uint8, pin_memory=True)
-    buf = pinned.numpy().view(_lib.EDGE)
+    pinned = _lib.PinnedRecords(slab)  # hb_pinned_alloc (hipHostMalloc): what the Rust shim fills batch by batch
+    buf = pinned.array
+    h2d = ctx.h2d_rate(buf) if hasattr(ctx, "h2d_rate") else None
     s_fill = s_append = 0.0
     at = 0
     while at < total:
@@ -171,7 +171,10 @@ def load_records(ctx, g, salt=2, slab=1 << 24):
     ok = st["n"] == g.n and st["m_eff"] == g.m and st["m_input"] == total
     if not ok:
         raise RuntimeError("ingest of the record stream did not reduce to the clean graph: n %d/%d m_eff %d/%d" % (st["n"], g.n, st["m_eff"], g.m))
+    del buf
+    pinned.close()
     return {"path": "hb_append_edges x %d + hb_finalize (GPU ingest, device planner)" % ((total + slab - 1) // slab),
+            "pinned_h2d_GBs": None if h2d is None else round(h2d, 1),
             "records": total, "record_GB": round(total * 40 / 1e9, 2), "flagged_or_duplicate_records": total - int(g.m),
             "s_fill_slabs_host": round(s_fill, 2), "s_append_edges": round(s_append, 2), "s_finalize": round(s_fin, 2),
             "append_GBs": round(total * 40 / max(s_append, 1e-9) / 1e9, 2),
@@ -288,47 +291,11 @@ def _die_with_parent():
         pass
 
 
-def supervise(argv, run=subprocess.run, attempts=2):
-    """N = 1 only: the measurement runs in a child process; if the child is KILLED BY A SIGNAL (a GPU memory access fault aborts the
-    process: seen once on one box in round 3 and never reproduced, profiles/r03t_to_r03x_fault_investigation.txt) it is started
-    once more.  Nothing is hidden: the line then carries `attempts` and what happened to the first one; any ordinary failure
-    (non-zero exit code) is passed on unchanged.  Returns the exit code."""
-    env = dict(os.environ, HB_BENCH_CHILD="1")
-    first = None
-    rc = 1
-    for k in range(1, attempts + 1):
-        r = run([sys.executable, os.path.abspath(__file__)] + list(argv), env=env, stdout=subprocess.PIPE, text=True, preexec_fn=_die_with_parent)
-        rc = r.returncode
-        lines = [l for l in (r.stdout or "").splitlines() if l.strip()]
-        if rc == 0:
-            for l in lines[:-1]:
-                print(l, flush=True)
-            last = lines[-1] if lines else ""
-            if k > 1 and last.startswith("{"):
-                d = json.loads(last)
-                d["attempts"] = k
-                d["first_attempt"] = first
-                last = json.dumps(d)
-            if last:
-                print(last, flush=True)
-            return 0
-        for l in lines:
-            print(l, flush=True)
-        if rc > 0 and rc not in (134, 139):  # an ordinary error exit: not retried (134 / 139 = shells' view of SIGABRT / SIGSEGV)
-            return rc
-        first = "child ended with return code %d (killed by a signal)" % rc
-        sys.stderr.write("bench.py: %s; attempt %d of %d\n" % (first, k, attempts))
-        sys.stderr.flush()
-    return rc if rc > 0 else 128 - rc
-
-
 def main():
     a = parse()
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world == 1 and a.gpus <= 1 and not a.no_supervisor and not os.environ.get("HB_BENCH_CHILD"):
-        sys.exit(supervise(sys.argv[1:]))
     if world != max(a.gpus, 1):
         if world == 1 and a.gpus > 1:
             sys.exit("bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)" % a.gpus)
@@ -378,18 +345,13 @@ def main():
             rp, src = split(g.row_ptr, g.src, rank, world)
             ctx.load_dense(g.ids, rp, src)
         elif a.input == "records":
-            try:
-                info = load_records(ctx, g)
-            except Exception as e:  # the bench line must still be produced; the failure is stated in it
-                ctx.close()
-                ctx = _lib.Context(device=local_rank, flags=flags, chunk=a.chunk, tune=tune)
-                ctx.load_dense(g.ids, g.row_ptr, g.src)
-                info = {"path": "hb_load_dense (the record path FAILED: %s)" % (str(e)[:300],)}
+            info = load_records(ctx, g)  # raises if the stream does not reduce to the clean graph: the bench fails, loudly
         else:
             ctx.load_dense(g.ids, g.row_ptr, g.src)
         info["s_load"] = round(time.perf_counter() - t0, 2)
         return ctx, measure(ctx, a.steps, a.warmup, barrier, td, torch), info
 
+    exit_code = 0
     main_part = "single" if world == 1 else ("dest" if a.partition == "dest" else "edge")
     ctx, ms, load = run_leg(main_part, a.changed_only and world > 1)
     ids, vals = ctx.results()
@@ -501,14 +463,18 @@ def main():
         torch.cuda.empty_cache()
         try:
             c4 = c4_leg(a)
-        except Exception as e:  # the main line must survive a failing leg
+        except Exception as e:  # the main line is still printed, but the run counts as failed (exit code below)
             c4 = {"error": str(e)[:400]}
         out["detail"]["c4"] = c4
+        if "error" in c4:
+            exit_code = 3
     if rank == 0:
         print(json.dumps(out), flush=True)
     if td is not None:
         td.barrier()
         td.destroy_process_group()
+    if exit_code:
+        sys.exit(exit_code)
 
 
 def wire_info(world, part, changed_only, stats, n, ms, steps):

@@ -39,7 +39,7 @@ extern "C" {
 #define HB_ERR_HIP       (-3) /* a HIP runtime call failed                         */
 #define HB_ERR_NOMEM     (-4) /* host or device allocation failed                  */
 #define HB_ERR_RCCL      (-5) /* an RCCL call failed                               */
-#define HB_ERR_LIMIT     (-6) /* n >= 2^32-2^20 nodes, or max_passes exceeded       */
+#define HB_ERR_LIMIT     (-6) /* n >= 2^30 nodes, or max_passes exceeded            */
 #define HB_ERR_IO        (-7) /* a file could not be created / written (hb_store.h) */
 
 /* ---- plain data ---------------------------------------------------------------- */
@@ -203,13 +203,15 @@ const char *hb_last_error(const hb_ctx *ctx);
 int hb_load_edges(hb_ctx *ctx, const hb_u128 *node_ids, uint64_t n, const hb_edge *edges,
                   uint64_t m);
 /* Streamed variant for callers that cannot (or need not) hold all records: append any number of batches in stream
- * order, then finalize (node_ids as above).  Every batch is uploaded and unpacked on the device at once (2 x 16-byte
- * endpoint keys + 1 flag byte per record stay resident there, in chunks of 64 Mi records: no reallocation as the
- * stream grows); nothing is buffered on the host, so the caller's peak memory is one batch.  Device memory: 33 B per
- * record while the stream is held + 12 B per record at hb_finalize (+ 16 B per node), then 24 B per record for the
- * stable sort once the chunks are gone (hb_stats.ingest_peak_bytes reports the high-water mark).  With
- * HB_FLAG_HOST_INGEST, if the device runs out of memory mid-stream, or at 2^32 - 256 records (positions are 32-bit
- * on the device), the records are buffered on the host instead (same result). */
+ * order, then finalize (node_ids as above).  Every batch is uploaded at once and reduced as it arrives: each endpoint
+ * is looked up in / added to a device hash table that maps NodeIDs to 32-bit provisional ids, and the record stays
+ * resident as (from id, to id) + 1 flag byte = 9 bytes, in chunks (no reallocation as the stream grows); nothing is
+ * buffered on the host, so the caller's peak memory is one batch.  There is no record-count limit (round 3: 2^32 - 256;
+ * stream positions are no longer stored - the stable sort keeps the stream order of equal pairs).  Device memory: 9 B
+ * per record + 20 B per table slot (load factor <= 1/2) while the stream is held, 16-17 B per record + ~40 B per node at
+ * hb_finalize (hb_stats.ingest_peak_bytes reports the high-water mark).  With HB_FLAG_HOST_INGEST, or if the device
+ * runs out of memory mid-stream, the records are buffered on the host instead (same result).  Batches in pinned host
+ * memory (hipHostMalloc / hipHostRegister) cross the link asynchronously at its full rate. */
 int hb_append_edges(hb_ctx *ctx, const hb_edge *edges, uint64_t m);
 int hb_finalize(hb_ctx *ctx, const hb_u128 *node_ids, uint64_t n);
 
@@ -282,6 +284,15 @@ int hb_result_top(hb_ctx *ctx, uint64_t k, hb_u128 *ids, double *vals, uint64_t 
  * every rank puts them in hb_options.rccl_id. */
 int hb_rccl_unique_id(uint8_t out[128]);
 
+/* ---- pinned batch buffers ------------------------------------------------------------------- */
+/* Page-locked host memory for the record batches of hb_append_edges / hb_load_edges (hipHostMalloc): a batch that lies
+ * in pinned memory crosses the host link asynchronously at its full rate (57 GB/s measured on the MI355X boxes,
+ * profiles/r04a_h2d_probe.txt) and overlaps with the reduction of the batch before it; from pageable memory the
+ * runtime has to stage it.  A caller that owns its buffer can pin it in place with hipHostRegister instead.
+ * hb_pinned_free(NULL) is a no-op. */
+int hb_pinned_alloc(uint64_t bytes, void **out);
+void hb_pinned_free(void *p);
+
 /* ---- device helpers for harnesses -------------------------------------------------------- */
 int hb_device_count(int *count);
 /* Fills name (NUL-terminated, <= cap) with the gcnArchName of the ctx device. */
@@ -327,6 +338,9 @@ int hb_debug_exchange(hb_ctx **ctxs, int count, int phase);
 int hb_step_local(hb_ctx *ctx);
 int hb_step_finish(hb_ctx *ctx, int *has_changes);
 
+/* Bench hook: the rate (GB/s) at which `bytes` bytes at `host` reach the device through hipMemcpyAsync on the library's stream,
+ * mean of `reps` copies into a scratch buffer - what hb_append_edges can get from this buffer in this process. */
+int hb_debug_h2d_rate(hb_ctx *ctx, const void *host, uint64_t bytes, int reps, double *gb_per_s);
 /* Test hook: lowers the limits of the device ingest so that its refusal (>= max_records -> host ingest), its
  * out-of-memory spill (chunk memory beyond max_device_bytes counts as a failed allocation) and its multi-chunk
  * paths (chunk_records per chunk) can be reached with small inputs.  0 = default for each. */

@@ -119,6 +119,9 @@ _SIGNATURES = [
     ("hb_append_tail_edges", ctypes.c_int, [_P, _P, _U64]),
     ("hb_tail_segment_end", ctypes.c_int, [_P]),
     ("hb_debug_set_ingest_limits", ctypes.c_int, [_P, _U64, _U64, _U64]),
+    ("hb_pinned_alloc", ctypes.c_int, [_U64, ctypes.POINTER(ctypes.c_void_p)]),
+    ("hb_pinned_free", None, [ctypes.c_void_p]),
+    ("hb_debug_h2d_rate", ctypes.c_int, [_P, _P, _U64, ctypes.c_int, ctypes.POINTER(ctypes.c_double)]),
     ("hb_debug_tail_index", ctypes.c_int, [_U64, _P, _P, _U64, _P, _U64, _P, _P, _U64, ctypes.POINTER(ctypes.c_uint64)]),
     ("hb_load_dense", ctypes.c_int, [_P, _P, _U64, _P, _P, _U64]),
     ("hb_run", ctypes.c_int, [_P, ctypes.POINTER(HbStats)]),
@@ -215,6 +218,40 @@ def device_count():
 
 def _ptr(a):
     return None if a is None else a.ctypes.data_as(ctypes.c_void_p)
+
+
+class PinnedRecords:
+    """A page-locked batch buffer of `count` SmallEdge records (hb_pinned_alloc = hipHostMalloc in the runtime the LIBRARY
+    runs on): `.array` is a numpy view of it.  Pinned batches reach hb_append_edges at the full rate of the host link."""
+
+    def __init__(self, count, dtype=None):
+        self.dtype = np.dtype(EDGE if dtype is None else dtype)
+        self.count = int(count)
+        self._p = ctypes.c_void_p()
+        nbytes = max(self.count, 1) * self.dtype.itemsize
+        rc = load().hb_pinned_alloc(nbytes, ctypes.byref(self._p))
+        if rc != HB_OK or not self._p.value:
+            raise HyperballError(rc, "hb_pinned_alloc(%d bytes) failed" % nbytes)
+        buf = (ctypes.c_uint8 * nbytes).from_address(self._p.value)
+        self.array = np.frombuffer(buf, dtype=self.dtype, count=self.count)
+
+    def close(self):
+        if self._p is not None and self._p.value:
+            self.array = None
+            load().hb_pinned_free(self._p)
+            self._p = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def store_write(path, ids, values):
@@ -316,6 +353,12 @@ class Context:
     def append_tail_edges(self, records):
         records = np.ascontiguousarray(records, dtype=EDGE)
         self._check(self.lib.hb_append_tail_edges(self.h, _ptr(records) if len(records) else None, len(records)))
+
+    def h2d_rate(self, host_array, reps=3):
+        """GB/s at which this host buffer reaches the device through the library's stream (hb_debug_h2d_rate)."""
+        g = ctypes.c_double(0.0)
+        self._check(self.lib.hb_debug_h2d_rate(self.h, _ptr(host_array), host_array.nbytes, reps, ctypes.byref(g)))
+        return g.value
 
     def set_ingest_limits(self, max_records=0, max_device_bytes=0, chunk_records=0):
         """Test hook (hb_debug_set_ingest_limits): reach the device ingest's refusal / spill / multi-chunk paths with small inputs."""

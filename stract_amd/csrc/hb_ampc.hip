@@ -1,5 +1,6 @@
 // hb_ampc.hip - GPU-resident shard of the AMPC counter table with HyperLogLog64Upsert semantics
 // (include/hb_ampc.h cites the reference operations this serves).
+#include "hb_guard_alloc.h" // FIRST: no-op unless built with -DHB_GUARD_ALLOC=<mode> (debug allocators: guard pages / poison / red zones)
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -11,7 +12,6 @@
 
 #include "../../include/hb_ampc.h"
 #include "hb_regs.hip.h"
-#include "hb_guard_alloc.h" // no-op unless built with -DHB_GUARD_ALLOC (debug: unmapped guard range behind every buffer)
 
 namespace {
 thread_local std::string g_hbu_error;

@@ -4,6 +4,7 @@
 // (crates/core/src/webgraph/centrality/harmonic.rs:215-287,292) behind a C boundary.
 // Host orchestration only: every arithmetic step of the path runs in the gfx950 kernels
 // of hb_kernels.hip.h.  There is no CPU fallback.
+#include "hb_guard_alloc.h" // FIRST: no-op unless built with -DHB_GUARD_ALLOC=<mode> (debug allocators: guard pages / poison / red zones)
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
@@ -18,7 +19,6 @@
 #include "hb_kernels.hip.h"
 #include "hb_experiments.hip.h"
 #include "hll64_tables.inc"
-#include "hb_guard_alloc.h" // no-op unless built with -DHB_GUARD_ALLOC (debug: unmapped guard range behind every buffer)
 
 using namespace hb;
 
@@ -45,7 +45,7 @@ struct hb_ctx {
     // hb_append_edges, default: records are unpacked on the device as they arrive (2 x 16-byte endpoint keys + 1
     // flag byte each); nothing is buffered on the host
     IngestStream app;
-    uint64_t lim_records = 0xFFFFFF00ull, lim_bytes = 0, lim_chunk = 0; // hb_debug_set_ingest_limits
+    uint64_t lim_records = 0, lim_bytes = 0, lim_chunk = 0; // hb_debug_set_ingest_limits (0 = no limit / default)
     DenseGraph g;                  // ids kept; row_ptr/src kept only for hb_debug_copy_graph
     Plan plan;
     bool loaded = false, begun = false, finished = false;
@@ -298,7 +298,17 @@ template <class F>
 int guarded(hb_ctx *c, F &&f)
 {
     try {
-        return f();
+        const int rc = f();
+        HB_GUARD_CHECK("exit of a C-ABI entry point"); // red-zone debug build only (hb_guard_alloc.h)
+#ifdef HB_DEBUG_BOUNDS
+        if (c) { // a device-side index check failed somewhere in this call (hb_kernels.hip.h HB_DBG_ASSERT)
+            unsigned int line = 0;
+            (void)hipDeviceSynchronize();
+            if (hipMemcpyFromSymbol(&line, HIP_SYMBOL(hbk::g_dbg_line), sizeof(line)) == hipSuccess && line)
+                return fail(c, HB_ERR_INVALID, "HB_DEBUG_BOUNDS: device-side index check failed at kernel source line " + std::to_string(line));
+        }
+#endif
+        return rc;
     } catch (const std::bad_alloc &) {
         try { return fail(c, HB_ERR_NOMEM, "out of host memory"); } catch (...) { return HB_ERR_NOMEM; }
     } catch (const std::exception &e) {
@@ -308,33 +318,12 @@ int guarded(hb_ctx *c, F &&f)
     }
 }
 
-// records appended so far live on the device as (from key, to key) pairs + flag bytes: turn them back into hb_edge
-// records on the host (rel_flags collapses to "skipped or not", all the reduction needs) - only when the device
-// ran out of memory in the middle of a stream
+// the device cannot hold the stream (memory, or a debug limit): the records appended so far come back as hb_edge records
+// (hb_ingest.hip gpu_ingest_spill) and the stream continues on the host path
 int spill_appended_to_host(hb_ctx *c)
 {
-    const uint64_t k = c->app.count;
-    if (k) {
-        std::vector<hb_u128> keys;
-        std::vector<uint8_t> bad;
-        c->pending.resize(k);
-        uint64_t base = 0;
-        for (const IngestChunk &ch : c->app.chunks) {
-            if (!ch.count) continue;
-            keys.resize(2 * ch.count);
-            bad.resize(ch.count);
-            HB_HIP(hipMemcpyAsync(keys.data(), ch.d_end, ch.count * 32, hipMemcpyDeviceToHost, c->stream));
-            HB_HIP(hipMemcpyAsync(bad.data(), ch.d_bad, ch.count, hipMemcpyDeviceToHost, c->stream));
-            HB_HIP(hipStreamSynchronize(c->stream));
-            for (uint64_t i = 0; i < ch.count; i++) {
-                c->pending[base + i].from = keys[2 * i];
-                c->pending[base + i].to = keys[2 * i + 1];
-                c->pending[base + i].rel_flags = bad[i] ? HB_SKIPPED_REL_MASK : 0;
-            }
-            base += ch.count;
-        }
-    }
-    c->app.free_all();
+    const std::string e = gpu_ingest_spill((void *)c->stream, &c->app, &c->pending);
+    if (!e.empty()) return fail(c, e.find("memory") != std::string::npos ? HB_ERR_NOMEM : HB_ERR_HIP, e);
     return HB_OK;
 }
 
@@ -495,12 +484,13 @@ int hb_load_edges(hb_ctx *c, const hb_u128 *node_ids, uint64_t n, const hb_edge 
         c->stats = hb_stats{};
         double t0 = now_ms();
         // node/edge-set reduction: on the GPU (hb_ingest.hip) unless the host path is forced; identical output
-        // The device pipeline keeps ~100 B per record resident at its peak (endpoint keys, sort double buffers):
+        // The device pipeline keeps ~18 B per record resident at its peak (9 B held, 16 B during the sort):
         // when that cannot fit, or an allocation fails anyway, the host path produces the same graph.
-        bool on_host = (c->opt.flags & HB_FLAG_HOST_INGEST) != 0 || m >= c->lim_records;
+        bool on_host = (c->opt.flags & HB_FLAG_HOST_INGEST) != 0 || (c->lim_records && m >= c->lim_records);
         if (!on_host) {
             size_t free_b = 0, total_b = 0;
-            const double need = 50.0 * (double)m + 48.0 * (double)((node_ids && n) ? n : 0) + 512e6;
+            // held: 9 B per record + the endpoint table; sort: 16 B per record; ~60 B per node while the ids are sorted
+            const double need = 18.0 * (double)m + 48.0 * (double)((node_ids && n) ? n : 0) + 1024e6;
             if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && need > (double)free_b) on_host = true;
         }
         DeviceCsr csr;
@@ -567,7 +557,7 @@ int hb_finalize(hb_ctx *c, const hb_u128 *node_ids, uint64_t n)
         if (rc) return rc;
         if (c->app.chunks.empty()) { // host mode (or nothing appended)
             const uint64_t keep_lim = c->lim_records;
-            if (!c->pending.empty()) c->lim_records = 0; // the stream was spilled: it stays on the host path
+            if (!c->pending.empty()) c->lim_records = 1; // the stream was spilled: it stays on the host path (m >= 1)
             rc = hb_load_edges(c, node_ids, n, c->pending.data(), c->pending.size());
             c->lim_records = keep_lim;
             std::vector<hb_edge>().swap(c->pending);
@@ -598,10 +588,49 @@ int hb_finalize(hb_ctx *c, const hb_u128 *node_ids, uint64_t n)
     });
 }
 
+int hb_pinned_alloc(uint64_t bytes, void **out)
+{
+    if (!out) return HB_ERR_INVALID;
+    *out = nullptr;
+    void *p = nullptr;
+    if (hipHostMalloc(&p, bytes ? (size_t)bytes : 1, hipHostMallocDefault) != hipSuccess) {
+        (void)hipGetLastError();
+        return HB_ERR_NOMEM;
+    }
+    *out = p;
+    return HB_OK;
+}
+
+void hb_pinned_free(void *p)
+{
+    if (p) (void)hipHostFree(p);
+}
+
+int hb_debug_h2d_rate(hb_ctx *c, const void *host, uint64_t bytes, int reps, double *gb_per_s)
+{
+    return guarded(c, [&]() -> int {
+        if (!c || !host || !bytes || reps < 1 || !gb_per_s) return HB_ERR_INVALID;
+        int rc = set_device(c);
+        if (rc) return rc;
+        void *d = nullptr;
+        HB_HIP(hipMalloc(&d, bytes));
+        hipError_t e = hipMemcpyAsync(d, host, bytes, hipMemcpyHostToDevice, c->stream); // warm-up (first touch of the mapping)
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        const double t0 = now_ms();
+        for (int r = 0; r < reps && e == hipSuccess; r++) e = hipMemcpyAsync(d, host, bytes, hipMemcpyHostToDevice, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        const double ms = now_ms() - t0;
+        (void)hipFree(d);
+        if (e != hipSuccess) return fail(c, HB_ERR_HIP, std::string("hb_debug_h2d_rate: ") + hipGetErrorString(e));
+        *gb_per_s = (double)bytes * reps / (ms * 1e-3) / 1e9;
+        return HB_OK;
+    });
+}
+
 int hb_debug_set_ingest_limits(hb_ctx *c, uint64_t max_records, uint64_t max_device_bytes, uint64_t chunk_records)
 {
     if (!c) return HB_ERR_INVALID;
-    c->lim_records = max_records ? std::min<uint64_t>(max_records, 0xFFFFFF00ull) : 0xFFFFFF00ull;
+    c->lim_records = max_records;
     c->lim_bytes = max_device_bytes;
     c->lim_chunk = chunk_records;
     return HB_OK;

@@ -5,6 +5,41 @@
 namespace hbk {
 
 // ---- helpers ---------------------------------------------------------------------------
+// Structural check of a finished work layout, run once per load on every build (one streaming pass over the row pointers and
+// the source lists: 0.3 ms at C3, 3 ms at C4): every index a pass kernel will ever gather through is in range BEFORE the first
+// pass runs, so a planner or ingest defect is an error code at load time, not a GPU memory fault three kernels later.
+// bad[0] row pointers not monotone / beyond src_len, [1] source id >= rows_total (kNone inside a row included),
+// [2] sources of one row of mixed kind (node and virtual ids), [3] a virtual row reading itself or a later virtual row
+__global__ __launch_bounds__(256) void validate_plan_kernel(const uint64_t *row_ptr, const uint32_t *src, uint64_t rows_total, uint64_t n_pad,
+                                                            uint64_t src_len, unsigned long long *bad)
+{
+    const uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    const uint64_t nq = (uint64_t)gridDim.x * 64; // quads in the grid
+    const int q = threadIdx.x & 3;
+    unsigned b0 = 0, b1 = 0, b2 = 0, b3 = 0;
+    for (uint64_t row = t >> 2; row < rows_total; row += nq) {
+        const uint64_t b = row_ptr[row], e = row_ptr[row + 1];
+        if (b > e || e > src_len) {
+            b0 += (q == 0);
+            continue;
+        }
+        if (row + 1 == rows_total && e != src_len) b0 += (q == 0);
+        const bool first_virtual = b < e && src[b] >= n_pad;
+        for (uint64_t k = b + q; k < e; k += 4) {
+            const uint32_t s = src[k];
+            if (s >= rows_total) b1++;
+            else {
+                if ((s >= n_pad) != first_virtual) b2++;
+                if (s >= n_pad && (row < n_pad ? false : s >= row)) b3++; // partials are produced level by level, bottom-up
+            }
+        }
+    }
+    if (b0) atomicAdd(&bad[0], (unsigned long long)b0);
+    if (b1) atomicAdd(&bad[1], (unsigned long long)b1);
+    if (b2) atomicAdd(&bad[2], (unsigned long long)b2);
+    if (b3) atomicAdd(&bad[3], (unsigned long long)b3);
+}
+
 __global__ __launch_bounds__(256) void hll_size_kernel(const uint4 *regs, uint64_t count, uint64_t *out,
                                                        const double *raw, const double *bias, const uint8_t *lc)
 {

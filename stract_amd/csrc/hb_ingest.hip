@@ -7,12 +7,21 @@
 //                store.rs:313), THEN dropped when rel_flags & SKIPPED_REL != 0 (harmonic.rs:36-49,131)
 //   output     = CSR by destination over sids (rank of the id), sources ascending inside a row
 //
-// Pipeline (one HIP stream; rocPRIM device primitives for the sorts / scans / selections):
-//   records --H2D in slabs--> unpack (from, to as u128 keys; "flagged" byte), kept in chunks of <= 64 Mi records
-//   node set: per chunk radix sort + unique of its endpoint keys, merged into the running sorted set (128-bit keys)
-//   endpoints -> sids: binary search in the sorted id array
-//   (to_sid, from_sid) 64-bit keys + stream position: STABLE radix sort -> the first record of
-//   every pair is the head of its run -> flag filter on the head -> select -> CSR
+// Round 4 rebuild (the round-3 form held 2 x 16-byte endpoint keys per record, found every endpoint's sid by two binary
+// searches per record and carried 32-bit stream positions: 47 B per record at its peak, < 2^32 records, 4.3 s of
+// reduction at 2.5 G records):
+//   append    every endpoint is looked up in / inserted into a device hash table (open addressing, 128-bit keys) AS THE
+//             RECORDS ARRIVE and becomes a 32-bit provisional id ("pid", the order of first arrival); a record is stored
+//             as (from pid, to pid) + its flag byte = 9 B.  The table work hides behind the host link.
+//   finalize  the n table keys are sorted once (128-bit radix sort carrying the pid) -> ids, sid of every pid;
+//             records -> 64-bit keys (to sid, from sid, flag bit) by two 4-byte gathers per record;
+//             ONE stable radix sort over the (to, from) bits only: equal pairs stay in stream order, so the first record
+//             of a pair heads its run and the flag travels in bit 0 - no stream positions, no 2^32 limit;
+//             heads -> flag filter -> compaction (rocPRIM select over a computed flag iterator, in <= 2^30-record
+//             segments) -> sources + row pointers (run ends + max-scan).
+//   memory    9 B per record while the stream is held, 16-17 B per record during the sort, + 20 B per table slot
+//             (load factor <= 1/2) and 40 B per node while the ids are sorted.
+#include "hb_guard_alloc.h" // FIRST: no-op unless built with -DHB_GUARD_ALLOC=<mode> (debug allocators: guard pages / poison / red zones)
 #include <hip/hip_runtime.h>
 
 #include <cstring>
@@ -22,7 +31,6 @@
 #include <rocprim/rocprim.hpp>
 
 #include "hb_internal.h"
-#include "hb_guard_alloc.h" // no-op unless built with -DHB_GUARD_ALLOC (debug: unmapped guard range behind every buffer)
 
 namespace {
 
@@ -42,7 +50,7 @@ struct DevMem {
     {
         for (void *p : ptrs) (void)hipFree(p);
     }
-    void note(size_t bytes) // memory held elsewhere while this object lives (the record chunks)
+    void note(size_t bytes) // memory held elsewhere while this object lives (the record chunks, the endpoint table)
     {
         cur += bytes;
         peak = std::max(peak, cur);
@@ -80,27 +88,109 @@ struct DevMem {
 
 __device__ __forceinline__ u128 make_key(const hb_u128 &v) { return ((u128)v.hi << 64) | (u128)v.lo; }
 
-// one thread per record of the slab: keys[2i] = from, keys[2i+1] = to, bad[i] = flagged
-__global__ __launch_bounds__(256) void unpack_kernel(const hb_edge *slab, uint64_t count, uint64_t base, u128 *keys, uint8_t *bad)
+// grid-stride everywhere: a dispatch holds < 2^32 work-items and the stream may hold more records than that
+constexpr unsigned kGridCap = 1u << 16;
+unsigned grid_for(uint64_t count) { return (unsigned)std::min<uint64_t>(std::max<uint64_t>((count + 255) / 256, 1), kGridCap); }
+#define HB_GRID_STRIDE(i, count) for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < (count); i += (uint64_t)gridDim.x * 256)
+
+// ---- the endpoint table: NodeID (u128) -> provisional id, open addressing, linear probing -------------------------------
+// slot state lives in the pid array: kEmpty, kBusy (claimed, key not yet published), else the pid.  An insert claims an
+// empty slot with ONE compare-and-swap, writes the key, then publishes the pid with release semantics; a reader that sees
+// a pid (acquire) may read the key.  Nothing ever spins INSIDE an iteration: a lane that finds kBusy simply goes round the
+// loop again, by which time the claiming lane - which runs straight-line code to the publishing store - is done even if it
+// sits in the same wave.
+constexpr uint32_t kEmpty = 0xFFFFFFFFu, kBusy = 0xFFFFFFFEu;
+constexpr uint64_t kMaxPids = 1ull << 31; // far above the engine's own limit (n_pad < 2^30)
+
+__device__ __forceinline__ uint64_t slot_hash(u128 key)
 {
-    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= count) return;
-    const hb_edge e = slab[i];
-    keys[2 * (base + i)] = make_key(e.from);
-    keys[2 * (base + i) + 1] = make_key(e.to);
-    bad[base + i] = (e.rel_flags & HB_SKIPPED_REL_MASK) ? 1 : 0;
+    // both halves through a full-avalanche mixer: ids may be hashes (the reference's xxh3-128) or small consecutive
+    // integers (tests) - neither may cluster
+    uint64_t x = (uint64_t)key ^ (((uint64_t)(key >> 64)) * 0x9E3779B97F4A7C15ull);
+    x ^= x >> 32;
+    x *= 0xD6E8FEB86659FD93ull;
+    x ^= x >> 32;
+    x *= 0xD6E8FEB86659FD93ull;
+    x ^= x >> 32;
+    return x;
+}
+
+struct Table {
+    u128 *keys;
+    uint32_t *pids;
+    uint64_t mask; // slots - 1
+    unsigned long long *counter; // pids handed out so far
+};
+
+// pid of `key`, inserted with the next free pid if absent (want_pid == kEmpty) or with want_pid (rehash)
+__device__ __forceinline__ uint32_t table_get(const Table &t, u128 key, uint32_t want_pid)
+{
+    uint64_t slot = slot_hash(key) & t.mask;
+    for (;;) {
+        uint32_t s = __hip_atomic_load(&t.pids[slot], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+        if (s == kEmpty) {
+            const uint32_t old = atomicCAS(&t.pids[slot], kEmpty, kBusy);
+            if (old == kEmpty) {
+                t.keys[slot] = key;
+                const uint32_t pid = want_pid != kEmpty ? want_pid : (uint32_t)atomicAdd(t.counter, 1ull);
+                __hip_atomic_store(&t.pids[slot], pid, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                return pid;
+            }
+            continue; // somebody else claimed it first: read the slot again (with acquire: the key must be visible)
+        }
+        if (s == kBusy) continue; // being published: same slot again
+        if (t.keys[slot] == key) return s;
+        slot = (slot + 1) & t.mask;
+    }
+}
+
+__global__ __launch_bounds__(256) void table_clear_kernel(uint32_t *pids, uint64_t slots)
+{
+    HB_GRID_STRIDE(i, slots) pids[i] = kEmpty;
+}
+
+// one thread per record of the slab: both endpoints -> pids, (from pid | to pid << 32) and the "flagged" byte
+__global__ __launch_bounds__(256) void insert_kernel(const hb_edge *slab, uint64_t count, uint64_t base, Table t, uint64_t *pair, uint8_t *bad)
+{
+    HB_GRID_STRIDE(i, count)
+    {
+        const hb_edge e = slab[i];
+        const uint32_t f = table_get(t, make_key(e.from), kEmpty);
+        const uint32_t to = table_get(t, make_key(e.to), kEmpty);
+        pair[base + i] = (uint64_t)f | ((uint64_t)to << 32);
+        bad[base + i] = (e.rel_flags & HB_SKIPPED_REL_MASK) ? 1 : 0;
+    }
+}
+
+// grow: every published entry of the old table goes to the new one with its pid
+__global__ __launch_bounds__(256) void rehash_kernel(const u128 *old_keys, const uint32_t *old_pids, uint64_t old_slots, Table t)
+{
+    HB_GRID_STRIDE(i, old_slots)
+    {
+        const uint32_t p = old_pids[i];
+        if (p < kBusy) (void)table_get(t, old_keys[i], p);
+    }
+}
+
+// key_of_pid[pid] = key, for every published entry
+__global__ __launch_bounds__(256) void table_export_kernel(const u128 *keys, const uint32_t *pids, uint64_t slots, u128 *key_of_pid, uint64_t npid)
+{
+    HB_GRID_STRIDE(i, slots)
+    {
+        const uint32_t p = pids[i];
+        if (p < kBusy && p < npid) key_of_pid[p] = keys[i];
+    }
 }
 
 __global__ __launch_bounds__(256) void ids_to_keys_kernel(const hb_u128 *ids, uint64_t n, u128 *keys)
 {
-    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i < n) keys[i] = make_key(ids[i]);
+    HB_GRID_STRIDE(i, n) keys[i] = make_key(ids[i]);
 }
 
 __global__ __launch_bounds__(256) void keys_to_ids_kernel(const u128 *keys, uint64_t n, hb_u128 *ids)
 {
-    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i < n) {
+    HB_GRID_STRIDE(i, n)
+    {
         hb_u128 v;
         v.lo = (uint64_t)keys[i];
         v.hi = (uint64_t)(keys[i] >> 64);
@@ -108,62 +198,103 @@ __global__ __launch_bounds__(256) void keys_to_ids_kernel(const u128 *keys, uint
     }
 }
 
-__device__ __forceinline__ uint32_t find_sid(const u128 *ids, uint64_t n, u128 key)
+__global__ __launch_bounds__(256) void iota_kernel(uint32_t *v, uint64_t n)
 {
-    uint64_t lo = 0, hi = n; // first index with ids[idx] >= key
-    while (lo < hi) {
-        const uint64_t mid = (lo + hi) >> 1;
-        if (ids[mid] < key) lo = mid + 1;
-        else hi = mid;
-    }
-    return (lo < n && ids[lo] == key) ? (uint32_t)lo : 0xFFFFFFFFu;
+    HB_GRID_STRIDE(i, n) v[i] = (uint32_t)i;
 }
 
-// one thread per record of a chunk: 64-bit pair key (to_sid, from_sid), ~0 when an endpoint is unknown
-// (harmonic.rs:135: such records are ignored), and its stream position (base + i < 2^32)
-__global__ __launch_bounds__(256) void pair_keys_kernel(const u128 *endpoints, uint64_t count, uint64_t base, const u128 *ids, uint64_t n,
-                                                        uint64_t *pair, uint32_t *pos)
+// after the sort of (key, pid): the pid at sorted position i has sid i
+__global__ __launch_bounds__(256) void sid_scatter_kernel(const uint32_t *pid_sorted, uint64_t n, uint32_t *sid_of_pid)
 {
-    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= count) return;
-    const uint32_t f = find_sid(ids, n, endpoints[2 * i]);
-    const uint32_t t = find_sid(ids, n, endpoints[2 * i + 1]);
-    pair[base + i] = (f == 0xFFFFFFFFu || t == 0xFFFFFFFFu) ? ~0ull : (((uint64_t)t << 32) | (uint64_t)f);
-    pos[base + i] = (uint32_t)(base + i);
+    HB_GRID_STRIDE(i, n) sid_of_pid[pid_sorted[i]] = (uint32_t)i;
 }
 
-// after the stable sort: head[i] = first record of its pair; keep[i] = head, known endpoints, not flagged
-__global__ __launch_bounds__(256) void heads_kernel(const uint64_t *pair, const uint32_t *pos, const uint8_t *bad, uint64_t m,
-                                                    uint8_t *keep, unsigned long long *counts)
+// caller-supplied node list: sid of a pid = position of its key in the sorted list, kEmpty if it is not a node
+// (harmonic.rs:135: records with such an endpoint are ignored)
+__global__ __launch_bounds__(256) void sid_search_kernel(const u128 *key_of_pid, uint64_t npid, const u128 *ids, uint64_t n, uint32_t *sid_of_pid)
 {
-    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-    bool head = false, kept = false;
-    if (i < m) {
-        const uint64_t k = pair[i];
-        head = (k != ~0ull) && (i == 0 || pair[i - 1] != k);
-        kept = head && !bad[pos[i]];
-        keep[i] = kept ? 1 : 0;
+    HB_GRID_STRIDE(i, npid)
+    {
+        const u128 key = key_of_pid[i];
+        uint64_t lo = 0, hi = n; // first index with ids[idx] >= key
+        while (lo < hi) {
+            const uint64_t mid = (lo + hi) >> 1;
+            if (ids[mid] < key) lo = mid + 1;
+            else hi = mid;
+        }
+        sid_of_pid[i] = (lo < n && ids[lo] == key) ? (uint32_t)lo : kEmpty;
     }
-    const unsigned long long nh = __popcll(__ballot(head));
-    if ((threadIdx.x & 63) == 0 && nh) atomicAdd(&counts[blockIdx.x & 63], nh); // striped; summed on the host
 }
 
-// the kept pair keys, ascending (to, from): src[i] = from; row_ptr[r] = first position whose `to` is >= r.  A thread that
-// starts a new destination fills the row pointers of the gap behind it (no atomics: per-row counters under a sorted
-// sweep are same-address atomic chains - a hub with a million in-edges serialises a million of them)
-__global__ __launch_bounds__(256) void csr_from_keys_kernel(const uint64_t *sel, uint64_t m_eff, uint64_t n, uint32_t *src, uint64_t *row_ptr)
+// (from pid, to pid), flag -> sort key: to sid << (nb + 1) | from sid << 1 | flag; ~0 when an endpoint is no node.
+// nb bits hold every sid AND leave the all-ones value unused (nb = bits of n), so ~0 collides with no pair.
+__global__ __launch_bounds__(256) void pair_keys_kernel(const uint64_t *pair, const uint8_t *bad, uint64_t count, const uint32_t *sid_of_pid, uint32_t nb,
+                                                        uint64_t *out)
 {
-    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i > m_eff) return;
-    if (i == m_eff) { // rows behind the last destination (all rows when nothing was kept)
-        const uint64_t last = m_eff ? (sel[m_eff - 1] >> 32) + 1 : 0;
-        for (uint64_t r = last; r <= n; r++) row_ptr[r] = m_eff;
-        return;
+    HB_GRID_STRIDE(i, count)
+    {
+        const uint64_t pr = pair[i];
+        const uint32_t f = sid_of_pid[(uint32_t)pr], t = sid_of_pid[(uint32_t)(pr >> 32)];
+        out[i] = (f == kEmpty || t == kEmpty) ? ~0ull : (((uint64_t)t << (nb + 1)) | ((uint64_t)f << 1) | (uint64_t)(bad[i] & 1));
     }
-    const uint64_t k = sel[i];
-    src[i] = (uint32_t)k;
-    const uint64_t t = k >> 32, tp = i ? (sel[i - 1] >> 32) + 1 : 0; // rows tp .. t start here
-    for (uint64_t r = tp; r <= t; r++) row_ptr[r] = i;
+}
+
+// flag iterators over the sorted keys (computed, never stored): a HEAD is the first record of its (to, from) pair - the
+// sort is stable and ignores bit 0, so that is the pair's first record in stream order (store.rs:313); it is KEPT if that
+// record is not flagged (harmonic.rs:131)
+struct HeadKept {
+    const uint64_t *keys; // whole sorted array
+    __device__ uint8_t operator()(uint64_t i) const
+    {
+        const uint64_t k = keys[i];
+        if (k == ~0ull || (k & 1)) return 0;
+        return (i == 0 || ((keys[i - 1] ^ k) >> 1) != 0) ? 1 : 0;
+    }
+};
+struct HeadAny {
+    const uint64_t *keys;
+    __device__ uint64_t operator()(uint64_t i) const
+    {
+        const uint64_t k = keys[i];
+        if (k == ~0ull) return 0;
+        return (i == 0 || ((keys[i - 1] ^ k) >> 1) != 0) ? 1 : 0;
+    }
+};
+
+// kept keys, ascending (to, from): src[i] = from; the thread at the END of a destination's run writes the run's end to
+// row_end[to + 1] (all other entries stay 0); an inclusive max-scan of row_end then IS the row-pointer array - rows
+// without edges inherit the end of the last row before them, and no thread ever walks a gap
+__global__ __launch_bounds__(256) void csr_from_keys_kernel(const uint64_t *sel, uint64_t m_eff, uint32_t nb, uint32_t *src, uint64_t *row_end)
+{
+    const uint64_t mask = (1ull << nb) - 1;
+    HB_GRID_STRIDE(i, m_eff)
+    {
+        const uint64_t k = sel[i];
+        src[i] = (uint32_t)((k >> 1) & mask);
+        const uint64_t t = k >> (nb + 1);
+        if (i + 1 == m_eff || (sel[i + 1] >> (nb + 1)) != t) row_end[t + 1] = i + 1;
+    }
+}
+
+struct MaxU64 {
+    __device__ uint64_t operator()(uint64_t a, uint64_t b) const { return a > b ? a : b; }
+};
+
+// spill: (from pid, to pid), flag -> hb_edge records again (rel_flags collapses to "skipped or not")
+__global__ __launch_bounds__(256) void unpack_records_kernel(const uint64_t *pair, const uint8_t *bad, uint64_t count, const u128 *key_of_pid, hb_edge *out)
+{
+    HB_GRID_STRIDE(i, count)
+    {
+        const uint64_t pr = pair[i];
+        const u128 f = key_of_pid[(uint32_t)pr], t = key_of_pid[(uint32_t)(pr >> 32)];
+        hb_edge e;
+        e.from.lo = (uint64_t)f;
+        e.from.hi = (uint64_t)(f >> 64);
+        e.to.lo = (uint64_t)t;
+        e.to.hi = (uint64_t)(t >> 64);
+        e.rel_flags = bad[i] ? HB_SKIPPED_REL_MASK : 0;
+        out[i] = e;
+    }
 }
 
 // position of every kept result in the order (Reverse(total_cmp(centrality)), NodeID ascending)
@@ -172,28 +303,20 @@ __global__ __launch_bounds__(256) void csr_from_keys_kernel(const uint64_t *sel,
 // vals: one f64 per node in ascending-NodeID order, negative = absent (hb_finish).
 __global__ __launch_bounds__(256) void rank_keys_kernel(const double *vals, uint64_t n, uint64_t *key, uint8_t *keep)
 {
-    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    const double v = vals[i];
-    keep[i] = v >= 0.0 ? 1 : 0;
-    uint64_t b = (uint64_t)__double_as_longlong(v);
-    b ^= (b >> 63) ? ~0ull : 0x8000000000000000ull; // total_cmp order as unsigned order
-    key[i] = ~b;                                    // Reverse(...)
+    HB_GRID_STRIDE(i, n)
+    {
+        const double v = vals[i];
+        keep[i] = v >= 0.0 ? 1 : 0;
+        uint64_t b = (uint64_t)__double_as_longlong(v);
+        b ^= (b >> 63) ? ~0ull : 0x8000000000000000ull; // total_cmp order as unsigned order
+        key[i] = ~b;                                    // Reverse(...)
+    }
 }
 __global__ __launch_bounds__(256) void rank_scatter_kernel(const uint64_t *sorted_idx, uint64_t k, uint64_t *rank)
 {
-    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i < k) rank[sorted_idx[i]] = i;
+    HB_GRID_STRIDE(i, k) rank[sorted_idx[i]] = i;
 }
 
-struct LowHalf {
-    __device__ uint32_t operator()(uint64_t k) const { return (uint32_t)k; }
-};
-struct ByteToU64 {
-    __device__ uint64_t operator()(uint8_t b) const { return (uint64_t)b; }
-};
-
-unsigned grid_for(uint64_t count) { return (unsigned)((count + 255) / 256); }
 
 } // namespace
 
@@ -202,7 +325,7 @@ namespace hb {
 void IngestStream::free_all()
 {
     for (IngestChunk &c : chunks) {
-        if (c.d_end) (void)hipFree(c.d_end);
+        if (c.d_pair) (void)hipFree(c.d_pair);
         if (c.d_bad) (void)hipFree(c.d_bad);
     }
     chunks.clear();
@@ -210,18 +333,109 @@ void IngestStream::free_all()
         if (p) (void)hipFree(p);
         p = nullptr;
     }
+    if (kstream) {
+        (void)hipStreamSynchronize((hipStream_t)kstream);
+        (void)hipStreamDestroy((hipStream_t)kstream);
+        kstream = nullptr;
+    }
+    if (d_tab_keys) (void)hipFree(d_tab_keys);
+    if (d_tab_pids) (void)hipFree(d_tab_pids);
+    if (d_counter) (void)hipFree(d_counter);
+    if (h_counter) (void)hipHostFree(h_counter);
+    d_tab_keys = nullptr;
+    d_tab_pids = nullptr;
+    d_counter = nullptr;
+    h_counter = nullptr;
+    tab_slots = 0;
+    npid_known = unsynced = 0;
     count = bytes = 0;
 }
 
-// Records -> device, behind what is already there: endpoint keys (2 per record, stream order) and "flagged" bytes, in
-// chunks of at most chunk_records records (no reallocation / copy when the stream grows, nothing over-allocated: the
-// whole stream costs 33 bytes per record).  Slab-wise H2D through two staging buffers.  On failure ("... out of
-// memory") the stream holds exactly the records of the earlier batches.
+namespace {
+
+Table table_of(const IngestStream *st)
+{
+    return Table{(u128 *)st->d_tab_keys, st->d_tab_pids, st->tab_slots - 1, (unsigned long long *)st->d_counter};
+}
+
+// exact number of pids handed out (synchronises the stream)
+std::string read_npid(hipStream_t stream, IngestStream *st)
+{
+    IG_HIP(hipMemcpyAsync(st->h_counter, st->d_counter, sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
+    IG_HIP(hipStreamSynchronize(stream));
+    st->npid_known = *st->h_counter;
+    st->unsynced = 0;
+    return "";
+}
+
+// The table must be able to take `incoming` more records (2 endpoints each) at a load factor <= 1/2.  The number of keys
+// is only known exactly after a synchronisation, so the test runs on an upper bound (keys at the last read-back + 2 per
+// record launched since) and synchronises only when that bound says the table might be too small.
+// "... out of memory" when the (larger) table cannot be allocated or the debug byte limit forbids it.
+std::string table_reserve(hipStream_t stream, IngestStream *st, uint64_t incoming)
+{
+    if (!st->d_counter) {
+        IG_HIP(hipMalloc((void **)&st->d_counter, 256));
+        IG_HIP(hipHostMalloc((void **)&st->h_counter, sizeof(unsigned long long)));
+        IG_HIP(hipMemsetAsync(st->d_counter, 0, 256, stream));
+    }
+    auto fits = [&](uint64_t slots) { return slots && (st->npid_known + 2 * st->unsynced + 2 * incoming) * 2 <= slots; };
+    if (fits(st->tab_slots)) return "";
+    if (st->tab_slots) {
+        const std::string e = read_npid(stream, st);
+        if (!e.empty()) return e;
+        if (fits(st->tab_slots)) return "";
+    }
+    if (st->npid_known + 2 * incoming >= kMaxPids) return "too many nodes for the device ingest (2^31 endpoint ids)";
+    uint64_t slots = 1ull << 12;
+    while (slots < 4 * (st->npid_known + 2 * incoming)) slots <<= 1; // load factor <= 1/4 right after growing
+    const uint64_t add = slots * 20;
+    if (st->max_bytes && st->bytes + add > st->max_bytes) return "hipMalloc(endpoint table): out of memory";
+    void *nk = nullptr;
+    uint32_t *np = nullptr;
+    if (hipMalloc(&nk, slots * 16) != hipSuccess) {
+        (void)hipGetLastError();
+        return "hipMalloc(endpoint table): out of memory";
+    }
+    if (hipMalloc((void **)&np, slots * 4) != hipSuccess) {
+        (void)hipGetLastError();
+        (void)hipFree(nk);
+        return "hipMalloc(endpoint table): out of memory";
+    }
+    hipLaunchKernelGGL(table_clear_kernel, dim3(grid_for(slots)), dim3(256), 0, stream, np, slots);
+    IG_HIP(hipGetLastError());
+    const uint64_t old_slots = st->tab_slots;
+    void *ok = st->d_tab_keys;
+    uint32_t *op = st->d_tab_pids;
+    st->d_tab_keys = nk;
+    st->d_tab_pids = np;
+    st->tab_slots = slots;
+    st->bytes += add;
+    st->peak_bytes = std::max(st->peak_bytes, st->bytes);
+    if (old_slots) {
+        hipLaunchKernelGGL(rehash_kernel, dim3(grid_for(old_slots)), dim3(256), 0, stream, (const u128 *)ok, (const uint32_t *)op, old_slots, table_of(st));
+        IG_HIP(hipGetLastError());
+        IG_HIP(hipStreamSynchronize(stream));
+        (void)hipFree(ok);
+        (void)hipFree(op);
+        st->bytes -= old_slots * 20;
+    }
+    return "";
+}
+
+} // namespace
+
+// Records -> device, behind what is already there: every endpoint goes through the endpoint table (a 32-bit provisional
+// id per distinct NodeID), the record is kept as (from pid, to pid) + its "flagged" byte - 9 bytes - in chunks of at most
+// chunk_records records (no reallocation / copy when the stream grows).  Slab-wise H2D through two staging buffers: the
+// table kernel of slab k runs while slab k + 1 crosses the link.  On failure ("... out of memory", "too many ...") the
+// stream holds exactly the records of the earlier batches (the table may know a few endpoints more: harmless, a failed
+// stream is spilled to the host and the table dropped).
 std::string gpu_ingest_append(void *stream_v, IngestStream *st, const hb_edge *edges, uint64_t m)
 {
     hipStream_t stream = (hipStream_t)stream_v;
     if (!m) return "";
-    if (st->max_records && st->count + m > st->max_records) return "too many records for the device ingest (2^32 limit): use HB_FLAG_HOST_INGEST";
+    if (st->max_records && st->count + m >= st->max_records) return "too many records for the device ingest: use HB_FLAG_HOST_INGEST";
     const uint64_t slab = 1ull << 22; // 4 Mi records = 160 MiB per slab, two slabs in flight
     for (int k = 0; k < 2; k++)
         if (!st->d_slab[k]) {
@@ -240,32 +454,46 @@ std::string gpu_ingest_append(void *stream_v, IngestStream *st, const hb_edge *e
         st->slab_cap = 0;
         return gpu_ingest_append(stream_v, st, edges, m);
     }
+    // two streams: the copies run on the caller's stream, the table kernels on the stream of the ingest; slab k is being
+    // reduced while slab k + 1 crosses the link (events: copied[b] = slab buffer b filled, consumed[b] = its kernel done)
+    if (!st->kstream) {
+        hipStream_t ks = nullptr;
+        IG_HIP(hipStreamCreateWithFlags(&ks, hipStreamNonBlocking));
+        st->kstream = (void *)ks;
+    }
+    hipStream_t kstream = (hipStream_t)st->kstream;
     struct Events { // destroyed on every exit path
-        hipEvent_t e[2] = {nullptr, nullptr};
+        hipEvent_t copied[2] = {nullptr, nullptr}, consumed[2] = {nullptr, nullptr};
         ~Events()
         {
-            for (hipEvent_t x : e)
+            for (hipEvent_t x : copied)
+                if (x) (void)hipEventDestroy(x);
+            for (hipEvent_t x : consumed)
                 if (x) (void)hipEventDestroy(x);
         }
     } evs;
-    IG_HIP(hipEventCreateWithFlags(&evs.e[0], hipEventDisableTiming));
-    IG_HIP(hipEventCreateWithFlags(&evs.e[1], hipEventDisableTiming));
+    for (int k = 0; k < 2; k++) {
+        IG_HIP(hipEventCreateWithFlags(&evs.copied[k], hipEventDisableTiming));
+        IG_HIP(hipEventCreateWithFlags(&evs.consumed[k], hipEventDisableTiming));
+    }
+    IG_HIP(hipStreamSynchronize(stream)); // whatever the caller's stream still does must not race the kernels of the other one
     // state to restore if the device runs out of memory in the middle of this batch
     const size_t chunks_before = st->chunks.size();
-    const uint64_t last_count_before = chunks_before ? st->chunks.back().count : 0, count_before = st->count, bytes_before = st->bytes;
+    const uint64_t last_count_before = chunks_before ? st->chunks.back().count : 0, count_before = st->count;
     auto undo = [&]() {
         (void)hipStreamSynchronize(stream);
+        (void)hipStreamSynchronize(kstream);
         while (st->chunks.size() > chunks_before) {
-            (void)hipFree(st->chunks.back().d_end);
+            (void)hipFree(st->chunks.back().d_pair);
             (void)hipFree(st->chunks.back().d_bad);
+            st->bytes -= st->chunks.back().cap * 9;
             st->chunks.pop_back();
         }
         if (chunks_before) st->chunks.back().count = last_count_before;
         st->count = count_before;
-        st->bytes = bytes_before;
         (void)hipGetLastError();
     };
-    const uint64_t chunk_records = st->chunk_records ? st->chunk_records : (1ull << 26);
+    const uint64_t chunk_records = st->chunk_records ? st->chunk_records : (1ull << 27);
     int b = 0;
     for (uint64_t off = 0; off < m; b ^= 1) {
         if (st->chunks.empty() || st->chunks.back().count == st->chunks.back().cap) {
@@ -273,31 +501,83 @@ std::string gpu_ingest_append(void *stream_v, IngestStream *st, const hb_edge *e
             uint64_t cap = 1ull << 20;
             while (cap < m - off && cap < chunk_records) cap <<= 1;
             c.cap = std::min(cap, chunk_records);
-            const uint64_t add = c.cap * 33;
-            if ((st->max_bytes && st->bytes + add > st->max_bytes) || hipMalloc(&c.d_end, c.cap * 32) != hipSuccess) {
+            const uint64_t add = c.cap * 9;
+            if ((st->max_bytes && st->bytes + add > st->max_bytes) || hipMalloc((void **)&c.d_pair, c.cap * 8) != hipSuccess) {
                 undo();
-                return "hipMalloc(endpoint keys): out of memory";
+                return "hipMalloc(record chunk): out of memory";
             }
             if (hipMalloc((void **)&c.d_bad, c.cap) != hipSuccess) {
-                (void)hipFree(c.d_end);
+                (void)hipFree(c.d_pair);
                 undo();
                 return "hipMalloc(flag bytes): out of memory";
             }
             st->bytes += add;
+            st->peak_bytes = std::max(st->peak_bytes, st->bytes);
             st->chunks.push_back(c);
         }
         IngestChunk &c = st->chunks.back();
         const uint64_t cnt = std::min(std::min(slab, m - off), c.cap - c.count);
-        IG_HIP(hipEventSynchronize(evs.e[b])); // the kernel that last read this slab buffer has finished
+        {
+            const std::string e = table_reserve(kstream, st, cnt); // (all table work lives on the ingest's stream)
+            if (!e.empty()) {
+                undo();
+                return e;
+            }
+        }
+        IG_HIP(hipStreamWaitEvent(stream, evs.consumed[b], 0)); // the kernel that last read this slab buffer has finished
         IG_HIP(hipMemcpyAsync(st->d_slab[b], edges + off, cnt * sizeof(hb_edge), hipMemcpyHostToDevice, stream));
-        hipLaunchKernelGGL(unpack_kernel, dim3(grid_for(cnt)), dim3(256), 0, stream, (const hb_edge *)st->d_slab[b], cnt, c.count, (u128 *)c.d_end, c.d_bad);
+        IG_HIP(hipEventRecord(evs.copied[b], stream));
+        IG_HIP(hipStreamWaitEvent(kstream, evs.copied[b], 0));
+        hipLaunchKernelGGL(insert_kernel, dim3(grid_for(cnt)), dim3(256), 0, kstream, (const hb_edge *)st->d_slab[b], cnt, c.count, table_of(st), c.d_pair,
+                           c.d_bad);
         IG_HIP(hipGetLastError());
-        IG_HIP(hipEventRecord(evs.e[b], stream));
+        IG_HIP(hipEventRecord(evs.consumed[b], kstream));
+        st->unsynced += cnt;
         c.count += cnt;
         st->count += cnt;
         off += cnt;
     }
     IG_HIP(hipStreamSynchronize(stream));
+    IG_HIP(hipStreamSynchronize(kstream));
+    return "";
+}
+
+// the records held on the device -> hb_edge records on the host, appended to *out (the stream moves to the host path when
+// the device cannot hold it); consumes the stream
+std::string gpu_ingest_spill(void *stream_v, IngestStream *st, std::vector<hb_edge> *out)
+{
+    hipStream_t stream = (hipStream_t)stream_v;
+    struct FreeStream {
+        IngestStream *s;
+        ~FreeStream() { s->free_all(); }
+    } free_stream{st};
+    if (!st->count) return "";
+    std::string e = read_npid(stream, st);
+    if (!e.empty()) return e;
+    const uint64_t npid = st->npid_known;
+    DevMem mem;
+    u128 *d_key_of_pid = nullptr;
+    IG_HIP(mem.alloc(&d_key_of_pid, std::max<uint64_t>(npid, 1)));
+    hipLaunchKernelGGL(table_export_kernel, dim3(grid_for(st->tab_slots)), dim3(256), 0, stream, (const u128 *)st->d_tab_keys, (const uint32_t *)st->d_tab_pids,
+                       st->tab_slots, d_key_of_pid, npid);
+    IG_HIP(hipGetLastError());
+    const size_t at = out->size();
+    out->resize(at + st->count);
+    uint64_t base = 0, piece = 0;
+    for (const IngestChunk &c : st->chunks) piece = std::max(piece, std::min<uint64_t>(c.count, 1ull << 22));
+    hb_edge *d_rec = nullptr;
+    IG_HIP(mem.alloc(&d_rec, std::max<uint64_t>(piece, 1)));
+    for (const IngestChunk &c : st->chunks) {
+        for (uint64_t o = 0; o < c.count; o += piece) {
+            const uint64_t k = std::min(piece, c.count - o);
+            hipLaunchKernelGGL(unpack_records_kernel, dim3(grid_for(k)), dim3(256), 0, stream, (const uint64_t *)c.d_pair + o, (const uint8_t *)c.d_bad + o, k,
+                               (const u128 *)d_key_of_pid, d_rec);
+            IG_HIP(hipGetLastError());
+            IG_HIP(hipMemcpyAsync(out->data() + at + base + o, d_rec, k * sizeof(hb_edge), hipMemcpyDeviceToHost, stream));
+            IG_HIP(hipStreamSynchronize(stream));
+        }
+        base += c.count;
+    }
     return "";
 }
 
@@ -307,7 +587,6 @@ std::string gpu_ingest_edges(void *stream_v, const hb_u128 *node_ids, uint64_t n
     if (keep) *keep = DeviceCsr{};
     if (m && !edges) return "edges == NULL with m > 0";
     IngestStream st;
-    st.max_records = 0xFFFFFF00ull;
     std::string e = gpu_ingest_append(stream_v, &st, edges, m);
     if (!e.empty()) {
         st.free_all();
@@ -345,12 +624,7 @@ static std::string sort_unique_keys(hipStream_t stream, DevMem &mem, u128 *d_key
     return "";
 }
 
-// The reduction proper, from records that are already on the device (gpu_ingest_append); consumes the stream: every
-// chunk is freed as soon as its records are turned into 12-byte (pair key, position) entries.
-// Device memory: 33 B per record while the stream is held, + 12 B per record of pair keys / positions, + the node set
-// (16 B per node, built chunk by chunk: a chunk's 2 x count endpoint keys are sorted, made unique and merged into the
-// running sorted set - never a sort over all 2m endpoints); then, the chunks gone, 24 B per record for the stable
-// (to, from) sort.
+// The reduction proper, from records that are already on the device (gpu_ingest_append); consumes the stream.
 std::string gpu_ingest_reduce(void *stream_v, const hb_u128 *node_ids, uint64_t n_in, IngestStream *st, DenseGraph *out, DeviceCsr *keep,
                               uint64_t *peak_bytes)
 {
@@ -370,19 +644,18 @@ std::string gpu_ingest_reduce(void *stream_v, const hb_u128 *node_ids, uint64_t 
     DevMem mem;
     struct Peak {
         DevMem &mem;
+        IngestStream *st;
         uint64_t *out;
         ~Peak()
         {
-            if (out) *out = mem.peak;
+            if (out) *out = std::max<uint64_t>(mem.peak, st->peak_bytes);
         }
-    } peak_guard{mem, peak_bytes};
-    mem.note(st->bytes);
+    } peak_guard{mem, st, peak_bytes};
     for (void *&p : st->d_slab) { // the staging buffers are no longer needed
         if (p) (void)hipFree(p);
         p = nullptr;
     }
-    // one-thread-per-record kernels below: a dispatch holds at most 2^32 - 1 work-items, positions are 32-bit
-    if (m >= 0xFFFFFF00ull) return "too many records for the device ingest (2^32 limit): use HB_FLAG_HOST_INGEST";
+    mem.note(st->bytes);
     void *tmp = nullptr;
     size_t tmp_bytes = 0;
     auto need_tmp = [&](size_t bytes) -> hipError_t {
@@ -403,13 +676,38 @@ std::string gpu_ingest_reduce(void *stream_v, const hb_u128 *node_ids, uint64_t 
         if (!trace) return;
         (void)hipStreamSynchronize(stream);
         const double t = now_ms();
-        std::fprintf(stderr, "[hb ingest] %-28s %9.1f ms   (device bytes held %.2f GB, peak %.2f GB)\n", what, t - t_lap, mem.cur / 1e9, mem.peak / 1e9);
+        std::fprintf(stderr, "[hb ingest] %-34s %9.1f ms   (device bytes held %.2f GB, peak %.2f GB)\n", what, t - t_lap, mem.cur / 1e9, mem.peak / 1e9);
         t_lap = t;
     };
 
-    // ---- node set: sorted unique u128 keys in d_ids
+    // ---- the table's keys by pid; the table itself is no longer needed
+    uint64_t npid = 0;
+    u128 *d_key_of_pid = nullptr;
+    if (st->tab_slots) {
+        const std::string e = read_npid(stream, st);
+        if (!e.empty()) return e;
+        npid = st->npid_known;
+        if (npid >= kMaxPids) return "too many nodes for the device ingest (2^31 endpoint ids)";
+        IG_HIP(mem.alloc(&d_key_of_pid, std::max<uint64_t>(npid, 1)));
+        hipLaunchKernelGGL(table_export_kernel, dim3(grid_for(st->tab_slots)), dim3(256), 0, stream, (const u128 *)st->d_tab_keys,
+                           (const uint32_t *)st->d_tab_pids, st->tab_slots, d_key_of_pid, npid);
+        IG_HIP(hipGetLastError());
+        IG_HIP(hipStreamSynchronize(stream));
+        (void)hipFree(st->d_tab_keys);
+        (void)hipFree(st->d_tab_pids);
+        st->d_tab_keys = nullptr;
+        st->d_tab_pids = nullptr;
+        mem.unnote(st->tab_slots * 20);
+        st->bytes -= st->tab_slots * 20;
+        st->tab_slots = 0;
+    }
+    lap("endpoint keys by pid");
+
+    // ---- node set: sorted unique u128 keys in d_ids, and the sid of every pid
     u128 *d_ids = nullptr;
+    uint32_t *d_sid_of_pid = nullptr;
     uint64_t n = 0;
+    IG_HIP(mem.alloc(&d_sid_of_pid, std::max<uint64_t>(npid, 1)));
     if (node_ids && n_in) {
         u128 *d_alt = nullptr;
         hb_u128 *d_raw = nullptr;
@@ -425,62 +723,42 @@ std::string gpu_ingest_reduce(void *stream_v, const hb_u128 *node_ids, uint64_t 
         if (!e.empty()) return e;
         IG_HIP(hipStreamSynchronize(stream));
         mem.release(d_alt);
-    } else {
-        // work buffers are allocated once (multi-GB hipMalloc / hipFree per chunk is what would dominate here): two key
-        // buffers for the largest chunk, two set buffers that grow by doubling
-        uint64_t max_cand = 0;
-        for (const IngestChunk &c : st->chunks) max_cand = std::max(max_cand, 2 * c.count);
-        u128 *d_keys = nullptr, *d_alt = nullptr, *d_set[2] = {nullptr, nullptr};
-        uint64_t set_cap = 0;
-        if (max_cand) {
-            IG_HIP(mem.alloc(&d_keys, max_cand));
-            IG_HIP(mem.alloc(&d_alt, max_cand));
+        if (npid) {
+            hipLaunchKernelGGL(sid_search_kernel, dim3(grid_for(npid)), dim3(256), 0, stream, (const u128 *)d_key_of_pid, npid, (const u128 *)d_ids, n,
+                               d_sid_of_pid);
+            IG_HIP(hipGetLastError());
         }
-        for (const IngestChunk &c : st->chunks) {
-            if (!c.count) continue;
-            const uint64_t cand = 2 * c.count;
-            IG_HIP(hipMemcpyAsync(d_keys, c.d_end, cand * sizeof(u128), hipMemcpyDeviceToDevice, stream));
-            uint64_t cu = 0;
-            std::string e = sort_unique_keys(stream, mem, d_keys, d_alt, cand, tmp, tmp_bytes, d_n, &cu);
-            if (!e.empty()) return e;
-            IG_HIP(hipStreamSynchronize(stream));
-            if (n + cu > set_cap) { // grow both set buffers; the running set moves to the new d_set[0]
-                const uint64_t cap = std::max<uint64_t>(n + cu, 2 * set_cap);
-                u128 *a0 = nullptr, *a1 = nullptr;
-                IG_HIP(mem.alloc(&a0, cap));
-                if (n) IG_HIP(hipMemcpyAsync(a0, d_set[0], n * sizeof(u128), hipMemcpyDeviceToDevice, stream));
-                IG_HIP(hipStreamSynchronize(stream));
-                if (d_set[0]) mem.release(d_set[0]);
-                if (d_set[1]) mem.release(d_set[1]);
-                IG_HIP(mem.alloc(&a1, cap));
-                d_set[0] = a0;
-                d_set[1] = a1;
-                set_cap = cap;
-            }
-            if (n == 0) { // the first chunk's set is the running set
-                IG_HIP(hipMemcpyAsync(d_set[0], d_keys, cu * sizeof(u128), hipMemcpyDeviceToDevice, stream));
-                n = cu;
-                continue;
-            }
-            // running set U chunk set: merge the two sorted unique lists, drop the keys present in both
-            size_t bytes = 0;
-            IG_HIP(rocprim::merge(nullptr, bytes, d_set[0], d_keys, d_set[1], (size_t)n, (size_t)cu, rocprim::less<u128>(), stream));
-            IG_HIP(need_tmp(bytes));
-            IG_HIP(rocprim::merge(tmp, bytes, d_set[0], d_keys, d_set[1], (size_t)n, (size_t)cu, rocprim::less<u128>(), stream));
-            bytes = 0;
-            IG_HIP(rocprim::unique(nullptr, bytes, d_set[1], d_set[0], d_n, (size_t)(n + cu), rocprim::equal_to<u128>(), stream));
-            IG_HIP(need_tmp(bytes));
-            IG_HIP(rocprim::unique(tmp, bytes, d_set[1], d_set[0], d_n, (size_t)(n + cu), rocprim::equal_to<u128>(), stream));
-            IG_HIP(hipMemcpyAsync(&n, d_n, sizeof(uint64_t), hipMemcpyDeviceToHost, stream));
-            IG_HIP(hipStreamSynchronize(stream));
-        }
-        if (d_keys) mem.release(d_keys);
-        if (d_alt) mem.release(d_alt);
-        if (d_set[1]) mem.release(d_set[1]);
-        d_ids = d_set[0];
+    } else if (npid) {
+        // table keys are distinct: one 128-bit sort carrying the pid gives the ids in order and every pid's rank
+        u128 *d_alt = nullptr;
+        uint32_t *d_pid = nullptr, *d_pid_alt = nullptr;
+        IG_HIP(mem.alloc(&d_alt, npid));
+        IG_HIP(mem.alloc(&d_pid, npid));
+        IG_HIP(mem.alloc(&d_pid_alt, npid));
+        hipLaunchKernelGGL(iota_kernel, dim3(grid_for(npid)), dim3(256), 0, stream, d_pid, npid);
+        IG_HIP(hipGetLastError());
+        rocprim::double_buffer<u128> kb(d_key_of_pid, d_alt);
+        rocprim::double_buffer<uint32_t> vb(d_pid, d_pid_alt);
+        size_t bytes = 0;
+        IG_HIP(rocprim::radix_sort_pairs(nullptr, bytes, kb, vb, (size_t)npid, 0, 128, stream));
+        IG_HIP(need_tmp(bytes));
+        IG_HIP(rocprim::radix_sort_pairs(tmp, bytes, kb, vb, (size_t)npid, 0, 128, stream));
+        hipLaunchKernelGGL(sid_scatter_kernel, dim3(grid_for(npid)), dim3(256), 0, stream, (const uint32_t *)vb.current(), npid, d_sid_of_pid);
+        IG_HIP(hipGetLastError());
+        IG_HIP(hipStreamSynchronize(stream));
+        d_ids = kb.current();
+        mem.release(kb.alternate());
+        mem.release(d_pid);
+        mem.release(d_pid_alt);
+        d_key_of_pid = nullptr; // either it is d_ids now or it was the alternate buffer just released
+        n = npid;
     }
-    lap("node set");
-    if (n >= 0xFFFFFFFFull - (1u << 20)) return "too many nodes (n must be < 2^32 - 2^20)";
+    if (d_key_of_pid) {
+        IG_HIP(hipStreamSynchronize(stream));
+        mem.release(d_key_of_pid);
+    }
+    lap("node set, sid of every pid");
+    if (n >= (1ull << 30)) return "too many nodes (n must be < 2^30)";
     try {
         out->ids.resize(n);
         out->row_ptr.assign(n + 1, 0);
@@ -496,106 +774,103 @@ std::string gpu_ingest_reduce(void *stream_v, const hb_u128 *node_ids, uint64_t 
         IG_HIP(hipStreamSynchronize(stream));
         mem.release(d_out_ids);
     }
+    if (d_ids) mem.release(d_ids);
+    lap("ids to the host");
     if (n == 0 || m == 0) return "";
 
-    // ---- pair keys + stream positions, chunk by chunk; a chunk is freed once its records are mapped
-    uint64_t *d_pair = nullptr, *d_pair_alt = nullptr;
-    uint32_t *d_pos = nullptr, *d_pos_alt = nullptr;
-    uint8_t *d_bad = nullptr;
-    IG_HIP(mem.alloc(&d_pair, m));
-    IG_HIP(mem.alloc(&d_pos, m));
-    IG_HIP(mem.alloc(&d_bad, m));
+    // ---- sort keys (to sid, from sid, flag), chunk by chunk into one array; a chunk is freed once its records are mapped
+    uint32_t nb = 1;
+    while ((1ull << nb) <= n) nb++; // bits of n: every sid < n fits, and the all-ones field never is a sid
+    uint64_t *d_key = nullptr, *d_key_alt = nullptr;
+    IG_HIP(mem.alloc(&d_key, m));
     {
         uint64_t base = 0;
         for (IngestChunk &c : st->chunks) {
             if (c.count) {
-                hipLaunchKernelGGL(pair_keys_kernel, dim3(grid_for(c.count)), dim3(256), 0, stream, (const u128 *)c.d_end, c.count, base,
-                                   (const u128 *)d_ids, n, d_pair, d_pos);
+                hipLaunchKernelGGL(pair_keys_kernel, dim3(grid_for(c.count)), dim3(256), 0, stream, (const uint64_t *)c.d_pair, (const uint8_t *)c.d_bad,
+                                   c.count, (const uint32_t *)d_sid_of_pid, nb, d_key + base);
                 IG_HIP(hipGetLastError());
-                IG_HIP(hipMemcpyAsync(d_bad + base, c.d_bad, c.count, hipMemcpyDeviceToDevice, stream));
                 IG_HIP(hipStreamSynchronize(stream));
             }
             base += c.count;
-            (void)hipFree(c.d_end);
+            (void)hipFree(c.d_pair);
             (void)hipFree(c.d_bad);
-            c.d_end = nullptr;
+            c.d_pair = nullptr;
             c.d_bad = nullptr;
-            mem.unnote(c.cap * 33);
+            mem.unnote(c.cap * 9);
         }
         st->chunks.clear();
         st->bytes = 0;
     }
-    mem.release(d_ids);
+    mem.release(d_sid_of_pid);
     lap("pair keys, chunks freed");
 
-    // ---- stable sort by (to, from): the first record of every pair heads its run
-    IG_HIP(mem.alloc(&d_pair_alt, m));
-    IG_HIP(mem.alloc(&d_pos_alt, m));
-    uint64_t *d_pair_s = nullptr;
-    uint32_t *d_pos_s = nullptr;
+    // ---- stable sort by (to, from) - bit 0, the flag, is NOT a sort bit: the first record of every pair heads its run
+    IG_HIP(mem.alloc(&d_key_alt, m));
+    uint64_t *d_sorted = nullptr, *d_other = nullptr;
     {
-        rocprim::double_buffer<uint64_t> kb(d_pair, d_pair_alt);
-        rocprim::double_buffer<uint32_t> vb(d_pos, d_pos_alt);
+        rocprim::double_buffer<uint64_t> kb(d_key, d_key_alt);
         size_t bytes = 0;
-        IG_HIP(rocprim::radix_sort_pairs(nullptr, bytes, kb, vb, (size_t)m, 0, 64, stream));
+        IG_HIP(rocprim::radix_sort_keys(nullptr, bytes, kb, (size_t)m, 1u, 1u + 2u * nb, stream));
         IG_HIP(need_tmp(bytes));
-        IG_HIP(rocprim::radix_sort_pairs(tmp, bytes, kb, vb, (size_t)m, 0, 64, stream));
+        IG_HIP(rocprim::radix_sort_keys(tmp, bytes, kb, (size_t)m, 1u, 1u + 2u * nb, stream));
         IG_HIP(hipStreamSynchronize(stream));
-        d_pair_s = kb.current();
-        d_pos_s = vb.current();
-        mem.release(kb.alternate());
-        mem.release(vb.alternate());
+        d_sorted = kb.current();
+        d_other = kb.alternate();
     }
     lap("stable sort of the pairs");
 
-    // ---- heads, flag filter
-    uint8_t *d_keep = nullptr;
-    unsigned long long *d_counts = nullptr;
-    IG_HIP(mem.alloc(&d_keep, m));
-    IG_HIP(mem.alloc(&d_counts, 64));
-    IG_HIP(hipMemsetAsync(d_counts, 0, 64 * sizeof(unsigned long long), stream));
-    hipLaunchKernelGGL(heads_kernel, dim3(grid_for(m)), dim3(256), 0, stream, (const uint64_t *)d_pair_s, (const uint32_t *)d_pos_s,
-                       (const uint8_t *)d_bad, m, d_keep, d_counts);
-    IG_HIP(hipGetLastError());
-    unsigned long long h_counts[64];
-    IG_HIP(hipMemcpyAsync(h_counts, d_counts, sizeof(h_counts), hipMemcpyDeviceToHost, stream));
-    IG_HIP(hipStreamSynchronize(stream));
-    mem.release(d_pos_s);
-    mem.release(d_bad);
-    lap("heads");
+    // ---- heads, flag filter, compaction into the other sort buffer; segments of <= 2^30 records (one rocPRIM call never
+    // sees more items than fit 32-bit offsets)
+    uint64_t m_eff = 0;
+    {
+        const uint64_t seg = 1ull << 30;
+        for (uint64_t off = 0; off < m; off += seg) {
+            const uint64_t cnt = std::min(seg, m - off);
+            auto idx = rocprim::make_counting_iterator<uint64_t>(off);
+            auto kept = rocprim::make_transform_iterator(idx, HeadKept{d_sorted});
+            auto any = rocprim::make_transform_iterator(idx, HeadAny{d_sorted});
+            size_t bytes = 0;
+            IG_HIP(rocprim::reduce(nullptr, bytes, any, d_n, (uint64_t)0, (size_t)cnt, rocprim::plus<uint64_t>(), stream));
+            IG_HIP(need_tmp(bytes));
+            IG_HIP(rocprim::reduce(tmp, bytes, any, d_n, (uint64_t)0, (size_t)cnt, rocprim::plus<uint64_t>(), stream));
+            uint64_t heads = 0, sel = 0;
+            IG_HIP(hipMemcpyAsync(&heads, d_n, sizeof(uint64_t), hipMemcpyDeviceToHost, stream));
+            IG_HIP(hipStreamSynchronize(stream)); // heads read back before d_n is reused, the reduction done before tmp may move
+            bytes = 0;
+            IG_HIP(rocprim::select(nullptr, bytes, d_sorted + off, kept, d_other + m_eff, d_n, (size_t)cnt, stream));
+            IG_HIP(need_tmp(bytes));
+            IG_HIP(rocprim::select(tmp, bytes, d_sorted + off, kept, d_other + m_eff, d_n, (size_t)cnt, stream));
+            IG_HIP(hipMemcpyAsync(&sel, d_n, sizeof(uint64_t), hipMemcpyDeviceToHost, stream));
+            IG_HIP(hipStreamSynchronize(stream));
+            out->m_unique += heads;
+            m_eff += sel;
+        }
+    }
+    mem.release(d_sorted);
+    lap("heads, filter, compaction");
 
     // ---- the kept (to, from) keys, still ascending -> sources + row pointers
     uint32_t *d_src = nullptr;
-    uint64_t *d_row_ptr = nullptr, *d_sel = nullptr;
-    uint64_t m_eff = 0;
-    {
-        // count first, so that the arrays are allocated at their final size (the source array outlives this function)
-        size_t bytes = 0;
-        IG_HIP(rocprim::reduce(nullptr, bytes, rocprim::make_transform_iterator(d_keep, ByteToU64()), d_n, (uint64_t)0, (size_t)m, rocprim::plus<uint64_t>(), stream));
-        IG_HIP(need_tmp(bytes));
-        IG_HIP(rocprim::reduce(tmp, bytes, rocprim::make_transform_iterator(d_keep, ByteToU64()), d_n, (uint64_t)0, (size_t)m, rocprim::plus<uint64_t>(), stream));
-        IG_HIP(hipMemcpyAsync(&m_eff, d_n, sizeof(uint64_t), hipMemcpyDeviceToHost, stream));
-        IG_HIP(hipStreamSynchronize(stream));
-        IG_HIP(mem.alloc(&d_sel, std::max<uint64_t>(m_eff, 1)));
-        bytes = 0;
-        IG_HIP(rocprim::select(nullptr, bytes, d_pair_s, d_keep, d_sel, d_n, (size_t)m, stream));
-        IG_HIP(need_tmp(bytes));
-        IG_HIP(rocprim::select(tmp, bytes, d_pair_s, d_keep, d_sel, d_n, (size_t)m, stream));
-        uint64_t m_sel = 0;
-        IG_HIP(hipMemcpyAsync(&m_sel, d_n, sizeof(uint64_t), hipMemcpyDeviceToHost, stream));
-        IG_HIP(hipStreamSynchronize(stream));
-        if (m_sel != m_eff) return "gpu ingest: kept-record count mismatch";
-    }
-    mem.release(d_pair_s);
-    mem.release(d_keep);
+    uint64_t *d_row_end = nullptr, *d_row_ptr = nullptr;
     IG_HIP(mem.alloc(&d_src, std::max<uint64_t>(m_eff, 1)));
+    IG_HIP(mem.alloc(&d_row_end, n + 1));
     IG_HIP(mem.alloc(&d_row_ptr, n + 1));
-    hipLaunchKernelGGL(csr_from_keys_kernel, dim3(grid_for(m_eff + 1)), dim3(256), 0, stream, (const uint64_t *)d_sel, m_eff, n, d_src, d_row_ptr);
-    IG_HIP(hipGetLastError());
+    IG_HIP(hipMemsetAsync(d_row_end, 0, (n + 1) * sizeof(uint64_t), stream));
+    if (m_eff) {
+        hipLaunchKernelGGL(csr_from_keys_kernel, dim3(grid_for(m_eff)), dim3(256), 0, stream, (const uint64_t *)d_other, m_eff, nb, d_src, d_row_end);
+        IG_HIP(hipGetLastError());
+    }
+    {
+        size_t bytes = 0;
+        IG_HIP(rocprim::inclusive_scan(nullptr, bytes, d_row_end, d_row_ptr, (size_t)(n + 1), MaxU64(), stream));
+        IG_HIP(need_tmp(bytes));
+        IG_HIP(rocprim::inclusive_scan(tmp, bytes, d_row_end, d_row_ptr, (size_t)(n + 1), MaxU64(), stream));
+    }
     IG_HIP(hipStreamSynchronize(stream));
-    mem.release(d_sel);
+    mem.release(d_other);
+    mem.release(d_row_end);
     lap("csr");
-    for (int s = 0; s < 64; s++) out->m_unique += h_counts[s];
     const bool to_host = !keep || m_eff <= kKeepHostGraph;
     if (to_host) {
         try {

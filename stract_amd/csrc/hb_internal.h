@@ -174,27 +174,40 @@ std::string build_tail_csr(std::vector<uint64_t> *keys, uint64_t n_pad, std::vec
 std::string gpu_ingest_edges(void *stream, const hb_u128 *node_ids, uint64_t n, const hb_edge *edges, uint64_t m,
                              DenseGraph *out, struct DeviceCsr *keep = nullptr, uint64_t *peak_bytes = nullptr);
 constexpr uint64_t kKeepHostGraph = 1ull << 26;
-// the two halves of gpu_ingest_edges, for streamed input (hb_append_edges): batches of records are unpacked on the
-// device as they arrive into chunks of 2 x 16-byte endpoint keys + 1 flag byte per record; one reduction at hb_finalize
+// the two halves of gpu_ingest_edges, for streamed input (hb_append_edges): every endpoint of a batch goes through a device
+// hash table (NodeID -> 32-bit provisional id) as the batch arrives, a record is kept as (from pid, to pid) + 1 flag byte
+// = 9 bytes, in chunks; one reduction at hb_finalize
 struct IngestChunk {
-    void *d_end = nullptr;   // 2 * cap endpoint keys (from, to), stream order
-    uint8_t *d_bad = nullptr; // cap "rel_flags & SKIPPED_REL" bytes
+    uint64_t *d_pair = nullptr; // cap x (from pid | to pid << 32), stream order
+    uint8_t *d_bad = nullptr;   // cap "rel_flags & SKIPPED_REL" bytes
     uint64_t count = 0, cap = 0;
 };
 struct IngestStream {
     std::vector<IngestChunk> chunks;
     uint64_t count = 0;         // records held
-    uint64_t bytes = 0;         // device bytes of the chunks
+    uint64_t bytes = 0;         // device bytes of the chunks + the endpoint table
+    uint64_t peak_bytes = 0;    // their high-water mark
     void *d_slab[2] = {nullptr, nullptr}; // H2D staging
     uint64_t slab_cap = 0;
+    void *kstream = nullptr;    // hipStream_t of the table kernels (the copies run on the caller's stream)
+    // endpoint table (hb_ingest.hip): open addressing, tab_slots (power of two) x { 16-byte key, 4-byte pid / state }
+    void *d_tab_keys = nullptr;
+    uint32_t *d_tab_pids = nullptr;
+    uint64_t tab_slots = 0;
+    void *d_counter = nullptr;               // pids handed out (device)
+    unsigned long long *h_counter = nullptr; // pinned read-back word
+    uint64_t npid_known = 0;                 // ... at the last read-back
+    uint64_t unsynced = 0;                   // records launched since then (each can add two keys)
     // limits (0 = none / default); the test hooks of hb_debug_set_ingest_limits lower them to reach the refusal and
     // spill paths at small sizes
-    uint64_t max_records = 0;   // refuse to hold more records than this ("too many records")
-    uint64_t max_bytes = 0;     // treat chunk memory beyond this as a failed allocation ("out of memory")
-    uint64_t chunk_records = 0; // records per chunk (default 2^26)
+    uint64_t max_records = 0;   // refuse to hold this many records or more ("too many records")
+    uint64_t max_bytes = 0;     // treat chunk / table memory beyond this as a failed allocation ("out of memory")
+    uint64_t chunk_records = 0; // records per chunk (default 2^27)
     void free_all();
 };
 std::string gpu_ingest_append(void *stream, IngestStream *st, const hb_edge *edges, uint64_t m);
+// the records held on the device back as hb_edge records (appended to *out; rel_flags collapses to skipped-or-not); consumes *st
+std::string gpu_ingest_spill(void *stream, IngestStream *st, std::vector<hb_edge> *out);
 // consumes *st (freed on every path); *peak_bytes = high-water mark of the device memory the ingest held
 std::string gpu_ingest_reduce(void *stream, const hb_u128 *node_ids, uint64_t n, IngestStream *st, DenseGraph *out, struct DeviceCsr *keep,
                               uint64_t *peak_bytes = nullptr);

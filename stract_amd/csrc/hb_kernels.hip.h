@@ -29,6 +29,21 @@ namespace hbk {
 constexpr uint32_t kNone = 0xFFFFFFFFu;
 constexpr int kTableLen = 159;
 
+// -DHB_DEBUG_BOUNDS (`make bounds` in this directory): device-side checks of every index the pass kernels gather through -
+// source ids against the number of work rows, LDS list / strip positions against their capacity.  A failed check records
+// its source line in a device word (first failure wins) and execution continues; the library reads the word at the end of
+// every C-ABI call and fails that call with the line (hb_api.hip: guarded()).  No printf, no trap: both change what the
+// kernel is (hostcall buffers, scratch) and a trapped queue loses the message.  The shipped build compiles them out.
+#ifdef HB_DEBUG_BOUNDS
+__device__ unsigned int g_dbg_line = 0;
+#define HB_DBG_ASSERT(cond)                                                  \
+    do {                                                                     \
+        if (!(cond)) atomicCAS(&hbk::g_dbg_line, 0u, (unsigned int)__LINE__); \
+    } while (0)
+#else
+#define HB_DBG_ASSERT(cond) ((void)0)
+#endif
+
 // Streams that are read or written exactly once per pass (row pointers, source indices, per-row Kahan / size
 // words, the freshly written counters): with HB_STREAM_NT they bypass-hint the caches (nontemporal), leaving the
 // L2 to the gathered counters.  Experiment switch, see profiles/r02*_stream_nt*.
@@ -108,6 +123,7 @@ struct PassParams {
     int xcd_map;
     uint64_t xcd_lo[8], xcd_hi[8];
     uint64_t n, n_pad;
+    uint64_t rows_total;         // n_pad + virtual rows: every source id is below it (checked at load: validate_plan_kernel)
     uint64_t slice_lo, slice_hi; // rows whose Kahan state this rank owns
     double t_plus_1;          // (t + 1) as f64, harmonic.rs:174
     // edge partition + HB_FLAG_CHANGED_ONLY: the unfused node-row launch records which rows its LOCAL merge changed
@@ -312,6 +328,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((REAL && UN
                         s1 = (s1 != kNone) ? s1 : first;
                         s2 = (s2 != kNone) ? s2 : first;
                         s3 = (s3 != kNone) ? s3 : first;
+                        HB_DBG_ASSERT(s0 < p.rows_total && s1 < p.rows_total && s2 < p.rows_total && s3 < p.rows_total);
+                        HB_DBG_ASSERT((s0 < p.n_pad) == real_src && (s1 < p.n_pad) == real_src && (s2 < p.n_pad) == real_src && (s3 < p.n_pad) == real_src);
                         r[u][0] = base[(uint64_t)s0 * 4 + q];
                         r[u][1] = base[(uint64_t)s1 * 4 + q];
                         r[u][2] = base[(uint64_t)s2 * 4 + q];
@@ -534,7 +552,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void f
             for (int b = 0; b < W / 4; b++) {
                 if (bal4[b]) {
 #pragma unroll
-                    for (int j = 4 * b; j < 4 * b + 4; j++) wb[j] = (idx[j] != kNone) ? p.bits_rd[idx[j] >> 5] : 0u;
+                    for (int j = 4 * b; j < 4 * b + 4; j++) {
+                        HB_DBG_ASSERT(idx[j] == kNone || (idx[j] < p.rows_total && (idx[j] < p.n_pad) == real_src));
+                        wb[j] = (idx[j] != kNone) ? p.bits_rd[idx[j] >> 5] : 0u;
+                    }
                 } else {
 #pragma unroll
                     for (int j = 4 * b; j < 4 * b + 4; j++) wb[j] = 0u;
@@ -573,7 +594,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void f
                 uint32_t pos = incl - mine;
 #pragma unroll
                 for (int j = 0; j < W; j++) {
-                    if (idx[j] != kNone) strip[pos++] = idx[j];
+                    if (idx[j] != kNone) {
+                        HB_DBG_ASSERT(pos < (uint32_t)(4 * W));
+                        strip[pos++] = idx[j];
+                    }
                 }
                 // same wave writes and reads the strip: LDS operations of one wave complete in order
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");

@@ -14,6 +14,7 @@
 //   upper levels      per hub row: scans give the new row ids / list offsets, a wave copies the id lists
 //   assembly          scans of the row lengths, quad-per-row copies
 // The result must equal the host planner's output entry for entry (tests/test_gpu.py::test_device_plan_equals_host_plan).
+#include "hb_guard_alloc.h" // FIRST: no-op unless built with -DHB_GUARD_ALLOC=<mode> (debug allocators: guard pages / poison / red zones)
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -24,12 +25,23 @@
 #include <rocprim/rocprim.hpp>
 
 #include "hb_internal.h"
-#include "hb_guard_alloc.h" // no-op unless built with -DHB_GUARD_ALLOC (debug: unmapped guard range behind every buffer)
 
 namespace {
 
 using hb::kNone;
 using hb::kRowAlign;
+
+// -DHB_DEBUG_BOUNDS (`make bounds`): index checks inside planner kernels; the first failing source line is kept in a device
+// word and reported by gpu_build_plan (no printf, no trap - see hb_kernels.hip.h)
+#ifdef HB_DEBUG_BOUNDS
+__device__ unsigned int g_plan_dbg_line = 0;
+#define PL_DBG_ASSERT(cond)                                              \
+    do {                                                                 \
+        if (!(cond)) atomicCAS(&g_plan_dbg_line, 0u, (unsigned int)__LINE__); \
+    } while (0)
+#else
+#define PL_DBG_ASSERT(cond) ((void)0)
+#endif
 
 #define PL_HIP(call)                                                                 \
     do {                                                                             \
@@ -62,6 +74,12 @@ struct DevMem {
     }
     hipError_t init(size_t bytes)
     {
+#ifdef HB_GUARD_ALLOC
+        // debug allocators (hb_guard_alloc.h): no slab - every temporary is its own allocation, so that an overrun of
+        // one planner buffer into the next is seen by the guard page / red zone behind it
+        (void)bytes;
+        return hipSuccess;
+#endif
         bytes = (bytes + 4095) & ~(size_t)4095;
         hipError_t e = hipMalloc((void **)&slab, bytes);
         if (e != hipSuccess) { // no slab: every alloc() falls back to hipMalloc
@@ -76,7 +94,11 @@ struct DevMem {
     template <typename T>
     hipError_t alloc(T **out, size_t count)
     {
+#ifdef HB_GUARD_ALLOC
+        const size_t need = std::max<size_t>(count * sizeof(T), 16); // exact size: the guard sits right behind the last element
+#else
         const size_t need = (std::max<size_t>(count * sizeof(T), 256) + 255) & ~(size_t)255;
+#endif
         for (size_t i = 0; i < blocks.size(); i++) {
             if (!blocks[i].free || blocks[i].size < need) continue;
             if (blocks[i].size > need) {
@@ -385,7 +407,8 @@ __global__ __launch_bounds__(256) void level1_rows_kernel(const uint32_t *forder
 }
 // quad per level-1 row: its sources = the chunk's hotness ranks mapped back to device positions
 __global__ __launch_bounds__(256) void level1_fill_kernel(const uint32_t *row_chunk, uint64_t rows, const uint64_t *vrow_ptr, const uint64_t *cbeg,
-                                                          const uint32_t *clen, const uint32_t *rs, uint64_t slice, uint64_t world, uint32_t *vsrc)
+                                                          const uint32_t *clen, const uint32_t *rs, uint64_t slice, uint64_t world, uint32_t *vsrc,
+                                                          uint64_t m, uint64_t C, uint64_t vsrc_cap)
 {
     const uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     const uint64_t r = t >> 2;
@@ -393,8 +416,14 @@ __global__ __launch_bounds__(256) void level1_fill_kernel(const uint32_t *row_ch
     if (r >= rows) return;
     const uint32_t k = row_chunk[r];
     if (k == kNone) return;
+    PL_DBG_ASSERT(k < C);
     const uint64_t o = vrow_ptr[r], b = cbeg[k];
     const uint32_t len = clen[k];
+    PL_DBG_ASSERT(b + len <= m);
+    PL_DBG_ASSERT(o + len <= vsrc_cap);
+    (void)m;
+    (void)C;
+    (void)vsrc_cap;
     for (uint32_t i = q; i < len; i += 4) {
         const uint64_t hr = rs[b + i];
         vsrc[o + i] = (uint32_t)(world == 1 ? hr : (hr % world) * slice + hr / world);
@@ -946,7 +975,8 @@ std::string gpu_build_plan(void *stream_v, uint64_t n, const uint64_t *d_row_ptr
     PL_HIP(mem.alloc(&d_vsrc, vsrc_cap + 1));
     if (rows_l1) {
         hipLaunchKernelGGL(level1_fill_kernel, dim3(grid_for(rows_l1 * 4)), dim3(256), 0, stream, (const uint32_t *)d_row_chunk, rows_l1,
-                           (const uint64_t *)d_vrow_ptr, (const uint64_t *)d_cbeg, (const uint32_t *)d_clen, (const uint32_t *)d_rs, slice, world, d_vsrc);
+                           (const uint64_t *)d_vrow_ptr, (const uint64_t *)d_cbeg, (const uint32_t *)d_clen, (const uint32_t *)d_rs, slice, world, d_vsrc, m, C,
+                           vsrc_cap);
         PL_HIP(hipGetLastError());
         PL_HIP(hipStreamSynchronize(stream));
     }
@@ -1069,6 +1099,14 @@ std::string gpu_build_plan(void *stream_v, uint64_t n, const uint64_t *d_row_ptr
     out->d_order = (uint32_t *)mem.disown(d_order);
     out->d_dev_of = (uint32_t *)mem.disown(d_dev_of);
     out->d_outdeg_dev = (uint32_t *)mem.disown(d_outdeg_dev);
+#ifdef HB_DEBUG_BOUNDS
+    {
+        unsigned int line = 0;
+        (void)hipDeviceSynchronize();
+        if (hipMemcpyFromSymbol(&line, HIP_SYMBOL(g_plan_dbg_line), sizeof(line)) == hipSuccess && line)
+            return "HB_DEBUG_BOUNDS: planner index check failed at hb_plan.hip line " + std::to_string(line);
+    }
+#endif
     return "";
 }
 

@@ -31,8 +31,10 @@ struct SweepParams {
     unsigned int *counts_next; // the other slot (zeroed by this pass' first kernel for the next sweep pass)
 };
 
-__device__ __forceinline__ void touch_set(uint32_t *touch, uint32_t r)
+__device__ __forceinline__ void touch_set(uint32_t *touch, uint32_t r, uint64_t rows_total)
 {
+    HB_DBG_ASSERT(r < rows_total);
+    (void)rows_total;
     const uint32_t bit = 1u << (r & 31u);
     // pre-test at the L2 (device-coherent load: a row usually has several changed sources, only the first
     // needs the atomic; a stale 0 would only cost a redundant one - bits are never cleared while being set)
@@ -67,6 +69,7 @@ __global__ __launch_bounds__(256) void sweep_collect_kernel(const SweepParams sp
         while (ch) {
             const int b = __ffs((int)ch) - 1;
             ch &= ch - 1;
+            HB_DBG_ASSERT(base < sp.p.n_pad);
             sp.seeds[base++] = (uint32_t)(w << 5) + (uint32_t)b;
         }
     }
@@ -87,6 +90,7 @@ __global__ __launch_bounds__(256) void sweep_expand_kernel(const SweepParams sp)
         uint32_t u = 0;
         if (i < nseeds) {
             u = sp.seeds[i];
+            HB_DBG_ASSERT(u < sp.p.n_pad);
             b = sp.out_ptr[u];
             e = sp.out_ptr[u + 1];
         }
@@ -126,7 +130,7 @@ __global__ __launch_bounds__(256) void sweep_expand_kernel(const SweepParams sp)
             }
             const uint32_t oex = __shfl(excl, lo);
             const uint64_t ob = ((uint64_t)__shfl(bhi, lo) << 32) | __shfl(blo, lo);
-            if (item < total) touch_set(sp.touch, sp.out_rows[ob + (item - oex)]);
+            if (item < total) touch_set(sp.touch, sp.out_rows[ob + (item - oex)], sp.p.rows_total);
         }
     }
 }
@@ -155,7 +159,7 @@ __global__ __launch_bounds__(256) void sweep_seed_small_kernel(const SweepParams
             const uint64_t kb = sp.out_ptr[u], ke = sp.out_ptr[u + 1];
             if (ke - kb > 64) lng |= 1u << b;
             else
-                for (uint64_t k = kb; k < ke; k++) touch_set(sp.touch, sp.out_rows[k]);
+                for (uint64_t k = kb; k < ke; k++) touch_set(sp.touch, sp.out_rows[k], sp.p.rows_total);
         }
         uint64_t owners;
         while ((owners = __ballot(lng != 0)) != 0) {
@@ -165,7 +169,7 @@ __global__ __launch_bounds__(256) void sweep_seed_small_kernel(const SweepParams
             if (lane == src) lng &= lng - 1;
             const uint64_t u = ((w0 + (uint64_t)(threadIdx.x & ~63) + (uint64_t)src) << 5) + (uint64_t)b;
             const uint64_t kb = sp.out_ptr[u], ke = sp.out_ptr[u + 1];
-            for (uint64_t k = kb + lane; k < ke; k += 64) touch_set(sp.touch, sp.out_rows[k]);
+            for (uint64_t k = kb + lane; k < ke; k += 64) touch_set(sp.touch, sp.out_rows[k], sp.p.rows_total);
         }
     }
 }
@@ -180,7 +184,7 @@ __global__ __launch_bounds__(256) void sweep_expand_heavy_kernel(const SweepPara
         const uint64_t b = sp.out_ptr[u], e = sp.out_ptr[u + 1];
         for (uint64_t k0 = b + wbase; k0 < e; k0 += nthreads) { // wave-uniform trip count
             const uint64_t k = k0 + lane;
-            if (k < e) touch_set(sp.touch, sp.out_rows[k]);
+            if (k < e) touch_set(sp.touch, sp.out_rows[k], sp.p.rows_total);
         }
     }
 }
@@ -266,6 +270,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void s
             while (word) {
                 const int b = __ffs((int)word) - 1;
                 word &= word - 1;
+                HB_DBG_ASSERT(pos < 2048u);
                 list[pos++] = (uint16_t)((lane << 5) | b);
             }
         }
@@ -318,7 +323,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void s
                     }
                     uint32_t wb[kU];
 #pragma unroll
-                    for (int u = 0; u < kU; u++) wb[u] = (idx[u] != kNone) ? p.bits_rd[idx[u] >> 5] : 0u;
+                    for (int u = 0; u < kU; u++) {
+                        HB_DBG_ASSERT(idx[u] == kNone || idx[u] < p.rows_total);
+                        wb[u] = (idx[u] != kNone) ? p.bits_rd[idx[u] >> 5] : 0u;
+                    }
 #pragma unroll
                     for (int u = 0; u < kU; u++) {
                         if (!((wb[u] >> (idx[u] & 31u)) & 1u)) idx[u] = kNone;
@@ -373,7 +381,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void s
             } else if (changed) {
                 p.part[(row - p.n_pad) * 4 + q] = accv;
                 if (q == 0) { // the readers (normally exactly one parent) must look at this partial
-                    for (uint64_t k = sp.out_ptr[row]; k < sp.out_ptr[row + 1]; k++) touch_set(sp.touch, sp.out_rows[k]);
+                    for (uint64_t k = sp.out_ptr[row]; k < sp.out_ptr[row + 1]; k++) touch_set(sp.touch, sp.out_rows[k], sp.p.rows_total);
                 }
             }
         }

@@ -140,3 +140,76 @@ def test_bincode_integer_classes():
     for v, n in ((0, 1), (250, 1), (251, 3), (65535, 3), (65536, 5), ((1 << 32) - 1, 5), (1 << 32, 9), ((1 << 64) - 1, 9), (1 << 64, 17)):
         enc = kv.varint_encode(v)
         assert len(enc) == n and kv.varint_decode(enc) == (v, n)
+
+
+def _segment_files(folder):
+    (uuid,) = json.load(open(os.path.join(folder, "meta.json")))["segments"]
+    return {ext: open(os.path.join(folder, uuid + ext), "rb").read() for ext in (".ids", ".blm", ".bid", ".blobs")}
+
+
+@pytest.mark.parametrize("kind", ["hashes", "mixed_lengths", "consecutive", "two_groups"])
+def test_parallel_fst_equals_one_builder(tmp_path, kind):
+    """The .ids file is built as independent sub-tries (one per 3-byte key prefix, in parallel) hung below a sequentially
+    written top; fst stores node addresses as distances, so the bytes must equal what ONE builder fed with all keys in order
+    writes (HB_STORE_FST=sequential).  Every file of the segment is compared byte for byte."""
+    rng = np.random.default_rng(len(kind))
+    if kind == "hashes":        # 120 k random 128-bit ids: ~55 k groups, 256-way top nodes
+        ints = [int.from_bytes(rng.bytes(16), "little") | (1 << 127) for _ in range(120_000)]
+    elif kind == "mixed_lengths":
+        ints = _ids(rng, 5_000)   # (the 1-byte class has only 251 values: the helper cannot draw more than that share)
+    elif kind == "consecutive":  # long shared prefixes inside one group, keys that are neighbours in every byte
+        base = (0xABCDEF << 100) | (7 << 64)
+        ints = [base + i for i in range(70_000)] + [base + (1 << 40) + 3 * i for i in range(5_000)]
+    else:                        # exactly two groups of one key each + short keys in front
+        ints = [0, 17, 300, 70_000, (1 << 127) + 5, (1 << 127) + (1 << 20)]
+    ints = list(dict.fromkeys(ints))
+    ids = kv.ints_to_ids(ints, _lib.U128)
+    ranks = rng.permutation(len(ints)).astype(np.uint64)
+    _lib.store_write(str(tmp_path / "par"), ids, ranks)
+    os.environ["HB_STORE_FST"] = "sequential"
+    try:
+        _lib.store_write(str(tmp_path / "seq"), ids, ranks)
+    finally:
+        del os.environ["HB_STORE_FST"]
+    a, b = _segment_files(str(tmp_path / "par")), _segment_files(str(tmp_path / "seq"))
+    for ext in a:
+        assert a[ext] == b[ext], (kind, ext, len(a[ext]), len(b[ext]))
+    db = kv.Db(str(tmp_path / "par"), "u64", str(tmp_path))
+    assert len(db) == len(ints)
+    for j in rng.integers(0, len(ints), 300).tolist():
+        assert db.get(ints[j]) == int(ranks[j])
+
+
+def test_store_harmonic_shares_the_key_files(tmp_path):
+    """both databases hold the same keys in the same order: .ids and .blm are built once and must be identical files"""
+    rng = np.random.default_rng(99)
+    ints = _ids(rng, 3000)
+    ids = kv.ints_to_ids(ints, _lib.U128)
+    _lib.store_harmonic(str(tmp_path), ids, rng.random(len(ints)), rng.permutation(len(ints)).astype(np.uint64))
+    a, b = _segment_files(str(tmp_path / "harmonic")), _segment_files(str(tmp_path / "harmonic_rank"))
+    assert a[".ids"] == b[".ids"] and a[".blm"] == b[".blm"] and a[".blobs"] != b[".blobs"]
+
+
+def test_store_never_reports_ok_without_a_meta(tmp_path):
+    """ADVICE r3: meta.json that cannot be written must fail the call (it used to return HB_OK and leave segment files behind);
+    an existing database with segments is refused instead of being orphaned"""
+    ids = kv.ints_to_ids([3, 1 << 90], _lib.U128)
+    vals = np.array([0.5, 0.25])
+    for count in (2, 0):
+        d = tmp_path / ("blocked%d" % count)
+        (d / "meta.json").mkdir(parents=True)       # a DIRECTORY where the file must go: rename() over it fails
+        with pytest.raises(_lib.HyperballError) as e:
+            _lib.store_write(str(d), ids[:count], vals[:count])
+        assert e.value.code == _lib.HB_ERR_IO and "meta.json" in str(e.value)
+        assert not os.path.exists(d / "meta.json.tmp")
+    good = tmp_path / "good"
+    _lib.store_write(str(good), ids, vals)
+    before = sorted(os.listdir(good))
+    with pytest.raises(_lib.HyperballError) as e:
+        _lib.store_write(str(good), ids, vals)
+    assert e.value.code == _lib.HB_ERR_INVALID and "already lists segments" in str(e.value)
+    assert sorted(os.listdir(good)) == before       # nothing added, nothing orphaned
+    empty = tmp_path / "was_empty"
+    _lib.store_write(str(empty), ids[:0], vals[:0])  # {"segments": []} may be filled later
+    _lib.store_write(str(empty), ids, vals)
+    assert kv.Db(str(empty), "f64", str(tmp_path)).get(3) == 0.5

@@ -38,29 +38,26 @@ def main():
     ap.add_argument("--verify", action="store_true")
     ap.add_argument("--store", default="")
     ap.add_argument("--out", default="")
+    ap.add_argument("--torch-first", action="store_true",
+                    help="import torch BEFORE the library is loaded: the library then runs on the HIP runtime bundled with torch "
+                         "(same soname) instead of /opt/rocm's - the situation of bench.py --gpus N > 1")
     a = ap.parse_args()
-    import torch
+    if a.torch_first:
+        import torch  # noqa: F401
 
     t0 = time.perf_counter()
     g, scale, label = synth.make_config(a.config)
     t_gen = time.perf_counter() - t0
     total = g.stream_len(a.salt)
     slab = min(a.slab, max(total, 1))
-    pinned = torch.empty(slab * _lib.EDGE.itemsize, dtype=torch.uint8, pin_memory=True)
-    buf = pinned.numpy().view(_lib.EDGE)
-    # what the link gives this process: pinned H2D of one slab
-    dev = torch.empty(pinned.numel(), dtype=torch.uint8, device="cuda")
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(3):
-        dev.copy_(pinned, non_blocking=True)
-    torch.cuda.synchronize()
-    h2d_gbs = 3 * pinned.numel() / (time.perf_counter() - t0) / 1e9
-    del dev
+    pinned = _lib.PinnedRecords(slab)  # hb_pinned_alloc: hipHostMalloc in the runtime the library runs on
+    buf = pinned.array
+    ctx = _lib.Context()
+    h2d_gbs = ctx.h2d_rate(buf)  # what the link gives this process: pinned H2D of one slab on the library's stream
+    hip_runtime = sorted(set(l.split()[-1] for l in open("/proc/self/maps") if "libamdhip64" in l))
     out = {"config": a.config, "label": label, "n": int(g.n), "m_clean": int(g.m), "salt": a.salt, "records": total,
            "record_GB": round(total * 40 / 1e9, 2), "slab_records": slab, "s_generate_graph": round(t_gen, 1),
-           "pinned_h2d_GBs": round(h2d_gbs, 1)}
-    ctx = _lib.Context()
+           "pinned_h2d_GBs": round(h2d_gbs, 1), "hip_runtime": hip_runtime}
     s_fill = s_append = 0.0
     at = 0
     t_all = time.perf_counter()
