@@ -82,6 +82,12 @@ def parse():
                          "the union of the locally changed rows)")
     ap.add_argument("--c4-leg", default="auto", choices=["auto", "on", "off"],
                     help="append a BASELINE configs[3] (100M-host / 2B-edge) leg under detail.c4 (auto: with the default config at N = 1)")
+    ap.add_argument("--end-to-end", default="auto", choices=["auto", "on", "off"],
+                    help="N = 1: also run the reference command's whole chain on the same graph (entrypoint/centrality.rs:41-71): on-disk edge "
+                         "store -> hb_load_webgraph -> hb_run -> results + ranks -> hb_store_harmonic, seconds per stage under "
+                         "detail.end_to_end (auto: with record input at N = 1 for C3 / C4 / LT)")
+    ap.add_argument("--e2e-dir", default="", help="where the end-to-end leg puts its edge store and output databases "
+                                                  "(default: $TMPDIR or /tmp if the store fits on that disk, else /dev/shm)")
     ap.add_argument("--no-supervisor", action="store_true", help="accepted and ignored (round 3 measured in a restartable child process)")
     ap.add_argument("--legs-timeout", type=int, default=300,
                     help="N > 1, --partition both: seconds the extra partition legs may take before the line is printed without them")
@@ -180,6 +186,94 @@ def load_records(ctx, g, salt=2, slab=1 << 24):
             "append_GBs": round(total * 40 / max(s_append, 1e-9) / 1e9, 2),
             "records_per_s": round(total / max(s_append + s_fin, 1e-9)),
             "ingest_peak_device_bytes": int(st["ingest_peak_bytes"]), "m_unique": int(st["m_unique"])}
+
+
+def end_to_end(a, g, ref_sig, ref_passes, salt=2, seg_records=1 << 24):
+    """The drop-in measured end to end: what `stract centrality harmonic <webgraph> <out>` does
+    (entrypoint/centrality.rs:41-71) as ONE chain of library calls on the same graph, seconds per stage:
+        open the webgraph's edge store + stream it   hb_load_webgraph (CRC-32 of every .col file checked; native column reader,
+                                                      pinned double buffer, GPU ingest, device planner)
+        HarmonicCentrality::calculate                 hb_run
+        the (NodeID, f64) list + harmonic_rank        hb_result_copy + hb_result_ranks
+        store_harmonic                                hb_store_harmonic (both speedy_kv databases)
+    Harness (not timed): the record stream is written as an edge store by tests/tantivy_fixture.py (a Python restatement of the
+    tantivy serialisers: format unpinned), segment by segment; a sample of keys is read back from the written databases with
+    tests/speedy_kv_reader.py."""
+    import ctypes
+    import shutil
+    import tempfile
+    from stract_amd import _lib, webgraph
+    from tests import speedy_kv_reader as kv
+    from tests import tantivy_fixture as tf
+
+    total = g.stream_len(salt)
+    store_bytes = total * 40
+    base = a.e2e_dir
+    if not base:
+        disk = os.environ.get("TMPDIR") or "/tmp"
+        try:
+            free = shutil.disk_usage(disk).free
+        except OSError:
+            free = 0
+        base = disk if free > store_bytes * 1.25 + 64 * (g.n + 1) else "/dev/shm"
+    work = tempfile.mkdtemp(prefix="hb_e2e_", dir=base)
+    out = {"medium": "tmpfs (/dev/shm: the store does not fit on the box's disk; read rates are memory rates)" if base.startswith("/dev/shm") else "disk (%s)" % base,
+           "records": int(total), "store_GB": round(store_bytes / 1e9, 2)}
+    try:
+        lib = _lib.load()
+
+        def segments():
+            for b in range(0, total, seg_records):
+                part = np.empty(min(seg_records, total - b), dtype=_lib.EDGE)
+                g.stream_fill(part, b, salt)
+                yield part
+
+        t0 = time.perf_counter()
+        edges_dir = os.path.join(work, "webgraph", "edges")
+        tf.write_edge_store_streamed(edges_dir, segments(), crc32=lambda buf: lib.hbw_debug_crc32(buf.ctypes.data_as(ctypes.c_void_p), buf.nbytes))
+        os.sync()  # the harness's writes are on the medium before the timed chain starts (no write-back competing with it)
+        out["s_harness_write_edge_store"] = round(time.perf_counter() - t0, 2)
+        out["segments"] = (total + seg_records - 1) // seg_records
+        with _lib.Context() as ctx:
+            t0 = time.perf_counter()
+            webgraph.load_webgraph(ctx, edges_dir, verify_crc=True)
+            t1 = time.perf_counter()
+            st = ctx.stats()
+            run = ctx.run()
+            t2 = time.perf_counter()
+            ids, vals = ctx.results()
+            ranks = ctx.ranks()
+            t3 = time.perf_counter()
+            _lib.store_harmonic(os.path.join(work, "centrality"), ids, vals, ranks)
+            t4 = time.perf_counter()
+        sig = (len(vals), int(vals.view(np.uint64).sum() & 0xFFFFFFFFFFFFFFFF)) if len(vals) else (0, 0)
+        stages = {"s_load_webgraph": t1 - t0, "s_run": t2 - t1, "s_results_and_ranks": t3 - t2, "s_store_harmonic": t4 - t3}
+        tot = t4 - t0
+        out.update({k: round(v, 3) for k, v in stages.items()})
+        out.update({"s_total": round(tot, 3), "compute_share": round(stages["s_run"] / tot, 4),
+                    "load_records_per_s": round(total / stages["s_load_webgraph"]), "load_GBs": round(store_bytes / stages["s_load_webgraph"] / 1e9, 2),
+                    "results": int(len(vals)), "store_entries_per_s_per_db": round(len(vals) / max(stages["s_store_harmonic"], 1e-9)),
+                    "store_entries_per_s_both_dbs": round(2 * len(vals) / max(stages["s_store_harmonic"], 1e-9)),
+                    "ms_ingest_reduce": round(st["ms_ingest"], 1), "ms_plan": round(st["ms_plan"], 1), "ms_state": round(st["ms_h2d"], 1),
+                    "ingest_peak_bytes_per_record": round(st["ingest_peak_bytes"] / max(total, 1), 2),
+                    "graph_ok": bool(st["n"] == g.n and st["m_eff"] == g.m and st["m_input"] == total),
+                    "passes": int(run["passes"]), "same_result_as_record_leg": bool(sig == tuple(ref_sig) and int(run["passes"]) == int(ref_passes))})
+        # read a sample back from both databases (harness)
+        ok = True
+        if len(vals):
+            rng = np.random.default_rng(11)
+            pick = rng.integers(0, len(vals), 64)
+            ints = kv.ids_to_ints(ids[pick])
+            db_c = kv.Db(os.path.join(work, "centrality", "harmonic"), "f64", tempfile.gettempdir())  # (the reader builds a small shim .so: not on a noexec tmpfs)
+            db_r = kv.Db(os.path.join(work, "centrality", "harmonic_rank"), "u64", tempfile.gettempdir())
+            ok = len(db_c) == len(vals) and len(db_r) == len(vals)
+            for j, key in zip(pick.tolist(), ints):
+                ok = ok and db_c.get(key) == float(vals[j]) and db_r.get(key) == int(ranks[j])
+        out["stores_read_back_ok"] = bool(ok)
+        out["stores_bytes"] = int(sum(os.path.getsize(os.path.join(d, f)) for d, _, fs in os.walk(os.path.join(work, "centrality")) for f in fs))
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
+    return out
 
 
 def per_pass_avg(all_pass_stats, n, m_eff, rows_in, work_rows, init_streamed):
@@ -455,6 +549,15 @@ def main():
         if dog.is_alive() and any("error" in v for v in legs.values() if isinstance(v, dict)):
             dog.join()  # a leg failed here: wait for the watchdog (it prints on rank 0 and ends the process)
 
+    # ---- the whole reference command on the same graph: store -> load -> run -> ranks -> store_harmonic
+    want_e2e = world == 1 and (a.end_to_end == "on" or (a.end_to_end == "auto" and a.input == "records" and a.config in ("C3", "C4", "LT")
+                                                          and not a.flags and not a.tune and not a.chunk))
+    if want_e2e:
+        out["detail"]["end_to_end"] = end_to_end(a, g, ref_sig, passes)
+        e2e = out["detail"]["end_to_end"]
+        if not (e2e["graph_ok"] and e2e["same_result_as_record_leg"] and e2e["stores_read_back_ok"]):
+            exit_code = 4  # the chain produced something else than the record leg: loud
+
     # ---- the north-star graph as an extra leg (BASELINE configs[3], 1 GPU): driver-visible C4 numbers + parity
     want_c4 = a.c4_leg == "on" or (a.c4_leg == "auto" and world == 1 and a.config == "C3" and not a.flags and not a.tune and not a.chunk)
     if want_c4 and world == 1:
@@ -493,7 +596,8 @@ def c4_leg(a):
     Runs as a CHILD process (this script with --config C4): generating the 2 B-edge graph takes tens of GB of host memory, and a
     child that is killed for it must not take the main line down with it."""
     cmd = [sys.executable, os.path.abspath(__file__), "--config", "C4", "--steps", "2", "--warmup", "1", "--c4-leg", "off",
-           "--cpu-seconds", str(a.cpu_seconds), "--input", a.input] + (["--verify"] if a.verify else [])
+           "--cpu-seconds", str(a.cpu_seconds), "--input", a.input, "--end-to-end", a.end_to_end] + (["--verify"] if a.verify else []) + (
+               ["--e2e-dir", a.e2e_dir] if a.e2e_dir else [])
     env = dict(os.environ, HB_BENCH_CHILD="1")  # measured in the child itself, not under another supervisor
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
         env.pop(k, None)
@@ -508,7 +612,7 @@ def c4_leg(a):
     return {"workload": d["config"]["workload"], "n_hosts": d["config"]["n_hosts"], "m_eff": d["config"]["m_eff"], "passes_T": d["config"]["passes_T"],
             "value": d["value"], "unit": d["unit"], "steps": d["steps"], "warmup": d["warmup"], "ms_per_step": d["ms_per_step"],
             "parity_bit_exact": d["parity_bit_exact"], "parity": d["parity"], "roofline": {k: roof[k] for k in keep if k in roof},
-            "cpu_baseline": d["cpu_baseline"], "input": det.get("input"), "s_generate": det.get("s_generate"),
+            "cpu_baseline": d["cpu_baseline"], "input": det.get("input"), "end_to_end": det.get("end_to_end"), "s_generate": det.get("s_generate"),
             "device_bytes": det.get("device_bytes"), "results": det.get("results")}
 
 

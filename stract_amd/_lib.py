@@ -7,7 +7,14 @@ fallback: if the library is missing, or no gfx950 device is present, calls raise
 import ctypes
 import os
 
-import numpy as np
+# OpenMP worker threads of the host-side pieces (store writer, column reader, the synthetic-graph and oracle support
+# libraries) must SLEEP when a parallel region ends, not spin: a box that shows 256 hardware threads under a 16-CPU
+# container quota otherwise has hundreds of spinning workers competing with the one thread that drives the GPU - measured:
+# ~100 ms lost in the first HIP wait after every parallel region (profiles/r04d_ingest_append_trace.txt).  libgomp reads the
+# variable when it is loaded, i.e. before the libraries below are.
+os.environ.setdefault("OMP_WAIT_POLICY", "passive")
+
+import numpy as np  # noqa: E402
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("HB_LIB_PATH") or os.path.join(_HERE, "lib", "libhyperball.so")  # HB_LIB_PATH: experiment builds

@@ -24,6 +24,7 @@
 #ifdef HB_GUARD_ALLOC
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstdio>
 #include <cstdlib>
 #include <map>
@@ -265,7 +266,16 @@ inline hipError_t gmalloc(void **out, size_t bytes)
     size_t gran = 0;
     hipError_t e = hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityMinimum);
     if (e != hipSuccess || !gran) return e != hipSuccess ? e : hipErrorUnknown;
-    const size_t align = HB_GUARD_ALIGN;
+    // Bisection aid: allocations are numbered in call order; HB_GUARD_STRICT_FROM / HB_GUARD_STRICT_TO (default: all) select
+    // the half-open range that gets the strict treatment (guard right behind the 16-byte aligned end, pattern fill); the
+    // others are "loose" like hipMalloc memory: end rounded up to 256 bytes, zero filled.  HB_GUARD_TRACE lists them.
+    static std::atomic<long> seq_counter{0};
+    static const long strict_from = std::getenv("HB_GUARD_STRICT_FROM") ? std::atol(std::getenv("HB_GUARD_STRICT_FROM")) : 0;
+    static const long strict_to = std::getenv("HB_GUARD_STRICT_TO") ? std::atol(std::getenv("HB_GUARD_STRICT_TO")) : (1L << 62);
+    const long seq = seq_counter.fetch_add(1);
+    const bool strict = seq >= strict_from && seq < strict_to;
+    if (std::getenv("HB_GUARD_TRACE")) std::fprintf(stderr, "[hbguard] alloc #%ld: %zu bytes (%s)\n", seq, bytes, strict ? "strict" : "loose");
+    const size_t align = strict ? (size_t)HB_GUARD_ALIGN : (size_t)256;
     size_t need = (bytes + align - 1) / align * align;
     if (!need) need = align;
     const size_t mapped = (need + gran - 1) / gran * gran, reserved = mapped + gran;
@@ -288,6 +298,16 @@ inline hipError_t gmalloc(void **out, size_t bytes)
     {
         std::lock_guard<std::mutex> g(mu());
         recs()[p] = Rec{va, reserved, mapped, bytes, h};
+    }
+    {
+        // fresh memory carries a pattern (default 0xA5; HB_GUARD_FILL=<hex byte>, e.g. 00): a result that depends on what a
+        // new allocation happens to hold becomes reproducible instead of allocator-dependent
+        static const int fill = [] {
+            const char *e = std::getenv("HB_GUARD_FILL");
+            return e ? (int)std::strtol(e, nullptr, 16) & 0xFF : 0xA5;
+        }();
+        (void)fill_kernel(va, strict ? fill : 0, mapped, nullptr);
+        (void)hipDeviceSynchronize();
     }
     *out = p;
     return hipSuccess;

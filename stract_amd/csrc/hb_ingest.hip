@@ -376,7 +376,7 @@ std::string table_reserve(hipStream_t stream, IngestStream *st, uint64_t incomin
 {
     if (!st->d_counter) {
         IG_HIP(hipMalloc((void **)&st->d_counter, 256));
-        IG_HIP(hipHostMalloc((void **)&st->h_counter, sizeof(unsigned long long)));
+        IG_HIP(hipHostMalloc((void **)&st->h_counter, 4 * sizeof(unsigned long long))); // [0] blocking read-back, [1 + b] snapshot behind slab buffer b
         IG_HIP(hipMemsetAsync(st->d_counter, 0, 256, stream));
     }
     auto fits = [&](uint64_t slots) { return slots && (st->npid_known + 2 * st->unsynced + 2 * incoming) * 2 <= slots; };
@@ -388,7 +388,7 @@ std::string table_reserve(hipStream_t stream, IngestStream *st, uint64_t incomin
     }
     if (st->npid_known + 2 * incoming >= kMaxPids) return "too many nodes for the device ingest (2^31 endpoint ids)";
     uint64_t slots = 1ull << 12;
-    while (slots < 4 * (st->npid_known + 2 * incoming)) slots <<= 1; // load factor <= 1/4 right after growing
+    while (slots < 4 * (st->npid_known + 2 * st->unsynced + 2 * incoming)) slots <<= 1; // load factor <= 1/4 even if every record in flight brings two new ids
     const uint64_t add = slots * 20;
     if (st->max_bytes && st->bytes + add > st->max_bytes) return "hipMalloc(endpoint table): out of memory";
     void *nk = nullptr;
@@ -436,7 +436,9 @@ std::string gpu_ingest_append(void *stream_v, IngestStream *st, const hb_edge *e
     hipStream_t stream = (hipStream_t)stream_v;
     if (!m) return "";
     if (st->max_records && st->count + m >= st->max_records) return "too many records for the device ingest: use HB_FLAG_HOST_INGEST";
-    const uint64_t slab = 1ull << 22; // 4 Mi records = 160 MiB per slab, two slabs in flight
+    // 1 Mi records = 40 MiB per slab, two slabs in flight: large enough for the link's full rate (55 GB/s from 16 MiB up,
+    // profiles/r04a_h2d_probe.txt), small enough that "every record in flight may bring two new ids" stays a small reserve
+    const uint64_t slab = 1ull << 20;
     for (int k = 0; k < 2; k++)
         if (!st->d_slab[k]) {
             st->slab_cap = std::max(st->slab_cap, std::min<uint64_t>(slab, m));
@@ -477,6 +479,22 @@ std::string gpu_ingest_append(void *stream_v, IngestStream *st, const hb_edge *e
         IG_HIP(hipEventCreateWithFlags(&evs.consumed[k], hipEventDisableTiming));
     }
     IG_HIP(hipStreamSynchronize(stream)); // whatever the caller's stream still does must not race the kernels of the other one
+    // Key-count snapshots without blocking: behind every table kernel the counter is copied to a pinned word; once that
+    // slab's `consumed` event has fired the word is exact for the moment after that slab, and only the records launched
+    // since then are unknown (table_reserve's upper bound) - a synchronisation per slab would serialise copy and kernel.
+    uint64_t launched = 0, snap_launched[2] = {0, 0};
+    bool snap_pending[2] = {false, false};
+    auto poll_snapshots = [&]() {
+        for (int k = 0; k < 2; k++)
+            if (snap_pending[k] && hipEventQuery(evs.consumed[k]) == hipSuccess) {
+                snap_pending[k] = false;
+                const uint64_t v = st->h_counter[1 + k];
+                if (v >= st->npid_known && launched - snap_launched[k] <= st->unsynced) {
+                    st->npid_known = v;
+                    st->unsynced = launched - snap_launched[k];
+                }
+            }
+    };
     // state to restore if the device runs out of memory in the middle of this batch
     const size_t chunks_before = st->chunks.size();
     const uint64_t last_count_before = chunks_before ? st->chunks.back().count : 0, count_before = st->count;
@@ -494,8 +512,13 @@ std::string gpu_ingest_append(void *stream_v, IngestStream *st, const hb_edge *e
         (void)hipGetLastError();
     };
     const uint64_t chunk_records = st->chunk_records ? st->chunk_records : (1ull << 27);
+    // HB_TRACE_INGEST=1: where the host time of this call goes
+    const bool trace = std::getenv("HB_TRACE_INGEST") != nullptr;
+    const double t_call = now_ms();
+    double ms_alloc = 0, ms_reserve = 0, ms_issue = 0;
     int b = 0;
     for (uint64_t off = 0; off < m; b ^= 1) {
+        const double t_a = now_ms();
         if (st->chunks.empty() || st->chunks.back().count == st->chunks.back().cap) {
             IngestChunk c;
             uint64_t cap = 1ull << 20;
@@ -517,6 +540,8 @@ std::string gpu_ingest_append(void *stream_v, IngestStream *st, const hb_edge *e
         }
         IngestChunk &c = st->chunks.back();
         const uint64_t cnt = std::min(std::min(slab, m - off), c.cap - c.count);
+        const double t_b = now_ms();
+        poll_snapshots();
         {
             const std::string e = table_reserve(kstream, st, cnt); // (all table work lives on the ingest's stream)
             if (!e.empty()) {
@@ -524,6 +549,7 @@ std::string gpu_ingest_append(void *stream_v, IngestStream *st, const hb_edge *e
                 return e;
             }
         }
+        const double t_c = now_ms();
         IG_HIP(hipStreamWaitEvent(stream, evs.consumed[b], 0)); // the kernel that last read this slab buffer has finished
         IG_HIP(hipMemcpyAsync(st->d_slab[b], edges + off, cnt * sizeof(hb_edge), hipMemcpyHostToDevice, stream));
         IG_HIP(hipEventRecord(evs.copied[b], stream));
@@ -531,14 +557,27 @@ std::string gpu_ingest_append(void *stream_v, IngestStream *st, const hb_edge *e
         hipLaunchKernelGGL(insert_kernel, dim3(grid_for(cnt)), dim3(256), 0, kstream, (const hb_edge *)st->d_slab[b], cnt, c.count, table_of(st), c.d_pair,
                            c.d_bad);
         IG_HIP(hipGetLastError());
+        IG_HIP(hipMemcpyAsync(&st->h_counter[1 + b], st->d_counter, sizeof(unsigned long long), hipMemcpyDeviceToHost, kstream));
         IG_HIP(hipEventRecord(evs.consumed[b], kstream));
+        launched += cnt;
+        snap_launched[b] = launched;
+        snap_pending[b] = true;
         st->unsynced += cnt;
         c.count += cnt;
         st->count += cnt;
         off += cnt;
+        ms_alloc += t_b - t_a;
+        ms_reserve += t_c - t_b;
+        ms_issue += now_ms() - t_c;
     }
+    const double t_s = now_ms();
     IG_HIP(hipStreamSynchronize(stream));
     IG_HIP(hipStreamSynchronize(kstream));
+    poll_snapshots(); // everything has completed: the newest snapshot is exact and nothing is unknown any more
+    if (trace)
+        std::fprintf(stderr, "[hb ingest] append of %llu records: %.1f ms (chunk allocation %.1f, table reserve %.1f, issue %.1f, final wait %.1f); "
+                             "%llu ids in %llu slots\n", (unsigned long long)m, now_ms() - t_call, ms_alloc, ms_reserve, ms_issue, now_ms() - t_s,
+                     (unsigned long long)st->npid_known, (unsigned long long)st->tab_slots);
     return "";
 }
 

@@ -36,6 +36,7 @@
 #include <unistd.h>
 
 #include "../../include/hb_store.h"
+#include "hb_threads.h"
 
 #define XXH_INLINE_ALL
 #include "../../third_party/xxhash/xxhash.h"
@@ -572,7 +573,7 @@ bool fst_parallel(const std::vector<Entry> &e, const std::string &path, std::str
         groups.push_back(Group{i, j, {}, 0, true});
         i = j;
     }
-#pragma omp parallel for schedule(dynamic, 1)
+#pragma omp parallel for num_threads(hb::host_threads()) schedule(dynamic, 1)
     for (size_t g = 0; g < groups.size(); g++) {
         Group &G = groups[g];
         MemSink mem;
@@ -662,9 +663,10 @@ void parallel_sort(std::vector<Entry> &e)
         return;
     }
     uint64_t diff = 0;
-#pragma omp parallel for schedule(static) reduction(| : diff)
+#pragma omp parallel for num_threads(hb::host_threads()) schedule(static) reduction(| : diff)
     for (size_t i = 0; i < n; i++) diff |= e[i].k0 ^ e[0].k0;
     if (!diff) { // all keys share their first 8 bytes: nothing to split on here
+        omp_set_num_threads(hb::host_threads());
         __gnu_parallel::sort(e.begin(), e.end());
         return;
     }
@@ -672,7 +674,7 @@ void parallel_sort(std::vector<Entry> &e)
     const int shift = top >= 15 ? top - 15 : 0;      // bucket = 16 bits from there down
     const uint64_t mask = top >= 15 ? 0xFFFFull : ((1ull << (top + 1)) - 1);
     const size_t nb = (size_t)mask + 1;
-    const int nt = omp_get_max_threads();
+    const int nt = hb::host_threads();
     std::vector<std::vector<size_t>> hist((size_t)nt, std::vector<size_t>(nb, 0));
     std::vector<Entry> tmp(n);
     std::vector<size_t> start(nb + 1, 0);
@@ -712,7 +714,7 @@ int sort_entries(const hb_u128 *ids, uint64_t count, std::vector<Entry> *out, ch
     if (count >= (1ull << 56)) return fail(err, err_len, HB_ERR_INVALID, "hb_store_write: too many entries");
     std::vector<Entry> &e = *out;
     e.resize(count);
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for num_threads(hb::host_threads()) schedule(static)
     for (uint64_t i = 0; i < count; i++) {
         uint8_t key[17] = {0};
         (void)varint_u128(((unsigned __int128)ids[i].hi << 64) | ids[i].lo, key);
@@ -724,7 +726,7 @@ int sort_entries(const hb_u128 *ids, uint64_t count, std::vector<Entry> *out, ch
     // keys in ascending byte order of their encodings (LiveSegment is a BTreeMap<Vec<u8>, _>, lib.rs:108-110)
     parallel_sort(e);
     bool dup = false;
-#pragma omp parallel for schedule(static) reduction(|| : dup)
+#pragma omp parallel for num_threads(hb::host_threads()) schedule(static) reduction(|| : dup)
     for (uint64_t i = 1; i < count; i++) dup = dup || e[i].same_key(e[i - 1]);
     if (dup) return fail(err, err_len, HB_ERR_INVALID, "hb_store_write: duplicate NodeID");
     return HB_OK;
@@ -745,7 +747,7 @@ bool write_blobs(const std::vector<Entry> &e, const void *values, int value_kind
         }
         return (uint64_t)x.key_len() + v;
     };
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for num_threads(hb::host_threads()) schedule(static)
     for (uint64_t b = 0; b < nblocks; b++) {
         uint64_t s = 0;
         for (uint64_t i = b * block; i < std::min(count, (b + 1) * block); i++) s += entry_len(e[i]);
@@ -758,7 +760,7 @@ bool write_blobs(const std::vector<Entry> &e, const void *values, int value_kind
     if (!ok) *why = "cannot create " + (fb < 0 ? pb : pi);
     std::atomic<bool> io_ok{true};
     if (ok) {
-#pragma omp parallel
+#pragma omp parallel num_threads(hb::host_threads())
         {
             bytes blob, bid;
 #pragma omp for schedule(dynamic, 4)
@@ -833,7 +835,7 @@ int write_dbs(const std::vector<Target> &targets, const hb_u128 *ids, uint64_t c
     auto lap = [&](const char *what) {
         if (!trace) return;
         const double t = omp_get_wtime();
-        std::fprintf(stderr, "[hb store] %-28s %8.3f s  (%d threads)\n", what, t - t_lap, omp_get_max_threads());
+        std::fprintf(stderr, "[hb store] %-28s %8.3f s  (%d threads)\n", what, t - t_lap, hb::host_threads());
         t_lap = t;
     };
     std::vector<Entry> entries;
@@ -844,7 +846,7 @@ int write_dbs(const std::vector<Target> &targets, const hb_u128 *ids, uint64_t c
     bytes blm;
     {
         Bloom bloom(count);
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for num_threads(hb::host_threads()) schedule(static)
         for (uint64_t i = 0; i < count; i++) {
             uint8_t key[17];
             entries[i].key_bytes(key);

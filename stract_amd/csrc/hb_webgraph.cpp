@@ -1,6 +1,7 @@
 // hb_webgraph.cpp - native reader of Stract's webgraph edge store (include/hb_webgraph.h states the format and
 // cites the reference serialisers it follows).  Host C++ only; nothing is copied from the reference.
 #include "../../include/hb_webgraph.h"
+#include "hb_threads.h"
 
 #include <dlfcn.h>
 #include <fcntl.h>
@@ -9,11 +10,16 @@
 #include <unistd.h>
 
 #include <algorithm>
+#include <chrono>
+#include <condition_variable>
+#include <cstdlib>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <memory>
 #include <string>
+#include <thread>
 #include <vector>
 
 namespace {
@@ -68,6 +74,52 @@ uint32_t crc32_ieee(const uint8_t *p, uint64_t n)
     }
     while (n--) c = T.t[0][(c ^ *p++) & 0xFF] ^ (c >> 8);
     return c ^ 0xFFFFFFFFu;
+}
+
+// crc of the concatenation A ++ B from crc(A), crc(B) and |B| (the zlib construction: crc(A) is advanced over |B| zero
+// bytes by repeated squaring of the "one zero bit" operator over GF(2), then xor-ed with crc(B))
+uint32_t gf2_times(const uint32_t *mat, uint32_t vec)
+{
+    uint32_t sum = 0;
+    for (; vec; vec >>= 1, mat++)
+        if (vec & 1) sum ^= *mat;
+    return sum;
+}
+void gf2_square(uint32_t *sq, const uint32_t *mat)
+{
+    for (int k = 0; k < 32; k++) sq[k] = gf2_times(mat, mat[k]);
+}
+uint32_t crc32_combine(uint32_t crc1, uint32_t crc2, uint64_t len2)
+{
+    if (!len2) return crc1;
+    uint32_t even[32], odd[32];
+    odd[0] = 0xEDB88320u; // operator for one zero bit
+    for (int k = 1; k < 32; k++) odd[k] = 1u << (k - 1);
+    gf2_square(even, odd); // two zero bits
+    gf2_square(odd, even); // four
+    do {                   // first squaring below: one zero byte
+        gf2_square(even, odd);
+        if (len2 & 1) crc1 = gf2_times(even, crc1);
+        len2 >>= 1;
+        if (!len2) break;
+        gf2_square(odd, even);
+        if (len2 & 1) crc1 = gf2_times(odd, crc1);
+        len2 >>= 1;
+    } while (len2);
+    return crc1 ^ crc2;
+}
+// the same CRC over a large range, pieces in parallel (a 100 GB store at one thread's 1.5 GB/s would take a minute)
+uint32_t crc32_ieee_parallel(const uint8_t *p, uint64_t n)
+{
+    const uint64_t piece = 64ull << 20;
+    if (n <= 2 * piece) return crc32_ieee(p, n);
+    const uint64_t pieces = (n + piece - 1) / piece;
+    std::vector<uint32_t> part((size_t)pieces);
+#pragma omp parallel for num_threads(hb::host_threads()) schedule(dynamic, 1)
+    for (int64_t k = 0; k < (int64_t)pieces; k++) part[(size_t)k] = crc32_ieee(p + (uint64_t)k * piece, std::min(piece, n - (uint64_t)k * piece));
+    uint32_t c = part[0];
+    for (uint64_t k = 1; k < pieces; k++) c = crc32_combine(c, part[(size_t)k], std::min(piece, n - k * piece));
+    return c;
 }
 
 // ---- zstd, only if a dictionary block is compressed (blocks above 2048 bytes, sstable/delta.rs:58-80) --------
@@ -405,7 +457,7 @@ std::string open_segment(const std::string &dir, uint32_t flags, Segment *s)
         const size_t at = js.find("\"crc\":");
         if (at == std::string::npos) return path + ": footer without crc";
         const uint64_t want = std::strtoull(js.c_str() + at + 6, nullptr, 10);
-        if ((uint64_t)crc32_ieee(body.p, body.n) != want) return path + ": CRC mismatch";
+        if ((uint64_t)crc32_ieee_parallel(body.p, body.n) != want) return path + ": CRC mismatch";
     }
     // columnar footer (reader/mod.rs:85-103): [column data][sstable][sstable_len u64][num_rows u32][version u32][magic 4]
     if (body.n < 20) return path + ": columnar body too small";
@@ -562,7 +614,7 @@ static int read_records(const hbw_reader *r, bool page_level, uint64_t first, ui
         if (!from || !to) return HB_ERR_INVALID; // page-level ids: the reader was opened without HBW_PAGE_IDS
         const uint64_t b = pos - s.first, n = std::min<uint64_t>(count - done, s.num_rows - b);
         hb_edge *dst = out + done;
-#pragma omp parallel for schedule(static) if (n > 65536)
+#pragma omp parallel for num_threads(hb::host_threads()) schedule(static) if (n > 65536)
         for (int64_t i = 0; i < (int64_t)n; i++) {
             std::memcpy(&dst[i].from, from + 16 * (b + (uint64_t)i), 16); // u128 little-endian = {lo, hi}
             std::memcpy(&dst[i].to, to + 16 * (b + (uint64_t)i), 16);
@@ -581,8 +633,12 @@ int hb_load_webgraph(hb_ctx *ctx, const char *edges_dir, uint32_t flags)
 {
     if (!ctx) return HB_ERR_INVALID;
     hbw_reader *raw = nullptr;
+    const bool trace = std::getenv("HB_TRACE_INGEST") != nullptr; // where the time of this call goes, on stderr
+    const auto t_begin = std::chrono::steady_clock::now();
+    auto since = [](std::chrono::steady_clock::time_point t0) { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); };
     int rc = hbw_open(edges_dir, flags, &raw);
     if (rc != HB_OK) return rc; // message: hbw_last_error(NULL)
+    const double s_open = since(t_begin);
     std::unique_ptr<hbw_reader, void (*)(hbw_reader *)> guard(raw, hbw_close); // closed on every path, exceptions included
     hbw_reader *r = raw;
     return guarded(r, [&]() -> int {
@@ -596,14 +652,84 @@ int hb_load_webgraph(hb_ctx *ctx, const char *edges_dir, uint32_t flags)
                 return rc0;
             }
         }
-        std::vector<hb_edge> buf((size_t)std::min<uint64_t>(slab, std::max<uint64_t>(r->total, 1)));
-        int rc2 = HB_OK;
-        for (uint64_t at = 0; at < r->total && rc2 == HB_OK; at += slab) {
-            const uint64_t n = std::min(slab, r->total - at);
-            rc2 = hbw_read_host_edges(r, at, n, buf.data());
-            if (rc2 == HB_OK) rc2 = hb_append_edges(ctx, buf.data(), n);
+        // two pinned slabs: a reader thread gathers slab k + 1 out of the mapped column files (all cores, read_records)
+        // while this thread hands slab k to the library (H2D at link rate + the table kernels)
+        struct Pinned {
+            hb_edge *p[2] = {nullptr, nullptr};
+            ~Pinned()
+            {
+                for (hb_edge *q : p) hb_pinned_free(q);
+            }
+        } pin;
+        const uint64_t cap = std::min<uint64_t>(slab, std::max<uint64_t>(r->total, 1));
+        for (int k = 0; k < 2; k++) {
+            void *q = nullptr;
+            if (hb_pinned_alloc(cap * sizeof(hb_edge), &q) != HB_OK) {
+                r->err = "hb_load_webgraph: cannot allocate the pinned record slabs";
+                return HB_ERR_NOMEM;
+            }
+            pin.p[k] = (hb_edge *)q;
         }
+        hb_edge *buf = pin.p[0]; // (the page-level pass below reuses the first slab)
+        const uint64_t nslabs = (r->total + slab - 1) / slab;
+        std::mutex mu;
+        std::condition_variable cv;
+        uint64_t filled = 0, taken = 0; // slabs gathered / handed over
+        int rd_rc = HB_OK;
+        bool stop = false;
+        double s_gather = 0, s_append = 0, s_wait = 0; // reader thread busy / this thread in hb_append_edges / waiting for a slab
+        std::thread producer([&]() {
+            for (uint64_t k = 0; k < nslabs; k++) {
+                {
+                    std::unique_lock<std::mutex> lk(mu);
+                    cv.wait(lk, [&] { return stop || k < taken + 2; }); // its buffer is free again
+                    if (stop) return;
+                }
+                const uint64_t at = k * slab, n = std::min(slab, r->total - at);
+                const auto t_g = std::chrono::steady_clock::now();
+                const int rc = hbw_read_host_edges(r, at, n, pin.p[k & 1]);
+                s_gather += since(t_g);
+                {
+                    std::lock_guard<std::mutex> lk(mu);
+                    if (rc != HB_OK) rd_rc = rc;
+                    filled = k + 1;
+                }
+                cv.notify_all();
+                if (rc != HB_OK) return;
+            }
+        });
+        int rc2 = HB_OK;
+        for (uint64_t k = 0; k < nslabs && rc2 == HB_OK; k++) {
+            {
+                const auto t_w = std::chrono::steady_clock::now();
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return filled > k || rd_rc != HB_OK; });
+                if (filled <= k) rc2 = rd_rc;
+                s_wait += since(t_w);
+            }
+            const auto t_a = std::chrono::steady_clock::now();
+            if (rc2 == HB_OK) rc2 = hb_append_edges(ctx, pin.p[k & 1], std::min(slab, r->total - k * slab));
+            s_append += since(t_a);
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                taken = k + 1;
+                if (rc2 != HB_OK) stop = true;
+            }
+            cv.notify_all();
+        }
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            stop = stop || rc2 != HB_OK;
+        }
+        cv.notify_all();
+        producer.join();
+        const auto t_f = std::chrono::steady_clock::now();
         if (rc2 == HB_OK) rc2 = hb_finalize(ctx, nullptr, 0); // node set = all endpoints = host_nodes() (store.rs:338-357)
+        if (trace)
+            std::fprintf(stderr, "[hb webgraph] %llu records in %zu segments: open%s %.3f s; %llu slabs: reader thread gathering %.3f s, this thread waiting "
+                                 "for a slab %.3f s, in hb_append_edges %.3f s; hb_finalize %.3f s; total %.3f s\n", (unsigned long long)r->total, r->segs.size(),
+                         (flags & HBW_VERIFY_CRC) ? " + CRC-32 of every file" : "", s_open, (unsigned long long)nslabs, s_gather, s_wait, s_append, since(t_f),
+                         since(t_begin));
         if (rc2 == HB_OK && (flags & HBW_PAGE_IDS)) {
             // HB_FLAG_REFERENCE_TAIL: every document's page-level (from_id, to_id, rel_flags), segment by segment in doc
             // order (a ForwardlinksQuery runs one LinksScorer per segment; its de-duplication depends on that order,
@@ -612,8 +738,8 @@ int hb_load_webgraph(hb_ctx *ctx, const char *edges_dir, uint32_t flags)
             for (const Segment &s : r->segs) {
                 for (uint64_t at = 0; at < s.num_rows && rc2 == HB_OK; at += slab) {
                     const uint64_t n = std::min(slab, s.num_rows - at);
-                    rc2 = hbw_read_page_edges(r, s.first + at, n, buf.data());
-                    if (rc2 == HB_OK) rc2 = hb_append_tail_edges(ctx, buf.data(), n);
+                    rc2 = hbw_read_page_edges(r, s.first + at, n, buf);
+                    if (rc2 == HB_OK) rc2 = hb_append_tail_edges(ctx, buf, n);
                 }
                 if (rc2 == HB_OK) rc2 = hb_tail_segment_end(ctx);
             }
@@ -651,6 +777,6 @@ int hbw_debug_sstable(const uint8_t *bytes, uint64_t len, int value_mode, uint8_
     });
 }
 
-uint32_t hbw_debug_crc32(const uint8_t *bytes, uint64_t len) { return crc32_ieee(bytes, len); }
+uint32_t hbw_debug_crc32(const uint8_t *bytes, uint64_t len) { return crc32_ieee_parallel(bytes, len); } // (pieces + combine above 128 MiB)
 
 } // extern "C"

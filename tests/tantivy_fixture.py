@@ -158,6 +158,64 @@ def with_footer(body):
     return body + js + struct.pack("<II", len(js), 1337)
 
 
+def _column_parts(ctype, values):
+    """column_bytes as a list of buffers (header bytes, the value array itself, trailer) - no copy of the values"""
+    b = column_bytes(ctype, values[:0])  # header layout from the one implementation above, values spliced in below
+    n = len(values)
+    if ctype == U128:
+        v = np.ascontiguousarray(values)
+        head = bytearray([0, 0]) + struct.pack("<I", n)
+        for pick in (np.min, np.max):
+            hi = pick(v["hi"]) if n else 0
+            lo = pick(v["lo"][v["hi"] == hi]) if n else 0
+            head += struct.pack("<QQ", int(lo), int(hi))
+    else:
+        v = np.ascontiguousarray(values, dtype="<u8")
+        head = bytearray([0, 3]) + struct.pack("<I", n) + struct.pack("<QQ", int(v.min()) if n else 0, int(v.max()) if n else 0)
+    assert len(head) == len(b) - 4
+    return [bytes(head), v.view(np.uint8).reshape(-1), struct.pack("<I", 1)]
+
+
+def write_edge_store_streamed(path, segments, crc32=None):
+    """The same store as write_edge_store(extra_columns=False), for BASELINE-size streams: `segments` may be a generator (one
+    EDGE array at a time, never the whole stream), every segment body is assembled once in one buffer, and `crc32` may be a
+    faster CRC-32 (IEEE) of a uint8 array than zlib's single thread (the library's hbw_debug_crc32: pieces on all cores)."""
+    os.makedirs(path, exist_ok=True)
+    metas, ids = [], []
+    for i, edges in enumerate(segments):
+        sid = uuid.UUID(int=(0xA5C4DFCBDFE645089129E308E26D5500 + i))
+        n = len(edges)
+        cols = {"from_host_id": (U128, edges["from"]), "to_host_id": (U128, edges["to"]), "rel_flags": (U64, edges["rel_flags"])}
+        parts, entries, at = [], [], 0
+        for name, (ctype, values) in sorted(cols.items(), key=lambda kv: (kv[0].encode(), kv[1][0])):
+            start = at
+            for piece in _column_parts(ctype, values):
+                parts.append(piece)
+                at += len(piece)
+            entries.append((name.encode() + b"\0" + bytes([ctype]), (start, at)))
+        sst = sstable_ranges(entries)
+        tail = sst + struct.pack("<QI", len(sst), n) + struct.pack("<I", 1) + bytes([2, 113, 119, 66])
+        body = np.empty(at + len(tail), dtype=np.uint8)
+        pos = 0
+        for piece in parts + [tail]:
+            k = len(piece)
+            body[pos:pos + k] = np.frombuffer(piece, dtype=np.uint8) if isinstance(piece, (bytes, bytearray)) else piece
+            pos += k
+        crc = (crc32(body) if crc32 else zlib.crc32(body)) & 0xFFFFFFFF
+        js = json.dumps({"version": {"major": 0, "minor": 23, "patch": 0, "index_format_version": 6}, "crc": crc}, separators=(",", ":")).encode()
+        with open(os.path.join(path, sid.hex + ".col"), "wb") as f:
+            f.write(body)
+            f.write(js + struct.pack("<II", len(js), 1337))
+        metas.append({"segment_id": str(sid), "max_doc": n, "deletes": None})
+        ids.append(sid.hex)
+    meta = {"index_settings": {"sort_by_field": {"field": "sort_score", "order": "Asc"}, "docstore_compression": "lz4",
+                               "docstore_blocksize": 16384},
+            "segments": metas, "schema": [{"name": "from_host_id", "type": "u128", "options": {"columnar": True}}], "opstamp": 7}
+    with open(os.path.join(path, "meta.json"), "w") as f:
+        json.dump(meta, f, separators=(",", ":"))
+    return ids
+
+
 def write_edge_store(path, segments, extra_columns=True, page_segments=None):
     """segments: list of EDGE record arrays (stract_amd._lib.EDGE), one tantivy segment each.  Returns the uuids.
     page_segments: per segment, EDGE arrays whose from / to are the documents' page-level `from_id` / `to_id`

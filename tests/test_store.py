@@ -213,3 +213,52 @@ def test_store_never_reports_ok_without_a_meta(tmp_path):
     _lib.store_write(str(empty), ids[:0], vals[:0])  # {"segments": []} may be filled later
     _lib.store_write(str(empty), ids, vals)
     assert kv.Db(str(empty), "f64", str(tmp_path)).get(3) == 0.5
+
+
+def test_published_vectors_of_the_restated_formats(tmp_path):
+    """Pins that do not come from this repository's own reading of the formats:
+      * bincode's documented variable-length integer encoding (bincode docs, `config::standard()` / VarintEncoding: u < 251 one
+        byte; 251 + u16; 252 + u32; 253 + u64; 254 + u128, little endian) at every class boundary - the key bytes in .blobs;
+      * XXH3: the published hashes of the empty input (xxHash's own sanity vectors: XXH3_64bits = 2D06800538D394C2,
+        XXH3_128bits = 99AA06D3014798D8 6001C324468D497F), so the vendored header is the real algorithm; and the documented
+        property that a secret generated from a seed reproduces the seeded variant for inputs above 240 bytes
+        (xxhash.h, XXH3_generateSecret_fromSeed) - the route by which `const_custom_default_secret(42)` is restated."""
+    import ctypes
+    import subprocess
+    want = {0: b"\x00", 250: b"\xfa", 251: b"\xfb\xfb\x00", 65535: b"\xfb\xff\xff", 65536: b"\xfc\x00\x00\x01\x00",
+            (1 << 32) - 1: b"\xfc\xff\xff\xff\xff", 1 << 32: b"\xfd\x00\x00\x00\x00\x01\x00\x00\x00",
+            (1 << 64) - 1: b"\xfd" + b"\xff" * 8, 1 << 64: b"\xfe" + b"\x00" * 8 + b"\x01" + b"\x00" * 7,
+            (1 << 128) - 1: b"\xfe" + b"\xff" * 16}
+    ints = list(want)
+    ids = kv.ints_to_ids(ints, _lib.U128)
+    _lib.store_write(str(tmp_path / "db"), ids, np.arange(len(ints), dtype=np.float64))
+    f = _segment_files(str(tmp_path / "db"))
+    keys = []
+    for i in range(len(ints)):
+        ks, ke, vs, ve = struct.unpack_from("<QQQQ", f[".bid"], 32 * i)
+        keys.append(f[".blobs"][ks:ke])
+        assert ve - vs == 8 and vs == ke
+    assert sorted(keys) == keys and set(keys) == set(want.values())
+    for i, k in want.items():
+        assert kv.varint_encode(i) == k
+    src = tmp_path / "x.c"
+    src.write_text('#define XXH_INLINE_ALL\n#include "%s"\n#include <string.h>\n'
+                   "unsigned long long h64(const void *p, unsigned long n) { return XXH3_64bits(p, n); }\n"
+                   "void h128(const void *p, unsigned long n, unsigned long long *o) { XXH128_hash_t h = XXH3_128bits(p, n); o[0] = h.high64; o[1] = h.low64; }\n"
+                   "int secret_matches_seed(const void *p, unsigned long n, unsigned long long seed) {\n"
+                   "  unsigned char s[XXH3_SECRET_DEFAULT_SIZE]; XXH3_generateSecret_fromSeed(s, seed);\n"
+                   "  XXH128_hash_t a = XXH3_128bits_withSecret(p, n, s, sizeof(s)), b = XXH3_128bits_withSeed(p, n, seed);\n"
+                   "  return a.low64 == b.low64 && a.high64 == b.high64; }\n" % os.path.join(kv.ROOT, "third_party", "xxhash", "xxhash.h"))
+    subprocess.check_call(["gcc", "-O2", "-shared", "-fPIC", "-o", str(tmp_path / "x.so"), str(src)])
+    x = ctypes.CDLL(str(tmp_path / "x.so"))
+    x.h64.restype = ctypes.c_ulonglong
+    x.h64.argtypes = [ctypes.c_char_p, ctypes.c_ulong]
+    x.h128.argtypes = [ctypes.c_char_p, ctypes.c_ulong, ctypes.POINTER(ctypes.c_ulonglong)]
+    x.secret_matches_seed.argtypes = [ctypes.c_char_p, ctypes.c_ulong, ctypes.c_ulonglong]
+    assert x.h64(b"", 0) == 0x2D06800538D394C2
+    o = (ctypes.c_ulonglong * 2)()
+    x.h128(b"", 0, o)
+    assert (o[0], o[1]) == (0x99AA06D3014798D8, 0x6001C324468D497F)
+    long_input = bytes(range(256)) * 3
+    assert x.secret_matches_seed(long_input, len(long_input), 42) == 1
+    assert x.secret_matches_seed(long_input, 241, 42) == 1

@@ -234,3 +234,29 @@ def test_zstd_compressed_dictionary_block():
     bad[20] ^= 0xFF
     buf2 = np.frombuffer(bytes(bad), dtype=np.uint8)
     assert lib.hbw_debug_sstable(buf2.ctypes.data, len(buf2), 1, keys_out.ctypes.data, len(keys_out), ranges.ctypes.data, len(ranges), ctypes.byref(cnt)) != 0
+
+
+def test_crc32_pieces_and_combine_equal_zlib():
+    """the CRC of a large .col body is computed in 64 MiB pieces on all cores and combined (crc of a concatenation from the
+    crcs of its parts); zlib.crc32 is the independent statement of the same polynomial"""
+    import zlib
+    rng = np.random.default_rng(5)
+    for nbytes in (0, 1, 7, 1 << 20, (130 << 20) + 12345, (64 << 20) * 3):
+        buf = rng.integers(0, 256, nbytes, dtype=np.uint8)
+        got = _lib.load().hbw_debug_crc32(buf.ctypes.data_as(ctypes.c_void_p), nbytes)
+        assert got == zlib.crc32(buf.tobytes()), nbytes
+
+
+def test_streamed_fixture_writer_equals_the_plain_one(tmp_path):
+    """write_edge_store_streamed (one assembled buffer per segment, generator input, pluggable CRC) must write the very
+    files write_edge_store(extra_columns=False) writes"""
+    g = synth.RmatGraph(10, 5000)
+    e = g.edges(salt=1, salt_seed=3)
+    segs = [e[:1000], e[1000:1001], e[1001:]]
+    a, b = tmp_path / "plain", tmp_path / "streamed"
+    ids_a = tf.write_edge_store(str(a), segs, extra_columns=False)
+    ids_b = tf.write_edge_store_streamed(str(b), (s for s in segs),
+                                         crc32=lambda buf: _lib.load().hbw_debug_crc32(buf.ctypes.data_as(ctypes.c_void_p), buf.nbytes))
+    assert ids_a == ids_b
+    for name in sorted(os.listdir(a)):
+        assert open(a / name, "rb").read() == open(b / name, "rb").read(), name

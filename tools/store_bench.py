@@ -39,7 +39,7 @@ def main():
            "bytes_written": size, "write_GBs": round(size / dt / 1e9, 3), "threads": os.cpu_count(), "dir": base}
     if a.check:
         from tests import speedy_kv_reader as kv
-        db = kv.Db(os.path.join(out, "harmonic_rank"), "u64", base)
+        db = kv.Db(os.path.join(out, "harmonic_rank"), "u64", tempfile.gettempdir())
         ints = kv.ids_to_ints(ids)
         pick = rng.integers(0, a.n, a.check)
         res["checked"] = int(a.check)
