@@ -45,12 +45,16 @@ torch.distributed.run, one rank per GPU).  Prints ONE JSON line on rank 0.
               of the SAME passes is reported next to it (like for like); `cpu_faithful` = the
               single-thread structure-faithful form on C1.
 """
-import argparse
-import json
 import os
-import subprocess
-import sys
-import time
+
+# before anything that may load an OpenMP runtime: idle OpenMP workers sleep instead of spinning (see stract_amd/_lib.py)
+os.environ.setdefault("OMP_WAIT_POLICY", "passive")
+
+import argparse  # noqa: E402
+import json  # noqa: E402
+import subprocess  # noqa: E402
+import sys  # noqa: E402
+import time  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
@@ -393,21 +397,31 @@ def main():
     if world != max(a.gpus, 1):
         if world == 1 and a.gpus > 1:
             sys.exit("bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)" % a.gpus)
-    import torch
-
-    if not torch.cuda.is_available():
-        sys.exit("bench.py needs a GPU: the HyperBall library has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    td = None
+    # PyTorch is plumbing for N > 1 only (torch.distributed: rendezvous, barrier, the max over ranks).  At N = 1 it is not
+    # imported at all: the library then runs on /opt/rocm's HIP runtime instead of the one bundled with torch (same soname:
+    # whichever is loaded first serves both), and no second OpenMP runtime enters the process.
+    torch, td = None, None
     if world > 1:
+        import torch
         import torch.distributed as td
 
+        if not torch.cuda.is_available():
+            sys.exit("bench.py needs a GPU: the HyperBall library has no CPU fallback")
+        torch.cuda.set_device(local_rank)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         td.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     from stract_amd import _lib, dist, synth
 
+    if world == 1 and _lib.device_count() < 1:
+        sys.exit("bench.py needs a GPU: the HyperBall library has no CPU fallback")
+    live_ctx = [None]  # the context whose stream the N = 1 barrier synchronises
+
     def barrier():
+        if torch is None:
+            if live_ctx[0] is not None:
+                live_ctx[0].synchronize()
+            return
         torch.cuda.synchronize()
         if td is not None:
             td.barrier()
@@ -443,6 +457,7 @@ def main():
         else:
             ctx.load_dense(g.ids, g.row_ptr, g.src)
         info["s_load"] = round(time.perf_counter() - t0, 2)
+        live_ctx[0] = ctx
         return ctx, measure(ctx, a.steps, a.warmup, barrier, td, torch), info
 
     exit_code = 0
@@ -563,7 +578,9 @@ def main():
     if want_c4 and world == 1:
         g.close()
         del g
-        torch.cuda.empty_cache()
+        live_ctx[0] = None
+        if torch is not None:
+            torch.cuda.empty_cache()
         try:
             c4 = c4_leg(a)
         except Exception as e:  # the main line is still printed, but the run counts as failed (exit code below)
@@ -688,8 +705,6 @@ def cpu_and_parity(a, g, ctx, td, rank, world, gpu_passes, gpu_ids, gpu_vals, gp
     (NodeID, f64) list when the oracle converged, else a checksum of registers (+ Kahan state on one GPU)
     after the last pass the oracle finished - the GPU is re-run for that many passes (collectively for
     N > 1).  Returns (cpu_baseline dict or None, parity dict)."""
-    import torch
-
     cpu, parity, done, o = None, None, 0, None
     if rank == 0:
         from oracle import hbo
@@ -744,10 +759,12 @@ def cpu_and_parity(a, g, ctx, td, rank, world, gpu_passes, gpu_ids, gpu_vals, gp
         except Exception as e:  # pragma: no cover
             cpu["cpu_faithful"] = {"error": str(e)}
     # did the oracle stop early?  then compare state checksums after `done` passes
-    need = torch.tensor([done if (rank == 0 and parity is None) else 0], dtype=torch.int64, device="cuda")
+    k = done if (rank == 0 and parity is None) else 0
     if td is not None:
+        import torch
+        need = torch.tensor([k], dtype=torch.int64, device="cuda")
         td.broadcast(need, src=0)
-    k = int(need.item())
+        k = int(need.item())
     if k > 0:
         ctx.begin()
         for _ in range(k):

@@ -284,6 +284,35 @@ int hb_result_top(hb_ctx *ctx, uint64_t k, hb_u128 *ids, double *vals, uint64_t 
  * every rank puts them in hb_options.rccl_id. */
 int hb_rccl_unique_id(uint8_t out[128]);
 
+/* The exchanges of a pass through the CALLER's collectives instead of RCCL [r4]: a context created with world_size > 1 and
+ * HB_FLAG_NO_RCCL behaves exactly like one with a communicator (same kernels, same row slices, same event ordering of the
+ * merge / all-reduce / epilogue pipeline, same changed-only packing) once these three functions are set - every
+ * ncclAllReduce / ncclAllGather / ncclBroadcast of the pass driver goes through them.  Purpose: (1) the multi-process
+ * protocol can run as real library code on ONE device, N processes exchanging through host-staged torch.distributed
+ * (gloo) tensors - tests/test_gpu.py, since RCCL refuses two ranks on one device; (2) an integrator whose ranks are
+ * already connected by another fabric (MPI, the reference's own DHT) needs no RCCL bootstrap.
+ * All pointers are DEVICE pointers; `stream` is the hipStream_t the call is ordered on (work queued on it before the call
+ * must be visible to the exchange, work queued after it must see the result; a blocking implementation simply
+ * synchronises the stream first).  Return 0, or non-zero to fail the pass with HB_ERR_RCCL.  Set before loading the graph. */
+#define HB_COLL_U8 0
+#define HB_COLL_U32 1
+#define HB_COLL_U64 2
+#define HB_COLL_F64 3
+#define HB_COLL_MAX 0
+#define HB_COLL_SUM 1
+typedef struct hb_collectives {
+    void *user;
+    /* in place over `count` elements of `dtype` on every rank */
+    int (*all_reduce)(void *user, void *buf, uint64_t count, int dtype, int op, void *stream);
+    /* recv = world x bytes_per_rank bytes, rank r's part at r x bytes_per_rank; send may be that very part of recv */
+    int (*all_gather)(void *user, const void *send, void *recv, uint64_t bytes_per_rank, void *stream);
+    /* `bytes` bytes at buf from rank `root` to every rank */
+    int (*broadcast)(void *user, void *buf, uint64_t bytes, int root, void *stream);
+} hb_collectives;
+int hb_set_collectives(hb_ctx *ctx, const hb_collectives *ops);
+/* helper for host-staged implementations of the above: copy on `stream`, then synchronise it (to_device: host -> device) */
+int hb_debug_staged_copy(void *dst, const void *src, uint64_t bytes, int to_device, void *stream);
+
 /* ---- pinned batch buffers ------------------------------------------------------------------- */
 /* Page-locked host memory for the record batches of hb_append_edges / hb_load_edges (hipHostMalloc): a batch that lies
  * in pinned memory crosses the host link asynchronously at its full rate (57 GB/s measured on the MI355X boxes,

@@ -22,6 +22,8 @@ LIB_PATH = os.environ.get("HB_LIB_PATH") or os.path.join(_HERE, "lib", "libhyper
 HB_OK = 0
 HB_ERR_INVALID, HB_ERR_NO_DEVICE, HB_ERR_HIP, HB_ERR_NOMEM, HB_ERR_RCCL, HB_ERR_LIMIT, HB_ERR_IO = -1, -2, -3, -4, -5, -6, -7
 HB_STORE_F64, HB_STORE_U64 = 0, 1
+HB_COLL_U8, HB_COLL_U32, HB_COLL_U64, HB_COLL_F64 = 0, 1, 2, 3
+HB_COLL_MAX, HB_COLL_SUM = 0, 1
 HB_SKIPPED_REL_MASK = 0x6FED00
 
 HB_FLAG_NO_FRONTIER = 0x01
@@ -126,6 +128,8 @@ _SIGNATURES = [
     ("hb_append_tail_edges", ctypes.c_int, [_P, _P, _U64]),
     ("hb_tail_segment_end", ctypes.c_int, [_P]),
     ("hb_debug_set_ingest_limits", ctypes.c_int, [_P, _U64, _U64, _U64]),
+    ("hb_set_collectives", ctypes.c_int, [_P, _P]),
+    ("hb_debug_staged_copy", ctypes.c_int, [_P, _P, _U64, ctypes.c_int, _P]),
     ("hb_pinned_alloc", ctypes.c_int, [_U64, ctypes.POINTER(ctypes.c_void_p)]),
     ("hb_pinned_free", None, [ctypes.c_void_p]),
     ("hb_debug_h2d_rate", ctypes.c_int, [_P, _P, _U64, ctypes.c_int, ctypes.POINTER(ctypes.c_double)]),

@@ -37,6 +37,7 @@ struct hb_ctx {
     int num_cu = 256;
     hipStream_t stream = nullptr;
     ncclComm_t comm = nullptr;
+    hb_collectives coll{}; // hb_set_collectives: the per-pass exchanges go through these instead of RCCL (HB_FLAG_NO_RCCL contexts)
     std::string err;
     std::string arch;
 
@@ -237,6 +238,58 @@ PlanTune plan_tune(uint32_t chunk, const uint32_t *tune)
 }
 
 bool multi_rank(const hb_ctx *c) { return c->opt.world_size > 1; }
+// the context can exchange with the other ranks by itself: an RCCL communicator, or the caller's collectives
+bool linked(const hb_ctx *c) { return c->comm != nullptr || c->coll.all_reduce != nullptr; }
+
+#define HB_COLL(call)                 \
+    do {                              \
+        const int rc_coll_ = (call);  \
+        if (rc_coll_) return rc_coll_; \
+    } while (0)
+int coll_dtype(ncclDataType_t dt) { return dt == ncclUint8 ? HB_COLL_U8 : dt == ncclUint32 ? HB_COLL_U32 : dt == ncclUint64 ? HB_COLL_U64 : HB_COLL_F64; }
+uint64_t coll_size(ncclDataType_t dt) { return dt == ncclUint8 ? 1 : dt == ncclUint32 ? 4 : 8; }
+// in place, like every exchange of the pass driver
+int coll_all_reduce(hb_ctx *c, void *buf, uint64_t count, ncclDataType_t dt, ncclRedOp_t op, hipStream_t s)
+{
+    if (c->comm) {
+        HB_NCCL(ncclAllReduce(buf, buf, count, dt, op, c->comm, s));
+        return HB_OK;
+    }
+    if (c->coll.all_reduce(c->coll.user, buf, count, coll_dtype(dt), op == ncclMax ? HB_COLL_MAX : HB_COLL_SUM, (void *)s))
+        return fail(c, HB_ERR_RCCL, "the caller's all_reduce (hb_set_collectives) failed");
+    return HB_OK;
+}
+// recv holds world x count elements, send = this rank's count elements (may lie inside recv at its place)
+int coll_all_gather(hb_ctx *c, const void *send, void *recv, uint64_t count, ncclDataType_t dt, hipStream_t s)
+{
+    if (c->comm) {
+        HB_NCCL(ncclAllGather(send, recv, count, dt, c->comm, s));
+        return HB_OK;
+    }
+    if (c->coll.all_gather(c->coll.user, send, recv, count * coll_size(dt), (void *)s))
+        return fail(c, HB_ERR_RCCL, "the caller's all_gather (hb_set_collectives) failed");
+    return HB_OK;
+}
+int coll_broadcast(hb_ctx *c, void *buf, uint64_t count, ncclDataType_t dt, int root, hipStream_t s)
+{
+    if (c->comm) {
+        HB_NCCL(ncclBroadcast(buf, buf, count, dt, root, c->comm, s));
+        return HB_OK;
+    }
+    if (c->coll.broadcast(c->coll.user, buf, count * coll_size(dt), root, (void *)s))
+        return fail(c, HB_ERR_RCCL, "the caller's broadcast (hb_set_collectives) failed");
+    return HB_OK;
+}
+int coll_group_start(hb_ctx *c)
+{
+    if (c->comm) HB_NCCL(ncclGroupStart());
+    return HB_OK;
+}
+int coll_group_end(hb_ctx *c)
+{
+    if (c->comm) HB_NCCL(ncclGroupEnd());
+    return HB_OK;
+}
 // destination partition: this rank owns the rows (nodes) with sid % world == rank and holds all their
 // in-edges; one all-gather of the owned counter slices per pass
 // (also with a 1-rank communicator, HB_FLAG_RCCL_SELF: the grouped all-gathers run for real on one GPU)
@@ -249,7 +302,7 @@ bool edge_partitioned(const hb_ctx *c) { return multi_rank(c) && !dest_mode(c); 
 bool ref_tail(const hb_ctx *c) { return (c->opt.flags & HB_FLAG_REFERENCE_TAIL) != 0; }
 bool unfused(const hb_ctx *c)
 {
-    return edge_partitioned(c) || (c->comm && !dest_mode(c)) || (c->opt.flags & HB_FLAG_UNFUSED) || ref_tail(c);
+    return edge_partitioned(c) || (linked(c) && !dest_mode(c)) || (c->opt.flags & HB_FLAG_UNFUSED) || ref_tail(c);
 }
 
 // Transposed work-row graph (who reads each node / virtual row), touch bitmap and seed lists for the
@@ -588,6 +641,40 @@ int hb_finalize(hb_ctx *c, const hb_u128 *node_ids, uint64_t n)
     });
 }
 
+int hb_set_collectives(hb_ctx *c, const hb_collectives *ops)
+{
+    return guarded(c, [&]() -> int {
+        if (!c) return HB_ERR_INVALID;
+        if (c->comm) return fail(c, HB_ERR_INVALID, "hb_set_collectives: the context already has an RCCL communicator (create it with HB_FLAG_NO_RCCL)");
+        if (c->loaded) return fail(c, HB_ERR_INVALID, "hb_set_collectives: set the collectives before the graph is loaded");
+        if (!ops) {
+            c->coll = hb_collectives{};
+            return HB_OK;
+        }
+        if (!ops->all_reduce || !ops->all_gather || !ops->broadcast) return fail(c, HB_ERR_INVALID, "hb_set_collectives: all three functions are required");
+        int rc = set_device(c);
+        if (rc) return rc;
+        if (!c->comm_stream) { // the merge / all-reduce / epilogue pipeline of the edge partition runs the exchange on its own stream
+            HB_HIP(hipStreamCreateWithFlags(&c->comm_stream, hipStreamNonBlocking));
+            for (int i = 0; i < hb_ctx::kOverlap; i++) {
+                HB_HIP(hipEventCreateWithFlags(&c->ov_merged[i], hipEventDisableTiming));
+                HB_HIP(hipEventCreateWithFlags(&c->ov_reduced[i], hipEventDisableTiming));
+            }
+        }
+        c->coll = *ops;
+        return HB_OK;
+    });
+}
+
+int hb_debug_staged_copy(void *dst, const void *src, uint64_t bytes, int to_device, void *stream)
+{
+    hipError_t e = hipSuccess;
+    if (bytes) e = hipMemcpyAsync(dst, src, bytes, to_device ? hipMemcpyHostToDevice : hipMemcpyDeviceToHost, (hipStream_t)stream);
+    if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
+    if (e != hipSuccess) (void)hipGetLastError();
+    return e == hipSuccess ? HB_OK : HB_ERR_HIP;
+}
+
 int hb_pinned_alloc(uint64_t bytes, void **out)
 {
     if (!out) return HB_ERR_INVALID;
@@ -836,10 +923,9 @@ int hb_finish(hb_ctx *c)
         if (rc) return rc;
         const Plan &p = c->plan;
         double t0 = now_ms();
-        if (c->comm && p.n_pad) {
+        if (linked(c) && p.n_pad) {
             // every rank ends with all Kahan sums: in-place all-gather of the owned slices
-            HB_NCCL(ncclAllGather(c->d_ksum + (uint64_t)c->opt.rank * c->slice_rows, c->d_ksum, c->slice_rows, ncclDouble,
-                                  c->comm, c->stream));
+            HB_COLL(coll_all_gather(c, c->d_ksum + (uint64_t)c->opt.rank * c->slice_rows, c->d_ksum, c->slice_rows, ncclDouble, c->stream));
         }
         // normalize_centralities (harmonic.rs:178-195) on the device, in ascending-NodeID order;
         // norm_factor = (num_nodes - 1) as f64 (:229)

@@ -372,7 +372,8 @@ std::string read_npid(hipStream_t stream, IngestStream *st)
 // is only known exactly after a synchronisation, so the test runs on an upper bound (keys at the last read-back + 2 per
 // record launched since) and synchronises only when that bound says the table might be too small.
 // "... out of memory" when the (larger) table cannot be allocated or the debug byte limit forbids it.
-std::string table_reserve(hipStream_t stream, IngestStream *st, uint64_t incoming)
+template <class Poll>
+std::string table_reserve(hipStream_t stream, IngestStream *st, uint64_t incoming, Poll &&poll)
 {
     if (!st->d_counter) {
         IG_HIP(hipMalloc((void **)&st->d_counter, 256));
@@ -380,9 +381,17 @@ std::string table_reserve(hipStream_t stream, IngestStream *st, uint64_t incomin
         IG_HIP(hipMemsetAsync(st->d_counter, 0, 256, stream));
     }
     auto fits = [&](uint64_t slots) { return slots && (st->npid_known + 2 * st->unsynced + 2 * incoming) * 2 <= slots; };
-    if (fits(st->tab_slots)) return "";
+    if (fits(st->tab_slots)) return ""; // the common case costs no runtime call at all
     if (st->tab_slots) {
+        const double t0 = now_ms();
+        poll(); // snapshots behind the slabs that have completed (non-blocking)
+        st->trace_polls++;
+        st->trace_ms_poll += now_ms() - t0;
+        if (fits(st->tab_slots)) return "";
+        const double t1 = now_ms();
         const std::string e = read_npid(stream, st);
+        st->trace_reads++;
+        st->trace_ms_read += now_ms() - t1;
         if (!e.empty()) return e;
         if (fits(st->tab_slots)) return "";
     }
@@ -541,9 +550,8 @@ std::string gpu_ingest_append(void *stream_v, IngestStream *st, const hb_edge *e
         IngestChunk &c = st->chunks.back();
         const uint64_t cnt = std::min(std::min(slab, m - off), c.cap - c.count);
         const double t_b = now_ms();
-        poll_snapshots();
         {
-            const std::string e = table_reserve(kstream, st, cnt); // (all table work lives on the ingest's stream)
+            const std::string e = table_reserve(kstream, st, cnt, poll_snapshots); // (all table work lives on the ingest's stream)
             if (!e.empty()) {
                 undo();
                 return e;
@@ -576,8 +584,9 @@ std::string gpu_ingest_append(void *stream_v, IngestStream *st, const hb_edge *e
     poll_snapshots(); // everything has completed: the newest snapshot is exact and nothing is unknown any more
     if (trace)
         std::fprintf(stderr, "[hb ingest] append of %llu records: %.1f ms (chunk allocation %.1f, table reserve %.1f, issue %.1f, final wait %.1f); "
-                             "%llu ids in %llu slots\n", (unsigned long long)m, now_ms() - t_call, ms_alloc, ms_reserve, ms_issue, now_ms() - t_s,
-                     (unsigned long long)st->npid_known, (unsigned long long)st->tab_slots);
+                             "%llu ids in %llu slots; so far %llu polls %.1f ms, %llu blocking read-backs %.1f ms\n", (unsigned long long)m, now_ms() - t_call,
+                     ms_alloc, ms_reserve, ms_issue, now_ms() - t_s, (unsigned long long)st->npid_known, (unsigned long long)st->tab_slots,
+                     (unsigned long long)st->trace_polls, st->trace_ms_poll, (unsigned long long)st->trace_reads, st->trace_ms_read);
     return "";
 }
 

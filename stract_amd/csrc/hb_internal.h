@@ -198,6 +198,8 @@ struct IngestStream {
     unsigned long long *h_counter = nullptr; // pinned read-back word
     uint64_t npid_known = 0;                 // ... at the last read-back
     uint64_t unsynced = 0;                   // records launched since then (each can add two keys)
+    uint64_t trace_polls = 0, trace_reads = 0; // HB_TRACE_INGEST: slow-path visits of the table-size check
+    double trace_ms_poll = 0, trace_ms_read = 0;
     // limits (0 = none / default); the test hooks of hb_debug_set_ingest_limits lower them to reach the refusal and
     // spill paths at small sizes
     uint64_t max_records = 0;   // refuse to hold this many records or more ("too many records")

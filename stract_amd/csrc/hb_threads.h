@@ -1,5 +1,5 @@
 // hb_threads.h - how many host threads the OpenMP parts of the library should use.
-// omp_get_max_threads() reports the machine's hardware threads (256 on the MI355X boxes) even when a container's cgroup
+// omp_get_num_procs() reports the machine's hardware threads (256 on the MI355X boxes) even when a container's cgroup
 // lets the process run on far fewer CPUs at a time (16 there): 256 threads time-slicing 16 CPUs cost the store writer
 // and the column reader more than half their throughput.  HB_HOST_THREADS overrides.
 #pragma once
@@ -12,7 +12,9 @@ namespace hb {
 inline int host_threads()
 {
     static const int n = [] {
-        int hw = omp_get_max_threads();
+        // the machine's processors, NOT omp_get_max_threads(): that is a mutable setting another OpenMP user of the process
+        // (the CPU oracle's omp_set_num_threads in bench.py) may have left at 1 or 2
+        int hw = omp_get_num_procs();
         if (hw < 1) hw = 1;
         if (const char *e = std::getenv("HB_HOST_THREADS")) {
             const int v = std::atoi(e);

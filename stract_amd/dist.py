@@ -95,3 +95,102 @@ def torch_unique_id(rank, world):
 
 def make_context(rank, world, device, rccl_id, **kw):
     return _lib.Context(device=device, rank=rank, world_size=world, rccl_id=rccl_id, **kw)
+
+
+class HostStagedCollectives:
+    """hb_set_collectives over torch.distributed tensors in HOST memory (any backend that moves CPU tensors: gloo): every
+    exchange of the pass driver - all-reduce(max, u8) of the counters, the pipelined per-range form, the changed-only packing
+    with its all-gather of bitmaps and per-rank broadcasts, the destination partition's all-gathers, the all-gather of the
+    Kahan slices - runs as the LIBRARY's code, with N processes that may all sit on one device (RCCL refuses that).  Slow by
+    construction (device -> host -> wire -> host -> device, blocking); its purpose is correctness of the multi-process
+    protocol where only one GPU exists (tests/test_gpu.py), and as a template for integrators with their own fabric.
+
+    Keep the object alive as long as the context uses it (it owns the ctypes callbacks)."""
+
+    _ALL_REDUCE = __import__("ctypes").CFUNCTYPE(__import__("ctypes").c_int, __import__("ctypes").c_void_p, __import__("ctypes").c_void_p,
+                                                 __import__("ctypes").c_uint64, __import__("ctypes").c_int, __import__("ctypes").c_int,
+                                                 __import__("ctypes").c_void_p)
+    _ALL_GATHER = __import__("ctypes").CFUNCTYPE(__import__("ctypes").c_int, __import__("ctypes").c_void_p, __import__("ctypes").c_void_p,
+                                                 __import__("ctypes").c_void_p, __import__("ctypes").c_uint64, __import__("ctypes").c_void_p)
+    _BROADCAST = __import__("ctypes").CFUNCTYPE(__import__("ctypes").c_int, __import__("ctypes").c_void_p, __import__("ctypes").c_void_p,
+                                                __import__("ctypes").c_uint64, __import__("ctypes").c_int, __import__("ctypes").c_void_p)
+
+    def __init__(self, ctx, group=None):
+        import ctypes
+        import torch
+        import torch.distributed as td
+
+        self.td, self.torch, self.group = td, torch, group
+        self.world = td.get_world_size(group)
+        self.rank = td.get_rank(group)
+        self.lib = _lib.load()
+        self.calls = {"all_reduce": 0, "all_gather": 0, "broadcast": 0, "bytes": 0}
+        self.error = None
+        np_of = {_lib.HB_COLL_U8: np.uint8, _lib.HB_COLL_U32: np.uint32, _lib.HB_COLL_U64: np.uint64, _lib.HB_COLL_F64: np.float64}
+
+        def to_host(dptr, nbytes, stream):
+            host = np.empty(nbytes, dtype=np.uint8)
+            if self.lib.hb_debug_staged_copy(host.ctypes.data_as(ctypes.c_void_p), ctypes.c_void_p(dptr), nbytes, 0, ctypes.c_void_p(stream)) != _lib.HB_OK:
+                raise RuntimeError("device -> host copy failed")
+            return host
+
+        def to_device(dptr, host, stream):
+            host = np.ascontiguousarray(host)
+            if self.lib.hb_debug_staged_copy(ctypes.c_void_p(dptr), host.ctypes.data_as(ctypes.c_void_p), host.nbytes, 1, ctypes.c_void_p(stream)) != _lib.HB_OK:
+                raise RuntimeError("host -> device copy failed")
+
+        def guard(fn):
+            def wrapped(*a):
+                try:
+                    fn(*a)
+                    return 0
+                except Exception as e:  # never unwind into the C library
+                    self.error = repr(e)
+                    return 1
+            return wrapped
+
+        @guard
+        def all_reduce(user, buf, count, dtype, op, stream):
+            dt = np.dtype(np_of[dtype])
+            host = to_host(buf, count * dt.itemsize, stream).view(dt)
+            if dtype == _lib.HB_COLL_U8:
+                t = torch.from_numpy(host)                      # byte-wise max: the counters
+            elif dtype == _lib.HB_COLL_F64:
+                t = torch.from_numpy(host)
+            else:                                               # u32 / u64 sums: as int64 (two's complement wrap = unsigned wrap)
+                t = torch.from_numpy(host.astype(np.int64) if dtype == _lib.HB_COLL_U32 else host.view(np.int64))
+            td.all_reduce(t, op=td.ReduceOp.MAX if op == _lib.HB_COLL_MAX else td.ReduceOp.SUM, group=self.group)
+            out = t.numpy()
+            if dtype == _lib.HB_COLL_U32:
+                out = out.astype(np.uint32)
+            to_device(buf, out.view(np.uint8) if out.dtype != np.uint8 else out, stream)
+            self.calls["all_reduce"] += 1
+            self.calls["bytes"] += int(count * dt.itemsize)
+
+        @guard
+        def all_gather(user, send, recv, nbytes, stream):
+            mine = torch.from_numpy(to_host(send, nbytes, stream))
+            parts = [torch.empty(nbytes, dtype=torch.uint8) for _ in range(self.world)]
+            td.all_gather(parts, mine, group=self.group)
+            to_device(recv, torch.cat(parts).numpy(), stream)
+            self.calls["all_gather"] += 1
+            self.calls["bytes"] += int(nbytes * self.world)
+
+        @guard
+        def broadcast(user, buf, nbytes, root, stream):
+            t = torch.from_numpy(to_host(buf, nbytes, stream)) if self.rank == root else torch.empty(nbytes, dtype=torch.uint8)
+            td.broadcast(t, src=root, group=self.group)
+            if self.rank != root:
+                to_device(buf, t.numpy(), stream)
+            self.calls["broadcast"] += 1
+            self.calls["bytes"] += int(nbytes)
+
+        self._cb = (self._ALL_REDUCE(all_reduce), self._ALL_GATHER(all_gather), self._BROADCAST(broadcast))
+
+        class Ops(ctypes.Structure):
+            _fields_ = [("user", ctypes.c_void_p), ("all_reduce", self._ALL_REDUCE), ("all_gather", self._ALL_GATHER), ("broadcast", self._BROADCAST)]
+
+        self._ops = Ops(None, *self._cb)
+        rc = self.lib.hb_set_collectives(ctx.h, ctypes.byref(self._ops))
+        if rc != _lib.HB_OK:
+            raise _lib.HyperballError(rc, (self.lib.hb_last_error(ctx.h) or b"").decode())

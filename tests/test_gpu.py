@@ -874,3 +874,50 @@ def test_reference_two_shard_fixture(gpu_ctx_factory):
     finally:
         for c in ctxs:
             c.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,modes", [(2, "edge,edge_no_pipeline,edge_changed,dest,dest_changed"), (3, "edge,dest_changed")])
+def test_multi_process_library_exchanges_on_one_device(tmp_path, world, modes):
+    """N PROCESSES (torch.distributed.run, gloo) drive the library's multi-rank pass driver on ONE device; the
+    exchanges go through hb_set_collectives + stract_amd.dist.HostStagedCollectives (host-staged gloo tensors) in place of RCCL,
+    which refuses two ranks on one device.  Every decomposition must give the single-GPU result bit for bit; the counters
+    must be identical on all ranks; the callbacks must have carried the traffic (call counts)."""
+    import json
+    import socket
+    import subprocess
+    import sys
+
+    scale, m = 12, 40_000
+    sk = socket.socket()
+    sk.bind(("127.0.0.1", 0))
+    port = sk.getsockname()[1]
+    sk.close()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "tests", "dist_gpu_worker.py"), str(scale), str(m), str(tmp_path), modes]
+    r = subprocess.run(cmd, cwd=root, env=dict(os.environ, OMP_NUM_THREADS="2"), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    g = synth.RmatGraph(scale, m)
+    o = hbo.Dense(g.id_low64(), g.row_ptr, g.src)
+    T = o.run()
+    ovals, keep, k = o.finish()
+    want_bits = ovals[keep].view(np.uint64).tolist()
+    ranks = [json.load(open(os.path.join(str(tmp_path), "rank%d.json" % i))) for i in range(world)]
+    for mode in modes.split(","):
+        edges = 0
+        for i, z in enumerate(ranks):
+            z = z[mode]
+            assert z["callback_error"] is None, (mode, i, z["callback_error"])
+            assert z["passes"] == T and z["results"] == k, (mode, i, z["passes"], T)
+            assert z["same_counters_on_all_ranks"], (mode, i)
+            assert z["calls"]["all_reduce"] + z["calls"]["all_gather"] + z["calls"]["broadcast"] >= T, (mode, z["calls"])
+            edges += z["local_edges"]
+        assert edges == g.m, mode
+        assert ranks[0][mode]["vals_bits"] == want_bits, mode          # the final list, every f64 bit
+        if mode == "edge":   # the pipelined form: four all-reduces (row ranges) per pass + the out-degree histogram at load + Kahan slices
+            assert ranks[0][mode]["calls"]["all_reduce"] >= 4 * T, ranks[0][mode]["calls"]
+        if mode == "edge_no_pipeline":
+            assert T <= ranks[0][mode]["calls"]["all_reduce"] <= T + 2, ranks[0][mode]["calls"]
+        if mode.endswith("changed"):
+            assert ranks[0][mode]["calls"]["all_gather"] >= T, ranks[0][mode]["calls"]

@@ -202,6 +202,102 @@ static bool node_set_pipeline(const std::vector<u128> &c1, const std::vector<u12
     return ok;
 }
 
+__global__ void atomics_kernel(unsigned long long *sum, unsigned int *mx, unsigned int *cas, size_t n)
+{
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        atomicAdd(&sum[i & 63], (unsigned long long)i);
+        atomicMax(&mx[i & 63], (unsigned int)(i * 2654435761u));
+        atomicCAS(&cas[i & 1023], 0u, (unsigned int)i + 1u);
+    }
+}
+struct IsOdd {
+    __device__ bool operator()(uint64_t v) const { return v & 1; }
+};
+
+// exclusive_scan, inclusive_scan(max), select(flag iterator), reduce, and global atomics on guarded buffers vs the host
+static void scans_and_atomics()
+{
+    const size_t n = (5u << 20) + 7;
+    std::vector<uint64_t> h(n), want_ex(n), want_sel;
+    std::mt19937_64 rng(99);
+    uint64_t acc = 0, total = 0;
+    for (size_t i = 0; i < n; i++) {
+        h[i] = rng() & 0xFFFF;
+        want_ex[i] = acc;
+        acc += h[i];
+        if (h[i] & 1) want_sel.push_back(h[i]);
+        total += h[i];
+    }
+    uint64_t *d_in = nullptr, *d_out = nullptr, *d_n = nullptr;
+    void *tmp = nullptr;
+    hipStream_t s;
+    CK(hipStreamCreate(&s));
+    CK(hipMalloc((void **)&d_in, n * 8));
+    CK(hipMalloc((void **)&d_out, n * 8));
+    CK(hipMalloc((void **)&d_n, 8));
+    CK(hipMemcpyAsync(d_in, h.data(), n * 8, hipMemcpyHostToDevice, s));
+    size_t bytes = 0;
+    CK(rocprim::exclusive_scan(nullptr, bytes, d_in, d_out, (uint64_t)0, n, rocprim::plus<uint64_t>(), s));
+    CK(hipMalloc(&tmp, bytes + 3));
+    CK(rocprim::exclusive_scan(tmp, bytes, d_in, d_out, (uint64_t)0, n, rocprim::plus<uint64_t>(), s));
+    std::vector<uint64_t> got(n);
+    CK(hipMemcpyAsync(got.data(), d_out, n * 8, hipMemcpyDeviceToHost, s));
+    CK(hipStreamSynchronize(s));
+    report("rocPRIM exclusive_scan on guarded buffers == host", got == want_ex);
+    (void)hipFree(tmp);
+    bytes = 0;
+    CK(rocprim::select(nullptr, bytes, d_in, d_out, d_n, n, IsOdd(), s));
+    CK(hipMalloc(&tmp, bytes + 5));
+    CK(rocprim::select(tmp, bytes, d_in, d_out, d_n, n, IsOdd(), s));
+    uint64_t cnt = 0;
+    CK(hipMemcpyAsync(&cnt, d_n, 8, hipMemcpyDeviceToHost, s));
+    CK(hipStreamSynchronize(s));
+    got.assign(want_sel.size(), 0);
+    CK(hipMemcpyAsync(got.data(), d_out, std::min<size_t>(cnt, want_sel.size()) * 8, hipMemcpyDeviceToHost, s));
+    CK(hipStreamSynchronize(s));
+    report("rocPRIM select on guarded buffers == host", cnt == want_sel.size() && got == want_sel);
+    (void)hipFree(tmp);
+    bytes = 0;
+    CK(rocprim::reduce(nullptr, bytes, d_in, d_n, (uint64_t)0, n, rocprim::plus<uint64_t>(), s));
+    CK(hipMalloc(&tmp, bytes + 1));
+    CK(rocprim::reduce(tmp, bytes, d_in, d_n, (uint64_t)0, n, rocprim::plus<uint64_t>(), s));
+    CK(hipMemcpyAsync(&cnt, d_n, 8, hipMemcpyDeviceToHost, s));
+    CK(hipStreamSynchronize(s));
+    report("rocPRIM reduce on guarded buffers == host", cnt == total);
+    (void)hipFree(tmp);
+    // atomics
+    unsigned long long *d_sum = nullptr;
+    unsigned int *d_mx = nullptr, *d_cas = nullptr;
+    CK(hipMalloc((void **)&d_sum, 64 * 8));
+    CK(hipMalloc((void **)&d_mx, 64 * 4));
+    CK(hipMalloc((void **)&d_cas, 1024 * 4));
+    CK(hipMemsetAsync(d_sum, 0, 64 * 8, s));
+    CK(hipMemsetAsync(d_mx, 0, 64 * 4, s));
+    CK(hipMemsetAsync(d_cas, 0, 1024 * 4, s));
+    const size_t na = 1u << 22;
+    hipLaunchKernelGGL(atomics_kernel, dim3(1024), dim3(256), 0, s, d_sum, d_mx, d_cas, na);
+    unsigned long long hs[64];
+    unsigned int hm[64], hc[1024];
+    CK(hipMemcpyAsync(hs, d_sum, sizeof(hs), hipMemcpyDeviceToHost, s));
+    CK(hipMemcpyAsync(hm, d_mx, sizeof(hm), hipMemcpyDeviceToHost, s));
+    CK(hipMemcpyAsync(hc, d_cas, sizeof(hc), hipMemcpyDeviceToHost, s));
+    CK(hipStreamSynchronize(s));
+    bool ok = true;
+    for (int k = 0; k < 64; k++) {
+        unsigned long long ws = 0;
+        unsigned int wm = 0;
+        for (size_t i = k; i < na; i += 64) {
+            ws += i;
+            wm = std::max(wm, (unsigned int)(i * 2654435761u));
+        }
+        ok = ok && hs[k] == ws && hm[k] == wm;
+    }
+    for (int k = 0; k < 1024; k++) ok = ok && hc[k] != 0 && ((hc[k] - 1) & 1023) == (unsigned)k;
+    report("global atomicAdd(u64) / atomicMax / atomicCAS on guarded buffers == host", ok);
+    for (void *p : {(void *)d_in, (void *)d_out, (void *)d_n, (void *)d_sum, (void *)d_mx, (void *)d_cas}) (void)hipFree(p);
+    CK(hipStreamDestroy(s));
+}
+
 int main()
 {
     CK((hipMalloc)((void **)&d_bad, 8));
@@ -250,6 +346,7 @@ int main()
     report(HB_GUARD_COPIES ? "rocPRIM pipeline on GUARDED buffers, runtime copies/fills replaced by kernels == host result"
                            : "rocPRIM pipeline on GUARDED buffers, runtime copies/fills as they are == host result",
            ok && got_guard == expect, extra);
+    scans_and_atomics();
     std::printf("%d check(s) failed\n", g_fail);
     return g_fail;
 }
