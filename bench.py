@@ -14,8 +14,10 @@ torch.distributed.run, one rank per GPU).  Prints ONE JSON line on rank 0.
               it says little about HBM), C4 = configs[3], C5 = configs[4], LT = the long-tail graph.
   input     = N = 1: the graph enters through the drop-in boundary - raw 40-byte SmallEdge records (with
               flagged-first pairs and duplicates, a stream the reference semantics reduce to exactly the
-              clean graph) streamed through hb_append_edges + hb_finalize (detail.input: records/s,
-              link rate, peak device bytes); --input dense = the bench-only hb_load_dense export.
+              clean graph) streamed from a page-locked batch buffer (hb_pinned_alloc) through hb_append_edges +
+              hb_finalize (detail.input: records/s, link rate, peak device bytes); --input dense = the bench-only
+              hb_load_dense export.  PyTorch is imported for N > 1 only (torch.distributed); at N = 1 the process
+              holds no torch and the library runs on /opt/rocm's HIP runtime.
   N > 1     = the same graph partitioned over the ranks (strong scaling), one RCCL collective of
               the counters per pass.  `value` = the north-star decomposition: edge
               partition + ncclAllReduce(max, u8); with --partition both (default) its changed-only form, the
@@ -23,6 +25,12 @@ torch.distributed.run, one rank per GPU).  Prints ONE JSON line on rank 0.
               detail.partitions, each with GTEPS, ms_collective, wire bytes and a same-result field.
   c4 leg    = with the default config at N = 1 the line also carries detail.c4: BASELINE configs[3]
               (100M hosts / 2B edges) on one GPU - GTEPS, roofline fractions, parity (~2-3 min).
+  end to end= N = 1, record input (default): detail.end_to_end (and detail.c4.end_to_end) = the reference command's whole chain
+              on the same graph (entrypoint/centrality.rs:41-71): an on-disk edge store (written by the harness, untimed) ->
+              hb_load_webgraph (CRC-32 checked, native column reader, GPU ingest) -> hb_run -> hb_result_copy + hb_result_ranks
+              -> hb_store_harmonic (both speedy_kv databases), seconds per stage, records/s of the load, entries/s of the
+              store emission, compute share of the total, and three checks (graph = clean graph, result = the record leg's,
+              a sample of keys read back from the written databases); a failed check makes the exit code non-zero.
   roofline  = SURVEY.md §8(d): HBM-bound.  Headline `achieved`/`frac` = the WHOLE generic dense pass
               (dense passes t >= 1: B_t with their own A_t) over its measured GPU time (HIP events on
               the library's stream) vs 8 TB/s.  Pass 0 (68*m_eff + 192.25*n algorithmic bytes) is
@@ -619,6 +627,8 @@ def c4_leg(a):
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
         env.pop(k, None)
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=3000, env=env, preexec_fn=_die_with_parent)
+    if r.stderr:
+        sys.stderr.write("---- stderr of the C4 leg ----\n" + r.stderr[-20000:] + "\n---- end of the C4 leg ----\n")
     line = next((ln for ln in reversed(r.stdout.splitlines()) if ln.startswith("{")), None)
     if r.returncode != 0 or line is None:
         return {"error": "child exited with %d: %s" % (r.returncode, (r.stderr or "")[-300:])}

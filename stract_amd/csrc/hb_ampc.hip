@@ -1,6 +1,7 @@
 // hb_ampc.hip - GPU-resident shard of the AMPC counter table with HyperLogLog64Upsert semantics
 // (include/hb_ampc.h cites the reference operations this serves).
 #include "hb_guard_alloc.h" // FIRST: no-op unless built with -DHB_GUARD_ALLOC=<mode> (debug allocators: guard pages / poison / red zones)
+#include "hb_pool.h"        // then: every hipMalloc / hipFree below goes through the caching device allocator (shipped build)
 #include <hip/hip_runtime.h>
 
 #include <algorithm>

@@ -5,6 +5,7 @@
 // Host orchestration only: every arithmetic step of the path runs in the gfx950 kernels
 // of hb_kernels.hip.h.  There is no CPU fallback.
 #include "hb_guard_alloc.h" // FIRST: no-op unless built with -DHB_GUARD_ALLOC=<mode> (debug allocators: guard pages / poison / red zones)
+#include "hb_pool.h"        // then: every hipMalloc / hipFree below goes through the caching device allocator (shipped build)
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
@@ -489,6 +490,9 @@ int hb_create(const hb_options *opt, hb_ctx **out)
 void hb_destroy(hb_ctx *ctx)
 {
     if (!ctx) return;
+    struct Trim { // after everything below has gone back to the caching allocator: free blocks return to the runtime
+        ~Trim() { HB_POOL_TRIM(); }
+    } trim_at_exit;
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     if (ctx->comm) (void)ncclCommDestroy(ctx->comm);
@@ -544,7 +548,7 @@ int hb_load_edges(hb_ctx *c, const hb_u128 *node_ids, uint64_t n, const hb_edge 
             size_t free_b = 0, total_b = 0;
             // held: 9 B per record + the endpoint table; sort: 16 B per record; ~60 B per node while the ids are sorted
             const double need = 18.0 * (double)m + 48.0 * (double)((node_ids && n) ? n : 0) + 1024e6;
-            if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && need > (double)free_b) on_host = true;
+            if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && need > (double)free_b + (double)HB_POOL_CACHED_FREE()) on_host = true;
         }
         DeviceCsr csr;
         const bool keep_on_device = !on_host && device_plan(c);
@@ -618,10 +622,12 @@ int hb_finalize(hb_ctx *c, const hb_u128 *node_ids, uint64_t n)
         }
         c->stats = hb_stats{};
         const double t0 = now_ms();
+        const bool trace = std::getenv("HB_TRACE_INGEST") != nullptr;
         DeviceCsr csr;
         const bool keep_on_device = device_plan(c);
         uint64_t peak = 0;
         const std::string e = gpu_ingest_reduce((void *)c->stream, node_ids, n, &c->app, &c->g, keep_on_device ? &csr : nullptr, &peak);
+        if (trace) std::fprintf(stderr, "[hb finalize] gpu_ingest_reduce returned after %.1f ms\n", now_ms() - t0);
         if (!e.empty())
             return fail(c, e.find("memory") != std::string::npos ? HB_ERR_NOMEM : (e.find("hip") != std::string::npos ? HB_ERR_HIP : HB_ERR_LIMIT), e);
         if ((rc = keep_owned(c, &csr))) {
@@ -637,6 +643,7 @@ int hb_finalize(hb_ctx *c, const hb_u128 *node_ids, uint64_t n)
         if (csr.d_src) (void)hipFree(csr.d_src);
         c->stats.ms_ingest = ing;
         c->stats.ingest_peak_bytes = peak;
+        if (trace) std::fprintf(stderr, "[hb finalize] done after %.1f ms (plan %.1f ms, state %.1f ms)\n", now_ms() - t0, c->stats.ms_plan, c->stats.ms_h2d);
         return rc;
     });
 }

@@ -22,6 +22,7 @@
 //   memory    9 B per record while the stream is held, 16-17 B per record during the sort, + 20 B per table slot
 //             (load factor <= 1/2) and 40 B per node while the ids are sorted.
 #include "hb_guard_alloc.h" // FIRST: no-op unless built with -DHB_GUARD_ALLOC=<mode> (debug allocators: guard pages / poison / red zones)
+#include "hb_pool.h"        // then: every hipMalloc / hipFree below goes through the caching device allocator (shipped build)
 #include <hip/hip_runtime.h>
 
 #include <cstring>
@@ -372,8 +373,8 @@ std::string read_npid(hipStream_t stream, IngestStream *st)
 // is only known exactly after a synchronisation, so the test runs on an upper bound (keys at the last read-back + 2 per
 // record launched since) and synchronises only when that bound says the table might be too small.
 // "... out of memory" when the (larger) table cannot be allocated or the debug byte limit forbids it.
-template <class Poll>
-std::string table_reserve(hipStream_t stream, IngestStream *st, uint64_t incoming, Poll &&poll)
+template <class Poll, class WaitOldest>
+std::string table_reserve(hipStream_t stream, IngestStream *st, uint64_t incoming, Poll &&poll, WaitOldest &&wait_oldest)
 {
     if (!st->d_counter) {
         IG_HIP(hipMalloc((void **)&st->d_counter, 256));
@@ -387,6 +388,11 @@ std::string table_reserve(hipStream_t stream, IngestStream *st, uint64_t incomin
         poll(); // snapshots behind the slabs that have completed (non-blocking)
         st->trace_polls++;
         st->trace_ms_poll += now_ms() - t0;
+        if (fits(st->tab_slots)) return "";
+        // wait for the OLDER of the two slabs in flight only (its kernel is usually done, the newer one keeps the device busy),
+        // take its snapshot; draining the whole pipe (read_npid) is the last resort
+        wait_oldest();
+        poll();
         if (fits(st->tab_slots)) return "";
         const double t1 = now_ms();
         const std::string e = read_npid(stream, st);
@@ -444,6 +450,7 @@ std::string gpu_ingest_append(void *stream_v, IngestStream *st, const hb_edge *e
 {
     hipStream_t stream = (hipStream_t)stream_v;
     if (!m) return "";
+    if (!st->count && st->chunks.empty()) HB_POOL_RESET_PEAK(); // a new stream: its high-water mark starts here
     if (st->max_records && st->count + m >= st->max_records) return "too many records for the device ingest: use HB_FLAG_HOST_INGEST";
     // 1 Mi records = 40 MiB per slab, two slabs in flight: large enough for the link's full rate (55 GB/s from 16 MiB up,
     // profiles/r04a_h2d_probe.txt), small enough that "every record in flight may bring two new ids" stays a small reserve
@@ -530,8 +537,10 @@ std::string gpu_ingest_append(void *stream_v, IngestStream *st, const hb_edge *e
         const double t_a = now_ms();
         if (st->chunks.empty() || st->chunks.back().count == st->chunks.back().cap) {
             IngestChunk c;
+            // capacity: at least this batch, and as much as the stream already holds (doubling), up to chunk_records - few
+            // large blocks, which the caching allocator can hand to later large requests, instead of one block per batch
             uint64_t cap = 1ull << 20;
-            while (cap < m - off && cap < chunk_records) cap <<= 1;
+            while (cap < std::max(m - off, st->count) && cap < chunk_records) cap <<= 1;
             c.cap = std::min(cap, chunk_records);
             const uint64_t add = c.cap * 9;
             if ((st->max_bytes && st->bytes + add > st->max_bytes) || hipMalloc((void **)&c.d_pair, c.cap * 8) != hipSuccess) {
@@ -551,7 +560,10 @@ std::string gpu_ingest_append(void *stream_v, IngestStream *st, const hb_edge *e
         const uint64_t cnt = std::min(std::min(slab, m - off), c.cap - c.count);
         const double t_b = now_ms();
         {
-            const std::string e = table_reserve(kstream, st, cnt, poll_snapshots); // (all table work lives on the ingest's stream)
+            auto wait_oldest = [&]() {
+                if (snap_pending[b]) (void)hipEventSynchronize(evs.consumed[b]); // buffer b is the one about to be reused: its slab is the older one
+            };
+            const std::string e = table_reserve(kstream, st, cnt, poll_snapshots, wait_oldest); // (all table work lives on the ingest's stream)
             if (!e.empty()) {
                 undo();
                 return e;
@@ -696,7 +708,7 @@ std::string gpu_ingest_reduce(void *stream_v, const hb_u128 *node_ids, uint64_t 
         uint64_t *out;
         ~Peak()
         {
-            if (out) *out = std::max<uint64_t>(mem.peak, st->peak_bytes);
+            if (out) *out = std::max<uint64_t>(std::max<uint64_t>(mem.peak, st->peak_bytes), (uint64_t)HB_POOL_PEAK()); // live bytes, or what the pool held
         }
     } peak_guard{mem, st, peak_bytes};
     for (void *&p : st->d_slab) { // the staging buffers are no longer needed
@@ -807,9 +819,10 @@ std::string gpu_ingest_reduce(void *stream_v, const hb_u128 *node_ids, uint64_t 
     }
     lap("node set, sid of every pid");
     if (n >= (1ull << 30)) return "too many nodes (n must be < 2^30)";
+    const bool small_graph = !keep || m <= kKeepHostGraph; // (m_eff <= m: the host copy of the CSR is only made for small graphs)
     try {
         out->ids.resize(n);
-        out->row_ptr.assign(n + 1, 0);
+        if (small_graph || n == 0 || m == 0) out->row_ptr.assign(n + 1, 0);
     } catch (const std::bad_alloc &) {
         return "out of host memory for the node set";
     }
@@ -922,6 +935,7 @@ std::string gpu_ingest_reduce(void *stream_v, const hb_u128 *node_ids, uint64_t 
     const bool to_host = !keep || m_eff <= kKeepHostGraph;
     if (to_host) {
         try {
+            out->row_ptr.assign(n + 1, 0);
             out->src.resize(m_eff);
         } catch (const std::bad_alloc &) {
             return "out of host memory for the edge set";

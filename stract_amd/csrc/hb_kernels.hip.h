@@ -44,35 +44,19 @@ __device__ unsigned int g_dbg_line = 0;
 #define HB_DBG_ASSERT(cond) ((void)0)
 #endif
 
-// Streams that are read or written exactly once per pass (row pointers, source indices, per-row Kahan / size
-// words, the freshly written counters): with HB_STREAM_NT they bypass-hint the caches (nontemporal), leaving the
-// L2 to the gathered counters.  Experiment switch, see profiles/r02*_stream_nt*.
-#ifndef HB_STREAM_NT
-#define HB_STREAM_NT 0
-#endif
+// Streams that are read or written exactly once per pass (row pointers, source indices, per-row Kahan / size words, the
+// freshly written counters) go through these two helpers.  A non-temporal variant of them (cache-bypass hints, leaving
+// the L2 to the gathered counters) was measured in rounds 2 and 3 and lost (dense pass 2.96 -> 3.04 ms at C3; DESIGN.md
+// "tried and rejected"); the switch is gone, the helpers stay as the one place such a hint would go.
 template <class T>
 __device__ __forceinline__ T ld_stream(const T *p)
 {
-#if HB_STREAM_NT
-    return __builtin_nontemporal_load(p);
-#else
     return *p;
-#endif
 }
 template <class T>
 __device__ __forceinline__ void st_stream(T *p, const T &v)
 {
     *p = v;
-}
-__device__ __forceinline__ void st_stream(uint4 *p, const uint4 &v)
-{
-#if HB_STREAM_NT
-    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-    u32x4 w = {v.x, v.y, v.z, v.w};
-    __builtin_nontemporal_store(w, (u32x4 *)p);
-#else
-    *p = v;
-#endif
 }
 // Per-pass counters are striped: kStripes copies of 4 words, a block adds to stripe blockIdx % kStripes
 // (one same-address atomic stream sustains only ~90 updates/us; 8192 waves finishing together made a
