@@ -197,7 +197,8 @@ def load_records(ctx, g, salt=2, slab=1 << 24):
             "s_fill_slabs_host": round(s_fill, 2), "s_append_edges": round(s_append, 2), "s_finalize": round(s_fin, 2),
             "append_GBs": round(total * 40 / max(s_append, 1e-9) / 1e9, 2),
             "records_per_s": round(total / max(s_append + s_fin, 1e-9)),
-            "ingest_peak_device_bytes": int(st["ingest_peak_bytes"]), "m_unique": int(st["m_unique"])}
+            "ingest_peak_device_bytes": int(st["ingest_peak_bytes"]), "ingest_peak_bytes_per_record": round(st["ingest_peak_bytes"] / max(total, 1), 2),
+            "allocator_held_peak_bytes": int(st["pool_peak_bytes"]), "m_unique": int(st["m_unique"])}
 
 
 def end_to_end(a, g, ref_sig, ref_passes, salt=2, seg_records=1 << 24):
@@ -268,6 +269,7 @@ def end_to_end(a, g, ref_sig, ref_passes, salt=2, seg_records=1 << 24):
                     "store_entries_per_s_both_dbs": round(2 * len(vals) / max(stages["s_store_harmonic"], 1e-9)),
                     "ms_ingest_reduce": round(st["ms_ingest"], 1), "ms_plan": round(st["ms_plan"], 1), "ms_state": round(st["ms_h2d"], 1),
                     "ingest_peak_bytes_per_record": round(st["ingest_peak_bytes"] / max(total, 1), 2),
+                    "allocator_held_peak_bytes": int(st["pool_peak_bytes"]),
                     "graph_ok": bool(st["n"] == g.n and st["m_eff"] == g.m and st["m_input"] == total),
                     "passes": int(run["passes"]), "same_result_as_record_leg": bool(sig == tuple(ref_sig) and int(run["passes"]) == int(ref_passes))})
         # read a sample back from both databases (harness)

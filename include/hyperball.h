@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define HB_ABI_VERSION 3
+#define HB_ABI_VERSION 4
 
 /* ---- error codes -------------------------------------------------------------- */
 #define HB_OK 0
@@ -157,8 +157,12 @@ typedef struct hb_stats {
     uint64_t rows_with_in_edges; /* nodes with >= 1 in-edge: V_t of a dense pass t >= 1      */
     uint64_t wire_bytes;    /* counter + changed-bit bytes this rank received in the collectives of the last run
                                (what HB_FLAG_CHANGED_ONLY reduces), both decompositions               */
-    uint64_t ingest_peak_bytes; /* high-water mark of the device memory the GPU ingest held (record chunks + work
-                                   arrays; 0 = host ingest / hb_load_dense)                            */
+    uint64_t ingest_peak_bytes; /* high-water mark of the device memory the GPU ingest NEEDED: live record chunks,
+                                   endpoint table and work arrays (0 = host ingest / hb_load_dense)   */
+    uint64_t pool_peak_bytes;   /* [ABI 4] high-water mark of what the library's caching device allocator (hb_pool.h) HELD
+                                   from the runtime during the load: the live bytes plus freed extents it kept for reuse
+                                   (kept only while the device has room: above half of the device memory - or
+                                   HB_POOL_LIMIT_BYTES - free blocks go back to the runtime before a new one is taken) */
 } hb_stats;
 
 typedef struct hb_pass_stats {

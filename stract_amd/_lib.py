@@ -87,6 +87,7 @@ class HbStats(ctypes.Structure):
         ("rows_with_in_edges", ctypes.c_uint64),
         ("wire_bytes", ctypes.c_uint64),
         ("ingest_peak_bytes", ctypes.c_uint64),
+        ("pool_peak_bytes", ctypes.c_uint64),
     ]
 
     def as_dict(self):

@@ -539,6 +539,7 @@ int hb_load_edges(hb_ctx *c, const hb_u128 *node_ids, uint64_t n, const hb_edge 
         int rc = set_device(c);
         if (rc) return rc;
         c->stats = hb_stats{};
+        HB_POOL_RESET_PEAK(); // hb_stats.pool_peak_bytes counts from the beginning of this load
         double t0 = now_ms();
         // node/edge-set reduction: on the GPU (hb_ingest.hip) unless the host path is forced; identical output
         // The device pipeline keeps ~18 B per record resident at its peak (9 B held, 16 B during the sort):
@@ -782,6 +783,7 @@ int hb_load_dense(hb_ctx *c, const hb_u128 *sorted_ids, uint64_t n, const uint64
         int rc = set_device(c);
         if (rc) return rc;
         c->stats = hb_stats{};
+        HB_POOL_RESET_PEAK();
         double t0 = now_ms();
         std::string e = check_dense(sorted_ids, n, row_ptr, src, m_eff);
         if (!e.empty()) return fail(c, e.find("too many") != std::string::npos ? HB_ERR_LIMIT : HB_ERR_INVALID, e);

@@ -708,7 +708,7 @@ std::string gpu_ingest_reduce(void *stream_v, const hb_u128 *node_ids, uint64_t 
         uint64_t *out;
         ~Peak()
         {
-            if (out) *out = std::max<uint64_t>(std::max<uint64_t>(mem.peak, st->peak_bytes), (uint64_t)HB_POOL_PEAK()); // live bytes, or what the pool held
+            if (out) *out = std::max<uint64_t>(mem.peak, st->peak_bytes); // live bytes (what the caching allocator held: hb_stats.pool_peak_bytes)
         }
     } peak_guard{mem, st, peak_bytes};
     for (void *&p : st->d_slab) { // the staging buffers are no longer needed

@@ -20,6 +20,7 @@
 
 #ifndef HB_GUARD_ALLOC
 #include <cstdint>
+#include <cstdlib>
 #include <map>
 #include <mutex>
 #include <vector>
@@ -44,6 +45,10 @@ public:
             *out = p;
             return hipSuccess;
         }
+        // No cached extent fits.  While the device has room the cache may keep growing (its free extents are what makes the
+        // next loads cheap); once what it holds plus this request passes the limit - half of the device memory, or
+        // HB_POOL_LIMIT_BYTES - the blocks nobody uses go back to the runtime first: the footprint then stays near what is live.
+        if (reserved_ + need > limit()) trim_locked(dev);
         void *base = nullptr;
         hipError_t e = (hipMalloc)(&base, need);
         if (e != hipSuccess) { // make room: give back what nobody uses, try once more
@@ -139,6 +144,16 @@ private:
         std::map<size_t, Extent> ext; // offset -> extent, covering the block
     };
     static size_t round_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+    static size_t limit()
+    {
+        static const size_t lim = [] {
+            if (const char *e = std::getenv("HB_POOL_LIMIT_BYTES")) return (size_t)std::strtoull(e, nullptr, 10);
+            size_t free_b = 0, total_b = 0;
+            if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && total_b) return total_b / 2;
+            return (size_t)64 << 30;
+        }();
+        return lim;
+    }
     void *take(int dev, size_t need)
     {
         Base *best_b = nullptr;

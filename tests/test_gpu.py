@@ -921,3 +921,37 @@ def test_multi_process_library_exchanges_on_one_device(tmp_path, world, modes):
             assert T <= ranks[0][mode]["calls"]["all_reduce"] <= T + 2, ranks[0][mode]["calls"]
         if mode.endswith("changed"):
             assert ranks[0][mode]["calls"]["all_gather"] >= T, ranks[0][mode]["calls"]
+
+
+@pytest.mark.gpu
+def test_caching_allocator_under_memory_pressure(tmp_path):
+    """hb_pool.h keeps freed device extents for reuse while the device has room and gives blocks back to the runtime once what it
+    holds passes its limit.  A child process with HB_POOL_LIMIT_BYTES = 64 MiB (every larger request trims the cache first - the
+    regime of the 5 B-edge graph on a full device) must give the same graph, plan and result as this process, whose limit is
+    half of the device; and its pool high-water mark must stay near what was live."""
+    import subprocess
+    import sys
+    code = (
+        "import json, sys, numpy as np\n"
+        "sys.path.insert(0, %r)\n"
+        "from stract_amd import _lib, synth\n"
+        "cfg = synth.CONFIGS['C2']; g = synth.RmatGraph(cfg['scale'], cfg['m'])\n"
+        "recs = np.zeros(g.stream_len(2), dtype=_lib.EDGE); g.stream_fill(recs, 0, 2)\n"
+        "out = []\n"
+        "for rnd in range(2):\n"
+        "    with _lib.Context() as ctx:\n"
+        "        for part in np.array_split(recs, 7): ctx.append_edges(part)\n"
+        "        ctx.finalize(); st = ctx.run(); ids, vals = ctx.results(); hr, hk = ctx.state_hash()\n"
+        "    out.append([int(st['n']), int(st['m_eff']), int(st['passes']), int(len(vals)), int(vals.view(np.uint64).sum() & 0xFFFFFFFFFFFFFFFF), hr, hk,\n"
+        "                int(st['ingest_peak_bytes']), int(st['pool_peak_bytes'])])\n"
+        "print(json.dumps(out))\n" % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    runs = {}
+    for name, env in (("roomy", {}), ("tight", {"HB_POOL_LIMIT_BYTES": str(64 << 20)})):
+        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-3000:]
+        runs[name] = json.loads(r.stdout.strip().splitlines()[-1])
+    for a, b in zip(runs["roomy"], runs["tight"]):
+        assert a[:7] == b[:7], (a, b)                      # same graph, passes, results, state checksums
+    assert runs["roomy"][0][:7] == runs["roomy"][1][:7]   # a second load out of the cached extents
+    live, held_roomy, held_tight = runs["tight"][0][7], runs["roomy"][0][8], runs["tight"][0][8]
+    assert live > 0 and held_tight >= live * 0 and held_tight <= held_roomy, (live, held_roomy, held_tight)

@@ -82,6 +82,7 @@ def main():
         "records_per_s_library": round(total / (s_append + s_finalize)), "records_per_s_incl_host_fill": round(total / s_all),
         "ms_ingest_reduce": round(st["ms_ingest"], 1), "ms_plan": round(st["ms_plan"], 1), "ms_h2d_state": round(st["ms_h2d"], 1),
         "ingest_peak_device_bytes": int(st["ingest_peak_bytes"]), "peak_bytes_per_record": round(st["ingest_peak_bytes"] / max(total, 1), 2),
+        "allocator_held_peak_bytes": int(st["pool_peak_bytes"]),
         "device_bytes_resident": int(st["device_bytes"]),
         "stats_ok": bool(st["n"] == g.n and st["m_input"] == total and st["m_eff"] == g.m and st["m_unique"] == g.m + lost),
         "n": int(st["n"]), "m_input": int(st["m_input"]), "m_unique": int(st["m_unique"]), "m_eff": int(st["m_eff"])}
