@@ -218,6 +218,9 @@ int hb_load_edges(hb_ctx *ctx, const hb_u128 *node_ids, uint64_t n, const hb_edg
  * memory (hipHostMalloc / hipHostRegister) cross the link asynchronously at its full rate. */
 int hb_append_edges(hb_ctx *ctx, const hb_edge *edges, uint64_t m);
 int hb_finalize(hb_ctx *ctx, const hb_u128 *node_ids, uint64_t n);
+/* Drops the batches appended since the last hb_finalize (device chunks, endpoint table, host buffer): the stream starts
+ * empty again.  For callers that find out mid-stream that their source is damaged (hb_load_webgraph on a CRC mismatch). */
+int hb_discard_appended(hb_ctx *ctx);
 
 /* HB_FLAG_REFERENCE_TAIL only; after the graph is loaded, before hb_begin / hb_run.  records = the store's page-level
  * (from_id, to_id, rel_flags) documents, SEGMENT BY SEGMENT IN DOC ORDER (sort_score ascending, store.rs:67-72) - the

@@ -125,6 +125,7 @@ _SIGNATURES = [
     ("hb_load_edges", ctypes.c_int, [_P, _P, _U64, _P, _U64]),
     ("hb_append_edges", ctypes.c_int, [_P, _P, _U64]),
     ("hb_finalize", ctypes.c_int, [_P, _P, _U64]),
+    ("hb_discard_appended", ctypes.c_int, [_P]),
     ("hb_load_tail_edges", ctypes.c_int, [_P, _P, _U64]),
     ("hb_append_tail_edges", ctypes.c_int, [_P, _P, _U64]),
     ("hb_tail_segment_end", ctypes.c_int, [_P]),

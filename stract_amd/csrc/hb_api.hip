@@ -649,6 +649,19 @@ int hb_finalize(hb_ctx *c, const hb_u128 *node_ids, uint64_t n)
     });
 }
 
+int hb_discard_appended(hb_ctx *c)
+{
+    return guarded(c, [&]() -> int {
+        if (!c) return HB_ERR_INVALID;
+        int rc = set_device(c);
+        if (rc) return rc;
+        HB_HIP(hipStreamSynchronize(c->stream));
+        c->app.free_all();
+        std::vector<hb_edge>().swap(c->pending);
+        return HB_OK;
+    });
+}
+
 int hb_set_collectives(hb_ctx *c, const hb_collectives *ops)
 {
     return guarded(c, [&]() -> int {

@@ -406,6 +406,9 @@ struct Segment {
     const uint8_t *page_from = nullptr, *page_to = nullptr;         // `from_id` / `to_id` (HBW_PAGE_IDS)
     uint64_t num_rows = 0;
     uint64_t first = 0; // stream position of its first document
+    uint64_t body_len = 0;   // bytes the directory footer's CRC-32 covers
+    uint64_t crc_want = 0;   // ... and its value (crc_known: the footer carries one)
+    bool crc_known = false;
 };
 
 // column bytes -> raw value array (column/serialize.rs:27-59)
@@ -452,12 +455,16 @@ std::string open_segment(const std::string &dir, uint32_t flags, Segment *s)
     if (magic != 1337) return path + ": footer magic mismatch";
     if (json_len > 50000 || (uint64_t)json_len + 8 > file.n) return path + ": footer length out of range";
     Bytes body = file.sub(0, file.n - 8 - json_len);
-    if (flags & HBW_VERIFY_CRC) {
+    {
         const std::string js((const char *)file.p + body.n, json_len);
         const size_t at = js.find("\"crc\":");
-        if (at == std::string::npos) return path + ": footer without crc";
-        const uint64_t want = std::strtoull(js.c_str() + at + 6, nullptr, 10);
-        if ((uint64_t)crc32_ieee_parallel(body.p, body.n) != want) return path + ": CRC mismatch";
+        s->body_len = body.n;
+        s->crc_known = at != std::string::npos;
+        if (s->crc_known) s->crc_want = std::strtoull(js.c_str() + at + 6, nullptr, 10);
+    }
+    if (flags & HBW_VERIFY_CRC) {
+        if (!s->crc_known) return path + ": footer without crc";
+        if ((uint64_t)crc32_ieee_parallel(body.p, body.n) != s->crc_want) return path + ": CRC mismatch";
     }
     // columnar footer (reader/mod.rs:85-103): [column data][sstable][sstable_len u64][num_rows u32][version u32][magic 4]
     if (body.n < 20) return path + ": columnar body too small";
@@ -636,7 +643,10 @@ int hb_load_webgraph(hb_ctx *ctx, const char *edges_dir, uint32_t flags)
     const bool trace = std::getenv("HB_TRACE_INGEST") != nullptr; // where the time of this call goes, on stderr
     const auto t_begin = std::chrono::steady_clock::now();
     auto since = [](std::chrono::steady_clock::time_point t0) { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); };
-    int rc = hbw_open(edges_dir, flags, &raw);
+    // HBW_VERIFY_CRC: the files are NOT checked in a pass of their own here (hbw_open does that for its direct users) - the
+    // check runs on a second thread WHILE the records stream to the device (the column bytes are read once, the cores idle
+    // while the device reduces); its verdict is taken before hb_finalize, a mismatch discards what was appended
+    int rc = hbw_open(edges_dir, flags & ~(uint32_t)HBW_VERIFY_CRC, &raw);
     if (rc != HB_OK) return rc; // message: hbw_last_error(NULL)
     const double s_open = since(t_begin);
     std::unique_ptr<hbw_reader, void (*)(hbw_reader *)> guard(raw, hbw_close); // closed on every path, exceptions included
@@ -678,6 +688,27 @@ int hb_load_webgraph(hb_ctx *ctx, const char *edges_dir, uint32_t flags)
         int rd_rc = HB_OK;
         bool stop = false;
         double s_gather = 0, s_append = 0, s_wait = 0; // reader thread busy / this thread in hb_append_edges / waiting for a slab
+        std::string crc_error;
+        double s_crc = 0;
+        std::thread checker;
+        if (flags & HBW_VERIFY_CRC)
+            checker = std::thread([&]() {
+                const auto t_c = std::chrono::steady_clock::now();
+                for (const Segment &sg : r->segs) {
+                    if (!crc_error.empty()) break;
+                    const std::string path = r->dir + "/" + sg.meta.uuid + ".col";
+                    if (!sg.crc_known) crc_error = path + ": footer without crc";
+                    else if ((uint64_t)crc32_ieee_parallel((const uint8_t *)sg.map, sg.body_len) != sg.crc_want) crc_error = path + ": CRC mismatch";
+                }
+                s_crc = since(t_c);
+            });
+        struct JoinChecker {
+            std::thread &t;
+            ~JoinChecker()
+            {
+                if (t.joinable()) t.join();
+            }
+        } join_checker{checker};
         std::thread producer([&]() {
             for (uint64_t k = 0; k < nslabs; k++) {
                 {
@@ -723,13 +754,20 @@ int hb_load_webgraph(hb_ctx *ctx, const char *edges_dir, uint32_t flags)
         }
         cv.notify_all();
         producer.join();
+        if (checker.joinable()) checker.join();
+        if (rc2 == HB_OK && !crc_error.empty()) { // a damaged file: nothing of it may become a graph
+            (void)hb_discard_appended(ctx);
+            r->err = crc_error;
+            g_open_error = crc_error;
+            return HB_ERR_INVALID;
+        }
         const auto t_f = std::chrono::steady_clock::now();
         if (rc2 == HB_OK) rc2 = hb_finalize(ctx, nullptr, 0); // node set = all endpoints = host_nodes() (store.rs:338-357)
         if (trace)
-            std::fprintf(stderr, "[hb webgraph] %llu records in %zu segments: open%s %.3f s; %llu slabs: reader thread gathering %.3f s, this thread waiting "
-                                 "for a slab %.3f s, in hb_append_edges %.3f s; hb_finalize %.3f s; total %.3f s\n", (unsigned long long)r->total, r->segs.size(),
-                         (flags & HBW_VERIFY_CRC) ? " + CRC-32 of every file" : "", s_open, (unsigned long long)nslabs, s_gather, s_wait, s_append, since(t_f),
-                         since(t_begin));
+            std::fprintf(stderr, "[hb webgraph] %llu records in %zu segments: open %.3f s; %llu slabs: reader thread gathering %.3f s, this thread waiting "
+                                 "for a slab %.3f s, in hb_append_edges %.3f s; CRC-32 of every file on a second thread %.3f s; hb_finalize %.3f s; total "
+                                 "%.3f s\n", (unsigned long long)r->total, r->segs.size(), s_open, (unsigned long long)nslabs, s_gather, s_wait, s_append, s_crc,
+                         since(t_f), since(t_begin));
         if (rc2 == HB_OK && (flags & HBW_PAGE_IDS)) {
             // HB_FLAG_REFERENCE_TAIL: every document's page-level (from_id, to_id, rel_flags), segment by segment in doc
             // order (a ForwardlinksQuery runs one LinksScorer per segment; its de-duplication depends on that order,

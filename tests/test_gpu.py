@@ -330,6 +330,27 @@ def test_load_webgraph_from_edge_store(gpu_ctx_factory, tmp_path):
     with gpu_ctx_factory() as ctx:
         with pytest.raises(_lib.HyperballError):
             webgraph.load_webgraph(ctx, str(tmp_path / "nothing_here"))
+    # a damaged column file: the CRC check runs beside the streaming and must stop the load before hb_finalize; what was
+    # appended is discarded (hb_discard_appended), so the SAME context then loads the intact store and gives the right result
+    import shutil
+    bad = tmp_path / "damaged" / "edges"
+    shutil.copytree(str(tmp_path / "edges"), str(bad))
+    victim = sorted(f for f in os.listdir(bad) if f.endswith(".col"))[-1]
+    with open(bad / victim, "r+b") as f:
+        f.seek(200)
+        b = f.read(1)
+        f.seek(200)
+        f.write(bytes([b[0] ^ 0x40]))
+    with gpu_ctx_factory() as ctx:
+        with pytest.raises(_lib.HyperballError) as err:
+            webgraph.load_webgraph(ctx, str(bad), verify_crc=True)
+        assert "CRC mismatch" in str(err.value) and victim[:8] in str(err.value)
+        webgraph.load_webgraph(ctx, str(tmp_path / "edges"), verify_crc=True)
+        st = ctx.run()
+        ids, vals = ctx.results()
+        assert st["n"] == fst["n"] and st["m_input"] == len(e) and st["m_eff"] == fst["m_eff"]
+        assert np.array_equal(ids, fids) and np.array_equal(vals.view(np.uint64), fvals.view(np.uint64))
+        webgraph.load_webgraph(ctx, str(bad))       # without the check the damaged store loads (one flipped id bit: another graph)
 
 
 def test_store_harmonic_writes_readable_stores(gpu_ctx_factory, tmp_path):
