@@ -96,10 +96,19 @@ unsigned grid_for(uint64_t count) { return (unsigned)std::min<uint64_t>(std::max
 
 // ---- the endpoint table: NodeID (u128) -> provisional id, open addressing, linear probing -------------------------------
 // slot state lives in the pid array: kEmpty, kBusy (claimed, key not yet published), else the pid.  An insert claims an
-// empty slot with ONE compare-and-swap, writes the key, then publishes the pid with release semantics; a reader that sees
-// a pid (acquire) may read the key.  Nothing ever spins INSIDE an iteration: a lane that finds kBusy simply goes round the
-// loop again, by which time the claiming lane - which runs straight-line code to the publishing store - is done even if it
-// sits in the same wave.
+// empty slot with ONE compare-and-swap, writes the key, then publishes the pid; a reader that sees a pid may read the key.
+// Nothing ever spins INSIDE an iteration: a lane that finds kBusy simply goes round the loop again, by which time the
+// claiming lane - which runs straight-line code to the publishing store - is done even if it sits in the same wave.
+//
+// Visibility across the 8 XCDs (their L2s are not coherent with each other, /opt/skills/guides/MI355X_MICROARCH.md
+// "inter-workgroup visibility"): EVERY access to a slot - id word and both key halves, readers and writers - is an 8-byte-or-
+// smaller agent-scope atomic (`sc1`: write-through stores, L1-bypassing loads), the guide's valid form "8-B agent atomics on
+// both sides"; the writer drains its key stores (`s_waitcnt vmcnt(0)`, as inline asm: the compiler may not drop it) before
+// the id store, a reader loads the key only after it has seen the id.  No release / acquire FENCE anywhere: the first form of
+// this kernel published with a release store (`buffer_wbl2`: a write-back of the XCD's whole L2, dirty with the kernel's own
+// output stream, per new id) and read with acquire loads (`buffer_inv` per probe) - at C4 the table kernel, not the host
+// link, set the pace of hb_append_edges (profiles/r04j_ingest_C4_trace.txt), and a returned atomic right in front of the
+// release is exactly the pattern the guide's "compiler hazard" warns about.
 constexpr uint32_t kEmpty = 0xFFFFFFFFu, kBusy = 0xFFFFFFFEu;
 constexpr uint64_t kMaxPids = 1ull << 31; // far above the engine's own limit (n_pad < 2^30)
 
@@ -126,21 +135,27 @@ struct Table {
 // pid of `key`, inserted with the next free pid if absent (want_pid == kEmpty) or with want_pid (rehash)
 __device__ __forceinline__ uint32_t table_get(const Table &t, u128 key, uint32_t want_pid)
 {
+    const unsigned long long klo = (unsigned long long)key, khi = (unsigned long long)(key >> 64);
+    unsigned long long *halves = (unsigned long long *)t.keys; // slot s: halves[2 s] = low, halves[2 s + 1] = high 64 bits
     uint64_t slot = slot_hash(key) & t.mask;
     for (;;) {
-        uint32_t s = __hip_atomic_load(&t.pids[slot], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t s = __hip_atomic_load(&t.pids[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (s == kEmpty) {
             const uint32_t old = atomicCAS(&t.pids[slot], kEmpty, kBusy);
             if (old == kEmpty) {
-                t.keys[slot] = key;
+                __hip_atomic_store(&halves[2 * slot], klo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&halves[2 * slot + 1], khi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 const uint32_t pid = want_pid != kEmpty ? want_pid : (uint32_t)atomicAdd(t.counter, 1ull);
-                __hip_atomic_store(&t.pids[slot], pid, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the key has left this CU before the id does
+                __hip_atomic_store(&t.pids[slot], pid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 return pid;
             }
-            continue; // somebody else claimed it first: read the slot again (with acquire: the key must be visible)
+            continue; // somebody else claimed it first: read the slot again
         }
         if (s == kBusy) continue; // being published: same slot again
-        if (t.keys[slot] == key) return s;
+        const unsigned long long lo = __hip_atomic_load(&halves[2 * slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long hi = __hip_atomic_load(&halves[2 * slot + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (lo == klo && hi == khi) return s;
         slot = (slot + 1) & t.mask;
     }
 }
