@@ -176,38 +176,65 @@ def _column_parts(ctype, values):
     return [bytes(head), v.view(np.uint8).reshape(-1), struct.pack("<I", 1)]
 
 
-def write_edge_store_streamed(path, segments, crc32=None):
+def _write_streamed_segment(path, i, edges, crc32):
+    """One segment file of write_edge_store_streamed; returns (meta entry, hex id)."""
+    if callable(edges):
+        edges = edges()
+    sid = uuid.UUID(int=(0xA5C4DFCBDFE645089129E308E26D5500 + i))
+    n = len(edges)
+    cols = {"from_host_id": (U128, edges["from"]), "to_host_id": (U128, edges["to"]), "rel_flags": (U64, edges["rel_flags"])}
+    parts, entries, at = [], [], 0
+    for name, (ctype, values) in sorted(cols.items(), key=lambda kv: (kv[0].encode(), kv[1][0])):
+        start = at
+        for piece in _column_parts(ctype, values):
+            parts.append(piece)
+            at += len(piece)
+        entries.append((name.encode() + b"\0" + bytes([ctype]), (start, at)))
+    sst = sstable_ranges(entries)
+    tail = sst + struct.pack("<QI", len(sst), n) + struct.pack("<I", 1) + bytes([2, 113, 119, 66])
+    body = np.empty(at + len(tail), dtype=np.uint8)
+    pos = 0
+    for piece in parts + [tail]:
+        k = len(piece)
+        body[pos:pos + k] = np.frombuffer(piece, dtype=np.uint8) if isinstance(piece, (bytes, bytearray)) else piece
+        pos += k
+    crc = (crc32(body) if crc32 else zlib.crc32(body)) & 0xFFFFFFFF
+    js = json.dumps({"version": {"major": 0, "minor": 23, "patch": 0, "index_format_version": 6}, "crc": crc}, separators=(",", ":")).encode()
+    with open(os.path.join(path, sid.hex + ".col"), "wb") as f:
+        f.write(body)
+        f.write(js + struct.pack("<II", len(js), 1337))
+    return {"segment_id": str(sid), "max_doc": n, "deletes": None}, sid.hex
+
+
+def write_edge_store_streamed(path, segments, crc32=None, workers=1):
     """The same store as write_edge_store(extra_columns=False), for BASELINE-size streams: `segments` may be a generator (one
-    EDGE array at a time, never the whole stream), every segment body is assembled once in one buffer, and `crc32` may be a
-    faster CRC-32 (IEEE) of a uint8 array than zlib's single thread (the library's hbw_debug_crc32: pieces on all cores)."""
+    EDGE array at a time, never the whole stream) of arrays or of zero-argument callables that produce them (so that `workers`
+    threads can generate, assemble, checksum and write different segments at the same time - the heavy steps are numpy copies,
+    C calls and file writes, which all release the interpreter lock; at most `workers` segments are alive at once); every
+    segment body is assembled once in one buffer, and `crc32` may be a faster CRC-32 (IEEE) of a uint8 array than zlib's single
+    thread (the library's hbw_debug_crc32: pieces on all cores).  The files do not depend on `workers`."""
     os.makedirs(path, exist_ok=True)
-    metas, ids = [], []
-    for i, edges in enumerate(segments):
-        sid = uuid.UUID(int=(0xA5C4DFCBDFE645089129E308E26D5500 + i))
-        n = len(edges)
-        cols = {"from_host_id": (U128, edges["from"]), "to_host_id": (U128, edges["to"]), "rel_flags": (U64, edges["rel_flags"])}
-        parts, entries, at = [], [], 0
-        for name, (ctype, values) in sorted(cols.items(), key=lambda kv: (kv[0].encode(), kv[1][0])):
-            start = at
-            for piece in _column_parts(ctype, values):
-                parts.append(piece)
-                at += len(piece)
-            entries.append((name.encode() + b"\0" + bytes([ctype]), (start, at)))
-        sst = sstable_ranges(entries)
-        tail = sst + struct.pack("<QI", len(sst), n) + struct.pack("<I", 1) + bytes([2, 113, 119, 66])
-        body = np.empty(at + len(tail), dtype=np.uint8)
-        pos = 0
-        for piece in parts + [tail]:
-            k = len(piece)
-            body[pos:pos + k] = np.frombuffer(piece, dtype=np.uint8) if isinstance(piece, (bytes, bytearray)) else piece
-            pos += k
-        crc = (crc32(body) if crc32 else zlib.crc32(body)) & 0xFFFFFFFF
-        js = json.dumps({"version": {"major": 0, "minor": 23, "patch": 0, "index_format_version": 6}, "crc": crc}, separators=(",", ":")).encode()
-        with open(os.path.join(path, sid.hex + ".col"), "wb") as f:
-            f.write(body)
-            f.write(js + struct.pack("<II", len(js), 1337))
-        metas.append({"segment_id": str(sid), "max_doc": n, "deletes": None})
-        ids.append(sid.hex)
+    if workers <= 1:
+        done = [_write_streamed_segment(path, i, edges, crc32) for i, edges in enumerate(segments)]
+    else:
+        import threading
+        from concurrent.futures import ThreadPoolExecutor
+        slots = threading.Semaphore(workers)
+
+        def job(i, edges):
+            try:
+                return _write_streamed_segment(path, i, edges, crc32)
+            finally:
+                slots.release()
+
+        futures = []
+        with ThreadPoolExecutor(max_workers=workers) as pool:
+            for i, edges in enumerate(segments):
+                slots.acquire()  # (a generator of arrays is only advanced when a worker is free)
+                futures.append(pool.submit(job, i, edges))
+        done = [f.result() for f in futures]
+    metas = [m for m, _ in done]
+    ids = [h for _, h in done]
     meta = {"index_settings": {"sort_by_field": {"field": "sort_score", "order": "Asc"}, "docstore_compression": "lz4",
                                "docstore_blocksize": 16384},
             "segments": metas, "schema": [{"name": "from_host_id", "type": "u128", "options": {"columnar": True}}], "opstamp": 7}

@@ -260,3 +260,10 @@ def test_streamed_fixture_writer_equals_the_plain_one(tmp_path):
     assert ids_a == ids_b
     for name in sorted(os.listdir(a)):
         assert open(a / name, "rb").read() == open(b / name, "rb").read(), name
+    # several segments in the making at once, produced on demand (what bench.py's end-to-end leg does): the same files again
+    c = tmp_path / "threaded"
+    made = []
+    ids_c = tf.write_edge_store_streamed(str(c), ((lambda s=s: (made.append(len(s)), s)[1]) for s in segs), workers=3)
+    assert ids_c == ids_a and sorted(made) == sorted(len(s) for s in segs)
+    for name in sorted(os.listdir(a)):
+        assert open(a / name, "rb").read() == open(c / name, "rb").read(), name
