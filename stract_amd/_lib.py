@@ -215,6 +215,11 @@ def load():
                              "%s not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
                              "or `make -C stract_amd/csrc` (there is no CPU fallback)" % LIB_PATH)
     lib = ctypes.CDLL(LIB_PATH)
+    if hasattr(lib, "hb_simt_interpreter") and os.environ.get("HB_ALLOW_SIMT_INTERPRETER") != "1":
+        # tests/simt builds the library's sources against a host interpreter of the device code: test infrastructure for
+        # kernel LOGIC, never a way to compute.  Only tests/test_simt.py sets the variable (for its own child process).
+        raise HyperballError(HB_ERR_NO_DEVICE, "%s is the SIMT-interpreter test build, not the gfx950 library: refused "
+                             "(there is no CPU fallback)" % LIB_PATH)
     for name, res, args in _SIGNATURES:
         fn = getattr(lib, name)  # AttributeError if the ABI lost a symbol
         fn.restype = res

@@ -35,6 +35,10 @@
 
 namespace {
 
+// every vector-memory operation this wave has issued is complete (gfx950: s_waitcnt vmcnt(0); a compiler barrier as well)
+#ifndef HB_DRAIN_VMEM
+#define HB_DRAIN_VMEM() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#endif
 using u128 = rocprim::uint128_t;
 
 #define IG_HIP(call)                                                                 \
@@ -146,7 +150,7 @@ __device__ __forceinline__ uint32_t table_get(const Table &t, u128 key, uint32_t
                 __hip_atomic_store(&halves[2 * slot], klo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 __hip_atomic_store(&halves[2 * slot + 1], khi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 const uint32_t pid = want_pid != kEmpty ? want_pid : (uint32_t)atomicAdd(t.counter, 1ull);
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the key has left this CU before the id does
+                HB_DRAIN_VMEM(); // the key has left this CU before the id does
                 __hip_atomic_store(&t.pids[slot], pid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 return pid;
             }

@@ -1,0 +1,211 @@
+// tests/simt/simt_core.cpp - TEST INFRASTRUCTURE (see simt.h): the fiber scheduler of the SIMT interpreter.
+#include "simt.h"
+
+#include <sys/mman.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#if !defined(__x86_64__)
+#error "the SIMT interpreter's context switch is written for x86-64"
+#endif
+
+// void simt_switch(void **save_sp, void *load_sp): callee-saved registers + stack pointer
+extern "C" void simt_switch(void **save_sp, void *load_sp);
+asm(".text\n"
+    ".globl simt_switch\n"
+    ".type simt_switch,@function\n"
+    "simt_switch:\n"
+    "    pushq %rbp\n    pushq %rbx\n    pushq %r12\n    pushq %r13\n    pushq %r14\n    pushq %r15\n"
+    "    movq %rsp, (%rdi)\n"
+    "    movq %rsi, %rsp\n"
+    "    popq %r15\n    popq %r14\n    popq %r13\n    popq %r12\n    popq %rbx\n    popq %rbp\n"
+    "    ret\n"
+    ".size simt_switch, .-simt_switch\n");
+
+namespace simt {
+thread_local Idx threadIdx_, blockIdx_, blockDim_, gridDim_;
+
+namespace {
+constexpr size_t kStack = 512 * 1024;
+enum State { RUN, WAIT, DONE };
+struct Lane {
+    void *sp = nullptr;
+    State st = DONE;
+    int kind = 0;
+    uint64_t value = 0, arg = 0, result = 0;
+    const void *site = nullptr;
+};
+struct Run {
+    std::vector<Lane> lanes;
+    char *stacks = nullptr;
+    size_t nstacks = 0;
+    void *sched_sp = nullptr;
+    int cur = -1;
+    const std::function<void()> *body = nullptr;
+};
+thread_local Run g;
+Stats g_stats;
+
+[[noreturn]] void die(const char *what)
+{
+    std::fprintf(stderr, "[simt] %s (block %u, lane %d)\n", what, blockIdx_.x, g.cur);
+    std::abort();
+}
+
+void lane_entry()
+{
+    (*g.body)();
+    g.lanes[g.cur].st = DONE;
+    void *dummy;
+    simt_switch(&dummy, g.sched_sp);
+    die("a finished lane was resumed");
+}
+
+void prepare_lane(int i)
+{
+    char *top = g.stacks + (size_t)(i + 1) * kStack;
+    uint64_t *sp = (uint64_t *)top;
+    *--sp = 0;                     // fake return address of lane_entry (it never returns)
+    *--sp = (uint64_t)&lane_entry; // popped by simt_switch's `ret`
+    for (int k = 0; k < 6; k++) *--sp = 0; // rbp rbx r12 r13 r14 r15
+    g.lanes[i].sp = sp;
+    g.lanes[i].st = RUN;
+}
+
+// serve the lanes of wave [w0, w1) that wait at the lowest code address
+bool serve_wave(int w0, int w1)
+{
+    const void *site = nullptr;
+    for (int i = w0; i < w1; i++) {
+        const Lane &L = g.lanes[i];
+        if (L.st == WAIT && L.kind != K_BLOCK_SYNC && (!site || L.site < site)) site = L.site;
+    }
+    if (!site) return false;
+    bool in[64];
+    int kind = 0, members = 0, live = 0;
+    for (int i = w0; i < w1; i++) {
+        const Lane &L = g.lanes[i];
+        live += L.st != DONE;
+        in[i - w0] = L.st == WAIT && L.kind != K_BLOCK_SYNC && L.site == site;
+        if (in[i - w0]) {
+            if (kind && kind != L.kind) die("lanes wait at one address with different operations");
+            kind = L.kind;
+            members++;
+        }
+    }
+    if (members < live) g_stats.partial_groups++;
+    g_stats.collectives++;
+    uint64_t ballot = 0;
+    if (kind == K_BALLOT)
+        for (int i = w0; i < w1; i++)
+            if (in[i - w0] && g.lanes[i].value) ballot |= 1ull << (i - w0);
+    uint64_t res[64];
+    for (int i = w0; i < w1; i++) {
+        if (!in[i - w0]) continue;
+        const Lane &L = g.lanes[i];
+        const int l = i - w0;
+        int src = l;
+        switch (kind) {
+        case K_BALLOT: res[l] = ballot; continue;
+        case K_WAVE_SYNC: res[l] = 0; continue;
+        case K_SHFL: src = (int)(L.arg & 63); break;
+        case K_SHFL_UP: src = l >= (int)L.arg ? l - (int)L.arg : l; break;
+        case K_SHFL_DOWN: src = l + (int)L.arg < 64 ? l + (int)L.arg : l; break;
+        case K_SHFL_XOR: src = (l ^ (int)L.arg) & 63; break;
+        case K_DPP: src = (l & ~3) | (int)((L.arg >> (2 * (l & 3))) & 3); break;
+        default: die("unknown cross-lane operation");
+        }
+        if (src < w1 - w0 && in[src]) {
+            res[l] = g.lanes[w0 + src].value;
+        } else { // the machine returns 0 for a DPP read of an inactive lane (bound_ctrl) and the own value for a shuffle out of range
+            res[l] = kind == K_DPP ? 0 : L.value;
+            if (src != l) g_stats.reads_of_inactive_lanes++;
+        }
+    }
+    for (int i = w0; i < w1; i++)
+        if (in[i - w0]) {
+            g.lanes[i].result = res[i - w0];
+            g.lanes[i].st = RUN;
+        }
+    return true;
+}
+
+void run_block(unsigned nthreads)
+{
+    for (unsigned i = 0; i < nthreads; i++) prepare_lane((int)i);
+    for (;;) {
+        bool ran = false;
+        for (unsigned i = 0; i < nthreads; i++) {
+            if (g.lanes[i].st != RUN) continue;
+            g.cur = (int)i;
+            threadIdx_.x = i;
+            simt_switch(&g.sched_sp, g.lanes[i].sp);
+            ran = true;
+        }
+        bool released = false, any_live = false, all_at_barrier = true;
+        for (unsigned w0 = 0; w0 < nthreads; w0 += 64) released |= serve_wave((int)w0, (int)std::min<unsigned>(w0 + 64, nthreads));
+        for (unsigned i = 0; i < nthreads; i++) {
+            const Lane &L = g.lanes[i];
+            if (L.st == DONE) continue;
+            any_live = true;
+            if (!(L.st == WAIT && L.kind == K_BLOCK_SYNC)) all_at_barrier = false;
+        }
+        if (!any_live) return;
+        if (released) continue;
+        if (all_at_barrier) { // __syncthreads: every live lane of the workgroup is there
+            for (unsigned i = 0; i < nthreads; i++)
+                if (g.lanes[i].st == WAIT) g.lanes[i].st = RUN;
+            continue;
+        }
+        if (!ran) die("deadlock: no lane can run and no group can be served");
+    }
+}
+} // namespace
+
+uint64_t collective(int kind, uint64_t value, uint64_t arg)
+{
+    if (g.cur < 0) die("cross-lane operation outside a kernel");
+    Lane &L = g.lanes[g.cur];
+    L.kind = kind;
+    L.value = value;
+    L.arg = arg;
+    L.site = __builtin_return_address(0);
+    L.st = WAIT;
+    simt_switch(&L.sp, g.sched_sp);
+    return g.lanes[g.cur].result;
+}
+
+void launch(unsigned grid, unsigned block, const std::function<void()> &body)
+{
+    if (g.cur >= 0) die("nested launch");
+    if (block == 0 || grid == 0) return;
+    if (g.nstacks < block) {
+        if (g.stacks) munmap(g.stacks, g.nstacks * kStack);
+        g.stacks = (char *)mmap(nullptr, (size_t)block * kStack, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
+        if (g.stacks == (char *)MAP_FAILED) die("mmap of the lane stacks failed");
+        g.nstacks = block;
+    }
+    g.lanes.assign(block, Lane());
+    g.body = &body;
+    const Idx keep_t = threadIdx_, keep_b = blockIdx_, keep_bd = blockDim_, keep_gd = gridDim_;
+    blockDim_ = Idx{block, 1, 1};
+    gridDim_ = Idx{grid, 1, 1};
+    g_stats.launches++;
+    for (unsigned b = 0; b < grid; b++) {
+        blockIdx_ = Idx{b, 0, 0};
+        g_stats.blocks++;
+        run_block(block);
+    }
+    g.cur = -1;
+    g.body = nullptr;
+    threadIdx_ = keep_t;
+    blockIdx_ = keep_b;
+    blockDim_ = keep_bd;
+    gridDim_ = keep_gd;
+}
+
+Stats &stats() { return g_stats; }
+} // namespace simt

@@ -1,0 +1,63 @@
+"""The library's DEVICE SOURCES under a SIMT interpreter on the host (tests/simt/simt.h: test infrastructure, not a compute path).
+
+tests/simt builds stract_amd/csrc/*.hip - unchanged, kernels included - with the host compiler against a fake
+<hip/hip_runtime.h> / <rocprim/rocprim.hpp> / <rccl/rccl.h>: the lanes of a workgroup run as fibers, cross-lane operations
+(ballot, shuffles, DPP quad permutations, wavefront fences, __syncthreads) are served with min-PC re-convergence, device memory
+is poisoned host memory, the device-side index checks of the `bounds` build are compiled in.  This test then runs a slice of
+the GPU parity suite (tests/test_gpu.py, the very same test functions that run on the MI355X) against that build in a child
+process: per-pass registers / Kahan words / sizes / changed counts of every pass mode and layout variant, the device ingest and
+planner against the host ones, the logical-rank and one-rank-communicator exchanges, the reference-tail mode, the AMPC
+operator - all compared with the oracle exactly as on the GPU.
+
+What it proves: the LOGIC of the kernels (tiling, collectives, LDS hand-overs, bitmaps, lazy double buffer, epilogues) - so a
+kernel change can be checked here before GPU minutes are spent on it.  What it cannot prove: anything about speed, about
+memory ordering between workgroups (they run one after the other), or about the compiler's gfx950 code: the parity tests
+proper remain the `-m gpu` tests.  stract_amd/_lib.py refuses to load this build unless HB_ALLOW_SIMT_INTERPRETER=1 (set
+here, for the child only); __graft_entry__.smoke() and bench.py never see it."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SIMT = os.path.join(ROOT, "tests", "simt")
+LIB = os.path.join(SIMT, "_build", "libhyperball_simt.so")
+
+# a slice of tests/test_gpu.py sized for the CPU suite (~1 minute); HB_SIMT_FULL=1: everything the interpreter can run (~3 min)
+QUICK = ("test_per_pass_state_matches_oracle or test_gpu_ingest_equals_host_ingest or test_device_plan_equals_host_plan or "
+         "test_logical_ranks_on_one_device or test_rccl_call_path_single_rank or test_first_occurrence_flag_wins or "
+         "test_empty_and_singleton_graphs or test_streamed_ingest_chunks_refusal_and_spill or test_ampc_counter_table_upsert_semantics")
+FULL = "not test_c2 and not test_caching_allocator_under_memory_pressure"
+
+
+@pytest.fixture(scope="module")
+def simt_lib():
+    if not os.path.exists("/opt/rocm/lib/llvm/bin/clang++") and not os.environ.get("CLANG"):
+        pytest.skip("no clang++ to build the interpreted library with")
+    subprocess.check_call(["make", "-s", "-j8", "-C", SIMT])
+    assert os.path.exists(LIB)
+    return LIB
+
+
+def _child_env(lib):
+    return dict(os.environ, HB_LIB_PATH=lib, HB_ALLOW_SIMT_INTERPRETER="1", PYTHONPATH=ROOT)
+
+
+def test_loader_refuses_the_interpreter_build_unless_asked(simt_lib):
+    code = "from stract_amd import _lib\ntry:\n    _lib.load()\n    print('LOADED')\nexcept _lib.HyperballError as e:\n    print('REFUSED', e.code)\n"
+    env = dict(os.environ, HB_LIB_PATH=simt_lib, PYTHONPATH=ROOT)
+    env.pop("HB_ALLOW_SIMT_INTERPRETER", None)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, cwd=ROOT, timeout=120)
+    assert r.stdout.strip() == "REFUSED -2", r.stdout + r.stderr
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=_child_env(simt_lib), cwd=ROOT, timeout=120)
+    assert r.stdout.strip() == "LOADED", r.stdout + r.stderr
+
+
+def test_device_sources_match_the_oracle_under_the_interpreter(simt_lib):
+    select = FULL if os.environ.get("HB_SIMT_FULL") == "1" else QUICK
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu.py"), "-m", "gpu", "-q", "-x", "-k", select,
+                        "-p", "no:cacheprovider"], capture_output=True, text=True, env=_child_env(simt_lib), cwd=ROOT, timeout=1700)
+    tail = "\n".join((r.stdout + r.stderr).splitlines()[-40:])
+    assert r.returncode == 0, tail
+    assert " passed" in tail and "failed" not in tail and "error" not in tail.lower(), tail
