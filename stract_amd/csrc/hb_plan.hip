@@ -98,7 +98,7 @@ struct DevMem {
     template <typename T>
     hipError_t alloc(T **out, size_t count)
     {
-#ifdef HB_GUARD_ALLOC
+#if defined(HB_GUARD_ALLOC) || defined(HB_EXACT_ALLOC)
         const size_t need = std::max<size_t>(count * sizeof(T), 16); // exact size: the guard sits right behind the last element
 #else
         const size_t need = (std::max<size_t>(count * sizeof(T), 256) + 255) & ~(size_t)255;

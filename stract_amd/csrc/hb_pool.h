@@ -13,12 +13,12 @@
 //                 extent goes back to its base block's free list (neighbours coalesce)
 //   pool_trim     base blocks that are entirely free go back to the runtime (end of a load, hb_destroy): what stays
 //                 allocated is what the context really holds (hb_stats.device_bytes)
-// One pool per process and device.  Debug builds (-DHB_GUARD_ALLOC, hb_guard_alloc.h) bypass it: there every buffer must be
-// its own allocation.  Include after hb_guard_alloc.h, before any other header of the translation unit.
+// One pool per process and device.  Debug builds (-DHB_GUARD_ALLOC, hb_guard_alloc.h) and memory-checker builds (-DHB_EXACT_ALLOC:
+// tests/simt under AddressSanitizer) bypass it: there every buffer must be its own allocation of its exact size.  Include after hb_guard_alloc.h, before any other header of the translation unit.
 #pragma once
 #include <hip/hip_runtime.h>
 
-#ifndef HB_GUARD_ALLOC
+#if !defined(HB_GUARD_ALLOC) && !defined(HB_EXACT_ALLOC)
 #include <cstdint>
 #include <cstdlib>
 #include <map>

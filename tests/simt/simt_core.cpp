@@ -25,6 +25,15 @@ asm(".text\n"
     "    ret\n"
     ".size simt_switch, .-simt_switch\n");
 
+// AddressSanitizer build (`make asan`): tell the runtime about every stack switch
+#if defined(__has_feature)
+#if __has_feature(address_sanitizer)
+#define SIMT_ASAN 1
+#include <sanitizer/asan_interface.h>
+#include <sanitizer/common_interface_defs.h>
+#endif
+#endif
+
 namespace simt {
 thread_local Idx threadIdx_, blockIdx_, blockDim_, gridDim_;
 
@@ -55,18 +64,42 @@ Stats g_stats;
     std::abort();
 }
 
+#ifdef SIMT_ASAN
+thread_local const void *g_sched_bottom = nullptr;
+thread_local size_t g_sched_size = 0;
+#endif
+// lane -> scheduler
+void to_scheduler(void **save_sp, bool final_switch)
+{
+#ifdef SIMT_ASAN
+    void *fake = nullptr;
+    __sanitizer_start_switch_fiber(final_switch ? nullptr : &fake, g_sched_bottom, g_sched_size);
+#endif
+    simt_switch(save_sp, g.sched_sp);
+#ifdef SIMT_ASAN
+    __sanitizer_finish_switch_fiber(fake, &g_sched_bottom, &g_sched_size);
+#endif
+    (void)final_switch;
+}
+
 void lane_entry()
 {
+#ifdef SIMT_ASAN
+    __sanitizer_finish_switch_fiber(nullptr, &g_sched_bottom, &g_sched_size);
+#endif
     (*g.body)();
     g.lanes[g.cur].st = DONE;
     void *dummy;
-    simt_switch(&dummy, g.sched_sp);
+    to_scheduler(&dummy, true);
     die("a finished lane was resumed");
 }
 
 void prepare_lane(int i)
 {
     char *top = g.stacks + (size_t)(i + 1) * kStack;
+#ifdef SIMT_ASAN
+    __asan_unpoison_memory_region(top - kStack, kStack); // frames of the lane that used this stack before never returned
+#endif
     uint64_t *sp = (uint64_t *)top;
     *--sp = 0;                     // fake return address of lane_entry (it never returns)
     *--sp = (uint64_t)&lane_entry; // popped by simt_switch's `ret`
@@ -142,7 +175,14 @@ void run_block(unsigned nthreads)
             if (g.lanes[i].st != RUN) continue;
             g.cur = (int)i;
             threadIdx_.x = i;
+#ifdef SIMT_ASAN
+            void *fake = nullptr;
+            __sanitizer_start_switch_fiber(&fake, g.stacks + (size_t)i * kStack, kStack);
+#endif
             simt_switch(&g.sched_sp, g.lanes[i].sp);
+#ifdef SIMT_ASAN
+            __sanitizer_finish_switch_fiber(fake, nullptr, nullptr);
+#endif
             ran = true;
         }
         bool released = false, any_live = false, all_at_barrier = true;
@@ -174,7 +214,7 @@ uint64_t collective(int kind, uint64_t value, uint64_t arg)
     L.arg = arg;
     L.site = __builtin_return_address(0);
     L.st = WAIT;
-    simt_switch(&L.sp, g.sched_sp);
+    to_scheduler(&L.sp, false);
     return g.lanes[g.cur].result;
 }
 

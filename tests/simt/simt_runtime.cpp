@@ -27,7 +27,12 @@ hipError_t hipMalloc(void **p, size_t n)
     if (!p) return hipErrorInvalidValue;
     const size_t bytes = (n ? n : 1);
     void *q = nullptr;
+#if defined(__has_feature) && __has_feature(address_sanitizer)
+    // exactly the bytes asked for: the sanitizer's red zone starts right behind the last one (64-byte aligned like a counter row)
+    if (posix_memalign(&q, 64, bytes) != 0 || !q) {
+#else
     if (posix_memalign(&q, 256, (bytes + 255) / 256 * 256) != 0 || !q) {
+#endif
         *p = nullptr;
         return hipErrorOutOfMemory;
     }

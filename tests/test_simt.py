@@ -61,3 +61,42 @@ def test_device_sources_match_the_oracle_under_the_interpreter(simt_lib):
     tail = "\n".join((r.stdout + r.stderr).splitlines()[-40:])
     assert r.returncode == 0, tail
     assert " passed" in tail and "failed" not in tail and "error" not in tail.lower(), tail
+
+
+def _asan_runtime():
+    r = subprocess.run([os.environ.get("CLANG", "/opt/rocm/lib/llvm/bin/clang++"), "-print-file-name=libclang_rt.asan-x86_64.so"], capture_output=True, text=True)
+    path = r.stdout.strip()
+    return path if os.path.isabs(path) and os.path.exists(path) else None
+
+
+def test_device_sources_under_address_sanitizer(simt_lib):
+    """`make asan`: the interpreted build under AddressSanitizer, every "device" buffer an allocation of its exact size
+    (-DHB_EXACT_ALLOC: no caching allocator, no planner slab): every load and store of every kernel - and of the stand-ins for
+    the rocPRIM primitives - is checked against the bounds of the allocation it touches.  First the checker itself: a kernel
+    that reads one element past a buffer must be caught, the same kernel inside its buffer must not.  Then GPU parity tests
+    run under it.  Default: two per-pass variants (dense + bitmap + sweep passes, device ingest and planner on the way);
+    HB_SIMT_ASAN=1: everything the interpreter can run (68 tests, ~16 min; profiles/r04_simt_asan_gpu_suite.txt)."""
+    rt = _asan_runtime()
+    if rt is None:
+        pytest.skip("no AddressSanitizer runtime next to clang")
+    subprocess.check_call(["make", "-s", "-j8", "-C", SIMT, "asan"])
+    clang = os.environ.get("CLANG", "/opt/rocm/lib/llvm/bin/clang++")
+    exe = os.path.join(SIMT, "_build_asan", "asan_selftest")
+    subprocess.check_call([clang, "-x", "c++", "-std=c++17", "-O0", "-g", "-fsanitize=address", "-shared-libasan", "-fno-omit-frame-pointer",
+                           "-I", os.path.join(SIMT, "include"), os.path.join(SIMT, "asan_selftest.cpp"), os.path.join(SIMT, "simt_core.cpp"),
+                           os.path.join(SIMT, "simt_runtime.cpp"), "-o", exe, "-Wl,-rpath," + os.path.dirname(rt)])
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0")
+    ok = subprocess.run([exe], capture_output=True, text=True, env=env, timeout=120)
+    assert ok.returncode == 0 and ok.stdout.strip() == "clean 1000", ok.stdout + ok.stderr
+    bad = subprocess.run([exe, "over"], capture_output=True, text=True, env=env, timeout=120)
+    assert bad.returncode != 0 and "heap-buffer-overflow" in bad.stderr and "0 bytes after 4000-byte region" in bad.stderr, bad.stderr[-2000:]
+    assert "sum_kernel" in bad.stderr  # ... and names the kernel's source line
+    select = ("not test_c2 and not test_caching_allocator_under_memory_pressure and not test_multi_process" if os.environ.get("HB_SIMT_ASAN") == "1"
+              else "test_per_pass_state_matches_oracle and (default or sparse_always_multilevel) and not long_tail")
+    lib = os.path.join(SIMT, "_build_asan", "libhyperball_simt_asan.so")
+    env = dict(_child_env(lib), LD_PRELOAD=rt, ASAN_OPTIONS="detect_leaks=0:detect_stack_use_after_return=0")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu.py"), "-m", "gpu", "-q", "-x", "-k", select,
+                        "-p", "no:cacheprovider"], capture_output=True, text=True, env=env, cwd=ROOT, timeout=3400)
+    tail = "\n".join((r.stdout + r.stderr).splitlines()[-40:])
+    assert r.returncode == 0 and "AddressSanitizer" not in r.stdout + r.stderr, tail
+    assert " passed" in tail and "failed" not in tail, tail
