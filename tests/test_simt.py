@@ -100,3 +100,21 @@ def test_device_sources_under_address_sanitizer(simt_lib):
     tail = "\n".join((r.stdout + r.stderr).splitlines()[-40:])
     assert r.returncode == 0 and "AddressSanitizer" not in r.stdout + r.stderr, tail
     assert " passed" in tail and "failed" not in tail, tail
+
+
+@pytest.mark.skipif(os.environ.get("HB_SIMT_UBSAN") != "1", reason="opt-in (HB_SIMT_UBSAN=1, ~2 min): the interpreted device sources under UndefinedBehaviorSanitizer")
+def test_device_sources_under_undefined_behaviour_sanitizer(simt_lib):
+    """`make ubsan`: shift widths, signed overflow, misaligned accesses, out-of-range float -> integer casts in the device sources
+    (the gfx950 compiler may assume none of them happens).  Round 4: 68 tests, no report (profiles/r04_simt_asan_gpu_suite.txt)."""
+    rt = _asan_runtime()
+    if rt is None:
+        pytest.skip("no sanitizer runtimes next to clang")
+    ub = os.path.join(os.path.dirname(rt), "libclang_rt.ubsan_standalone-x86_64.so")
+    subprocess.check_call(["make", "-s", "-j8", "-C", SIMT, "ubsan"])
+    lib = os.path.join(SIMT, "_build_ubsan", "libhyperball_simt_ubsan.so")
+    env = dict(_child_env(lib), LD_PRELOAD=ub, UBSAN_OPTIONS="halt_on_error=1:abort_on_error=1:print_stacktrace=1")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu.py"), "-m", "gpu", "-q", "-x", "-s", "-k",
+                        "not test_c2 and not test_caching_allocator_under_memory_pressure and not test_multi_process", "-p", "no:cacheprovider"],
+                       capture_output=True, text=True, env=env, cwd=ROOT, timeout=3400)
+    tail = "\n".join((r.stdout + r.stderr).splitlines()[-40:])
+    assert r.returncode == 0 and "runtime error" not in r.stdout + r.stderr, tail
