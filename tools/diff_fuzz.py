@@ -1,0 +1,126 @@
+#!/usr/bin/env python3
+"""Differential fuzzing of the pass driver against the oracle: random small graphs of several shapes x random layout / mode knobs,
+compared after EVERY pass (registers, Kahan words, cached sizes, changed count, pass count) and at the end (final list).
+Runs against whatever library HB_LIB_PATH names: the gfx950 library on a GPU box, or - on a machine without a GPU - the
+interpreted test build of the device sources (tests/simt, with HB_ALLOW_SIMT_INTERPRETER=1; add the AddressSanitizer preload
+for the `make asan` build).  A failure prints the seed and case that reproduce it and makes the exit code non-zero.
+
+usage: tools/diff_fuzz.py [--seconds S] [--seed N] [--max-nodes N]"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np  # noqa: E402
+
+from oracle import hbo  # noqa: E402
+from stract_amd import _lib  # noqa: E402
+from tests import graphs  # noqa: E402
+
+FLAG_POOL = ["NO_REORDER", "NO_XCD_MAP", "UNFUSED", "NO_SPARSE", "NO_FRONTIER", "PASS_STATS", "HOST_PLAN", "NO_INIT_PASS"]
+
+
+def big_graph(rng, max_nodes):
+    """Shapes the test-suite generator does not reach: hubs above 4096 in-edges (three-level chunk trees at small chunks), many
+    isolated / source-only nodes, a heavy-tailed in-degree, long chains hanging off a dense core."""
+    n = int(rng.integers(2, max_nodes))
+    kind = ("heavy_tail", "mega_hub", "core_and_chains")[int(rng.integers(0, 3))]
+    e = set()
+    if kind == "heavy_tail":
+        m = int(rng.integers(n, 8 * n))
+        dst = np.minimum((rng.pareto(1.1, m) * 3).astype(np.int64) + 1, n)
+        src = rng.integers(1, n + 1, m)
+        e = set(zip(src.tolist(), dst.tolist()))
+    elif kind == "mega_hub":
+        k = int(rng.integers(1, 4))
+        for h in range(1, k + 1):
+            for s in rng.choice(np.arange(1, n + 1), size=int(rng.integers(n // 2, n)), replace=False).tolist():
+                e.add((int(s), h))
+        for _ in range(2 * n):
+            e.add((int(rng.integers(1, n + 1)), int(rng.integers(1, n + 1))))
+    else:
+        core = max(2, n // 20)
+        for a in range(1, core + 1):
+            for b in rng.integers(1, core + 1, 8).tolist():
+                e.add((a, int(b)))
+        at = core + 1
+        while at < n:
+            length = int(rng.integers(1, 60))
+            prev = int(rng.integers(1, core + 1))
+            for v in range(at, min(at + length, n + 1)):
+                e.add((prev, v))
+                prev = v
+            at += length
+    return kind, sorted((a, b) for a, b in e if a != b)
+
+
+def one_case(rng, max_nodes, case):
+    if rng.random() < 0.5:
+        kind, edges = graphs.random_graph(rng)
+    else:
+        kind, edges = big_graph(rng, max_nodes)
+    if not edges:
+        return None
+    ids, row_ptr, src = graphs.dense_from_tuples(edges)
+    chunk = int(rng.choice([4, 8, 16, 32, 64, 128, 256]))
+    tune = (int(rng.choice([0, 0, 1, 2, 7])), int(rng.choice([0, 1, 2, 4])) | int(rng.choice([0, 0, 0x100, 0x800, 0x2000])), int(rng.choice([0, 0, 30, 101])),
+            int(rng.integers(4, 17)), int(rng.integers(1, 9)), int(rng.integers(0, chunk + 1)), int(rng.choice([0, 0, 1, 4, 1000000])))
+    names = sorted(set(rng.choice(FLAG_POOL, size=int(rng.integers(0, 3))).tolist()))
+    flags = 0
+    for nm in names:
+        flags |= getattr(_lib, "HB_FLAG_" + nm)
+    what = dict(case=case, kind=kind, n=int(len(ids)), m=int(len(src)), chunk=chunk, tune=tune, flags=names)
+    o = hbo.Dense(ids["lo"].copy(), row_ptr, src)
+    with _lib.Context(flags=flags, chunk=chunk, tune=tune) as ctx:
+        ctx.load_dense(ids, row_ptr, src)
+        ctx.begin()
+        assert np.array_equal(ctx.registers(), o.registers()), ("initial registers", what)
+        has, t = True, 0
+        while has:
+            has = ctx.step()
+            ohas, ost = o.step(hbo.FRONTIER)
+            assert has == ohas, ("has_changes after pass %d" % t, what)
+            assert np.array_equal(ctx.registers(), o.registers()), ("registers after pass %d" % t, what)
+            s, e = ctx.kahan()
+            os_, oe = o.kahan()
+            assert np.array_equal(s.view(np.uint64), os_.view(np.uint64)) and np.array_equal(e.view(np.uint64), oe.view(np.uint64)), ("Kahan words after pass %d" % t, what)
+            assert np.array_equal(ctx.sizes(), o.sizes()), ("sizes after pass %d" % t, what)
+            assert ctx.pass_stats()[t]["changed"] == ost["changed"], ("changed count of pass %d" % t, what)
+            t += 1
+        ctx.finish()
+        vals, keep, k = o.finish()
+        gids, gvals = ctx.results()
+        assert len(gvals) == k and np.array_equal(gids, ids[keep]) and np.array_equal(gvals.view(np.uint64), vals[keep].view(np.uint64)), ("final list", what)
+    what["passes"] = t
+    return what
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--seconds", type=float, default=60.0)
+    ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--max-nodes", type=int, default=6000)
+    a = ap.parse_args()
+    rng = np.random.default_rng(a.seed)
+    t0 = time.time()
+    done, edges, passes = 0, 0, 0
+    case = 0
+    while time.time() - t0 < a.seconds:
+        try:
+            w = one_case(rng, a.max_nodes, case)
+        except AssertionError as e:
+            print(json.dumps({"failed": str(e.args[0] if e.args else e), "seed": a.seed, "cases_before": done}))
+            sys.exit(1)
+        case += 1
+        if w:
+            done += 1
+            edges += w["m"]
+            passes += w["passes"]
+    print(json.dumps({"library": _lib.LIB_PATH, "seed": a.seed, "seconds": round(time.time() - t0, 1), "cases": done, "edges": edges, "passes_compared": passes, "failed": None}))
+
+
+if __name__ == "__main__":
+    main()
