@@ -451,6 +451,31 @@ def test_hub_rows_and_isolated_nodes(gpu_ctx_factory):
         assert np.array_equal(ids, fids) and np.array_equal(vals.view(np.uint64), fvals.view(np.uint64)), kw
 
 
+def test_sweep_seeds_with_very_long_reader_lists(gpu_ctx_factory):
+    """A hub SOURCE that keeps changing late: a chain with private feeders drips new elements into H for a dozen passes, H links to K
+    leaves, everything else is quiet - so the data-driven (sweep) passes get a seed with K readers.  K = 3000: <= 4096 nodes changed,
+    one launch collects and expands, H's list is walked by the whole wave (> 64 entries); K = 5000: the general path, H goes to the
+    grid-wide expansion (> 4096 readers).  Found by measuring block coverage of the kernels on the interpreted device sources
+    (tools/simt_coverage.py): no other test reached those branches."""
+    for K in (3000, 5000):
+        L = 14
+        H, chain0, feed0, leaf0 = 1, 10, 1000, 100000
+        tuples = [(chain0 + i, chain0 + i + 1, 0) for i in range(L - 1)] + [(chain0 + L - 1, H, 0)]
+        tuples += [(feed0 + 8 * i + j, chain0 + i, 0) for i in range(L) for j in range(6)]
+        tuples += [(H, leaf0 + k, 0) for k in range(K)]
+        tuples += [(leaf0 + k, leaf0 + K + (k % 7), 0) for k in range(0, K, 3)]   # a few leaves are read further on
+        e = EdgeListGraph.from_tuples(tuples)
+        fids, fvals, fst = hbo.faithful_run(e.host_edges())
+        for kw in (dict(tune=(0, 0, 101, 0, 0, 0, 1)), dict(tune=(0, 0x800, 101, 0, 0, 0, 1)), dict()):
+            hc = HarmonicCentrality.calculate(e, **kw)
+            ids, vals = hc.arrays()
+            assert hc.stats["passes"] == fst["passes"] and hc.stats["n"] == fst["n"], (K, kw)
+            assert np.array_equal(ids, fids) and np.array_equal(vals.view(np.uint64), fvals.view(np.uint64)), (K, kw)
+            if kw:
+                sweeps = [ps for ps in hc.pass_stats if ps["mode"] == 2]
+                assert len(sweeps) >= 8 and max(ps["changed"] for ps in sweeps) >= K, (K, kw)  # H (and with it its K leaves) changed in a sweep pass
+
+
 def test_randomized_graphs_and_knobs(gpu_ctx_factory):
     """Random small graphs of several shapes x random planner / mode knobs: final list, pass count and
     registers against the oracle."""
