@@ -666,8 +666,10 @@ void parallel_sort(std::vector<Entry> &e)
 #pragma omp parallel for num_threads(hb::host_threads()) schedule(static) reduction(| : diff)
     for (size_t i = 0; i < n; i++) diff |= e[i].k0 ^ e[0].k0;
     if (!diff) { // all keys share their first 8 bytes: nothing to split on here
+        const int before = omp_get_max_threads();
         omp_set_num_threads(hb::host_threads());
         __gnu_parallel::sort(e.begin(), e.end());
+        omp_set_num_threads(before); // (the caller's setting is not ours to change)
         return;
     }
     const int top = 63 - __builtin_clzll(diff);     // most significant differing bit of k0
@@ -680,8 +682,11 @@ void parallel_sort(std::vector<Entry> &e)
     std::vector<size_t> start(nb + 1, 0);
 #pragma omp parallel num_threads(nt)
     {
+        // the team may be SMALLER than asked for (a caller's own parallel region around this call, a thread limit): the shares
+        // are cut by the team that exists, or entries would be left out
+        const int team = omp_get_num_threads();
         const int t = omp_get_thread_num();
-        const size_t lo = n * (size_t)t / (size_t)nt, hi = n * (size_t)(t + 1) / (size_t)nt;
+        const size_t lo = n * (size_t)t / (size_t)team, hi = n * (size_t)(t + 1) / (size_t)team;
         std::vector<size_t> &h = hist[(size_t)t];
         for (size_t i = lo; i < hi; i++) h[(e[i].k0 >> shift) & mask]++;
 #pragma omp barrier
@@ -690,7 +695,7 @@ void parallel_sort(std::vector<Entry> &e)
             size_t at = 0;
             for (size_t b = 0; b < nb; b++) {
                 start[b] = at;
-                for (int u = 0; u < nt; u++) {
+                for (int u = 0; u < team; u++) {
                     const size_t c = hist[(size_t)u][b];
                     hist[(size_t)u][b] = at; // thread u's write position inside bucket b
                     at += c;

@@ -262,3 +262,30 @@ def test_published_vectors_of_the_restated_formats(tmp_path):
     long_input = bytes(range(256)) * 3
     assert x.secret_matches_seed(long_input, len(long_input), 42) == 1
     assert x.secret_matches_seed(long_input, 241, 42) == 1
+
+
+def test_store_sort_with_a_smaller_team_than_asked_for(tmp_path):
+    """OpenMP may hand out FEWER threads than num_threads() asks for (OMP_THREAD_LIMIT, a caller's own parallel region around the
+    call): the bucketed key sort used to cut its shares by the number it asked for, so entries were left out (found by building
+    the store writer with the pragmas ignored for the AddressSanitizer run, tests/simt).  8 threads wanted, 2 allowed."""
+    import subprocess
+    import sys
+    code = (
+        "import numpy as np, sys\n"
+        "from stract_amd import _lib\n"
+        "from tests import speedy_kv_reader as kv\n"
+        "rng = np.random.default_rng(3)\n"
+        "n = 200000\n"
+        "ids = np.zeros(n, dtype=_lib.U128)\n"
+        "ids['lo'] = rng.permutation(n).astype(np.uint64) * 2654435761 + 7\n"
+        "ids['hi'] = rng.integers(0, 1 << 40, n, dtype=np.uint64)\n"
+        "vals = rng.random(n)\n"
+        "_lib.store_write(sys.argv[1], ids, vals)\n"
+        "db = kv.Db(sys.argv[1], 'f64', sys.argv[2])\n"
+        "ints = kv.ids_to_ints(ids)\n"
+        "assert len(db) == n\n"
+        "assert all(db.get(ints[j]) == float(vals[j]) for j in rng.integers(0, n, 300).tolist())\n"
+        "print('ok')\n")
+    env = dict(os.environ, OMP_THREAD_LIMIT="2", HB_HOST_THREADS="8", PYTHONPATH=kv.ROOT)
+    r = subprocess.run([sys.executable, "-c", code, str(tmp_path / "db"), str(tmp_path)], capture_output=True, text=True, env=env, cwd=kv.ROOT, timeout=600)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stdout[-2000:] + r.stderr[-2000:]
