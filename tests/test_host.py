@@ -29,6 +29,24 @@ def test_header_symbols_all_exported():
     assert _lib.load().hb_abi_version() == 4
 
 
+def test_headers_are_plain_c99_and_struct_sizes_agree(tmp_path):
+    """What a cgo / bindgen / JNI binding compiles is C, not C++: every header under include/ must pass a strict C99 compiler on its own,
+    and the struct sizes the C compiler sees are the ones the Python binding (and INTEGRATION.md's Rust shim) assume."""
+    import subprocess
+    names = sorted(f for f in os.listdir(os.path.join(ROOT, "include")) if f.endswith(".h"))
+    for name in names:  # each header alone: it must include what it needs
+        src = tmp_path / ("only_" + name[:-2] + ".c")
+        src.write_text('#include "%s"\nint main(void) { return 0; }\n' % name)
+        subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(ROOT, "include"), "-c", str(src), "-o", str(tmp_path / "o.o")])
+    src = tmp_path / "sizes.c"
+    src.write_text("".join('#include "%s"\n' % n for n in names) + '#include <stdio.h>\n'
+                   'int main(void) { printf("%zu %zu %zu %zu %zu\\n", sizeof(hb_options), sizeof(hb_stats), sizeof(hb_pass_stats), sizeof(hb_edge), sizeof(hb_u128)); return 0; }\n')
+    exe = str(tmp_path / "sizes")
+    subprocess.check_call(["gcc", "-std=c99", "-I", os.path.join(ROOT, "include"), str(src), "-o", exe])
+    got = [int(x) for x in subprocess.check_output([exe], text=True).split()]
+    assert got == [ctypes.sizeof(_lib.HbOptions), ctypes.sizeof(_lib.HbStats), ctypes.sizeof(_lib.HbPassStats), _lib.EDGE.itemsize, _lib.U128.itemsize], got
+
+
 def test_struct_layouts_match_header():
     assert ctypes.sizeof(_lib.HbOptions) == 4 * 7 + 128 + 32
     assert _lib.EDGE.itemsize == 40 and _lib.U128.itemsize == 16

@@ -5,7 +5,7 @@ Runs against whatever library HB_LIB_PATH names: the gfx950 library on a GPU box
 interpreted test build of the device sources (tests/simt, with HB_ALLOW_SIMT_INTERPRETER=1; add the AddressSanitizer preload
 for the `make asan` build).  A failure prints the seed and case that reproduce it and makes the exit code non-zero.
 
-usage: tools/diff_fuzz.py [--seconds S] [--seed N] [--max-nodes N]"""
+usage: tools/diff_fuzz.py [--mode passes|records|mixed] [--seconds S] [--seed N] [--max-nodes N]"""
 import argparse
 import json
 import os
@@ -98,8 +98,63 @@ def one_case(rng, max_nodes, case):
     return what
 
 
+SKIPPED_BITS = [8, 10, 11, 13, 14, 15, 16, 17, 18, 19, 21, 22]  # HB_SKIPPED_REL_MASK = 0x6FED00
+HARMLESS_BITS = [0, 1, 2, 3, 4, 5, 6, 7, 9, 12, 20]
+
+
+def records_case(rng, max_nodes, case):
+    """The record boundary: a random stream of SmallEdge records - 128-bit ids (equal low halves, different high halves among them),
+    duplicates of a pair with other flags before and after it, skipped and harmless rel flags, self links - handed over in random
+    batches (hb_append_edges ... hb_finalize, the device ingest: hash table of provisional ids, one stable sort) or at once, with and
+    without an explicit node list; node / edge counts, pass count and the final list against the faithful (map-based) oracle."""
+    n = int(rng.integers(2, max(3, max_nodes // 4)))
+    m = int(rng.integers(1, 6 * n))
+    pool_lo = rng.integers(1, 1 << 62, n, dtype=np.uint64)
+    pool_hi = rng.integers(0, 3, n, dtype=np.uint64) if rng.random() < 0.5 else rng.integers(0, 1 << 63, n, dtype=np.uint64)
+    if rng.random() < 0.3:
+        pool_lo[: n // 2] = pool_lo[n // 2: n // 2 + n // 2]  # same low half, told apart only by the high half
+    e = np.zeros(m, dtype=_lib.EDGE)
+    a, b = rng.integers(0, n, m), rng.integers(0, n, m)
+    if rng.random() < 0.5:  # a hub destination
+        b[rng.random(m) < 0.3] = 0
+    e["from"]["lo"], e["from"]["hi"], e["to"]["lo"], e["to"]["hi"] = pool_lo[a], pool_hi[a], pool_lo[b], pool_hi[b]
+    flags = np.zeros(m, dtype=np.uint64)
+    for k in np.nonzero(rng.random(m) < 0.25)[0]:
+        bits = SKIPPED_BITS if rng.random() < 0.6 else HARMLESS_BITS
+        flags[k] = np.uint64(1) << np.uint64(int(rng.choice(bits)))
+    e["rel_flags"] = flags
+    dup = np.nonzero(rng.random(m) < 0.2)[0]  # repeat some records elsewhere in the stream with other flags
+    if len(dup):
+        extra = e[dup].copy()
+        extra["rel_flags"] = np.where(rng.random(len(dup)) < 0.5, np.uint64(0), np.uint64(1) << np.uint64(13))
+        e = np.concatenate([e, extra])
+        e = e[rng.permutation(len(e))]
+    fids, fvals, fst = hbo.faithful_run(e)
+    how = int(rng.integers(0, 3))
+    what = dict(case=case, kind="records", records=int(len(e)), pool=n, how=("batches", "at once", "at once + node list")[how])
+    flags_ctx = int(rng.choice([0, 0, _lib.HB_FLAG_HOST_INGEST, _lib.HB_FLAG_HOST_PLAN]))
+    with _lib.Context(flags=flags_ctx, chunk=int(rng.choice([8, 64]))) as ctx:
+        if how == 0:
+            cuts = np.sort(rng.integers(0, len(e) + 1, int(rng.integers(0, 6))))
+            for part in np.split(e, cuts):
+                ctx.append_edges(part)
+            ctx.finalize()
+        elif how == 1:
+            ctx.load_edges(e)
+        else:
+            nodes = np.unique(np.concatenate([e["from"], e["to"]]))
+            ctx.load_edges(e, nodes)
+        st = ctx.run()
+        ids, vals = ctx.results()
+    assert (st["n"], st["m_unique"], st["m_eff"], st["passes"]) == (fst["n"], fst["m_unique"], fst["m_eff"], fst["passes"]), ("counts", what, st, fst)
+    assert np.array_equal(ids, fids) and np.array_equal(vals.view(np.uint64), fvals.view(np.uint64)), ("final list", what)
+    what.update(m=int(fst["m_eff"]), passes=int(fst["passes"]))
+    return what
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--mode", choices=["passes", "records", "mixed"], default="passes")
     ap.add_argument("--seconds", type=float, default=60.0)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--max-nodes", type=int, default=6000)
@@ -110,7 +165,10 @@ def main():
     case = 0
     while time.time() - t0 < a.seconds:
         try:
-            w = one_case(rng, a.max_nodes, case)
+            if a.mode == "records" or (a.mode == "mixed" and case % 3 == 2):
+                w = records_case(rng, a.max_nodes, case)
+            else:
+                w = one_case(rng, a.max_nodes, case)
         except AssertionError as e:
             print(json.dumps({"failed": str(e.args[0] if e.args else e), "seed": a.seed, "cases_before": done}))
             sys.exit(1)
@@ -119,7 +177,7 @@ def main():
             done += 1
             edges += w["m"]
             passes += w["passes"]
-    print(json.dumps({"library": _lib.LIB_PATH, "seed": a.seed, "seconds": round(time.time() - t0, 1), "cases": done, "edges": edges, "passes_compared": passes, "failed": None}))
+    print(json.dumps({"library": _lib.LIB_PATH, "mode": a.mode, "seed": a.seed, "seconds": round(time.time() - t0, 1), "cases": done, "edges": edges, "passes_compared": passes, "failed": None}))
 
 
 if __name__ == "__main__":
