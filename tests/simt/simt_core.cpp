@@ -5,6 +5,7 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <algorithm>
 #include <cstring>
 #include <vector>
 
@@ -166,12 +167,53 @@ bool serve_wave(int w0, int w1)
     return true;
 }
 
+// HB_SIMT_ORDER: in which order the workgroups of a launch, and the runnable lanes of a workgroup between two cross-lane
+// operations, take their turns: "forward" (default), "reverse", or "shuffle:<seed>" (a different permutation per launch / per
+// sweep).  The machine promises no order at all; results that depend on one are races the default order would hide.
+struct Order {
+    int mode = 0; // 0 forward, 1 reverse, 2 shuffle
+    uint64_t state = 0x9E3779B97F4A7C15ull;
+    Order()
+    {
+        const char *e = std::getenv("HB_SIMT_ORDER");
+        if (!e) return;
+        if (!std::strcmp(e, "reverse")) mode = 1;
+        else if (!std::strncmp(e, "shuffle", 7)) {
+            mode = 2;
+            if (e[7] == ':') state ^= std::strtoull(e + 8, nullptr, 10) * 0xD1B54A32D192ED03ull;
+        }
+    }
+    uint64_t next()
+    {
+        state ^= state << 13;
+        state ^= state >> 7;
+        state ^= state << 17;
+        return state;
+    }
+    void fill(std::vector<unsigned> &v, unsigned n)
+    {
+        v.resize(n);
+        for (unsigned i = 0; i < n; i++) v[i] = mode == 1 ? n - 1 - i : i;
+        if (mode == 2)
+            for (unsigned i = n; i > 1; i--) std::swap(v[i - 1], v[(unsigned)(next() % i)]);
+    }
+};
+Order &order()
+{
+    static Order o;
+    return o;
+}
+
 void run_block(unsigned nthreads)
 {
     for (unsigned i = 0; i < nthreads; i++) prepare_lane((int)i);
+    thread_local std::vector<unsigned> turn;
+    order().fill(turn, nthreads);
     for (;;) {
         bool ran = false;
-        for (unsigned i = 0; i < nthreads; i++) {
+        if (order().mode == 2) order().fill(turn, nthreads);
+        for (unsigned k = 0; k < nthreads; k++) {
+            const unsigned i = turn[k];
             if (g.lanes[i].st != RUN) continue;
             g.cur = (int)i;
             threadIdx_.x = i;
@@ -234,7 +276,10 @@ void launch(unsigned grid, unsigned block, const std::function<void()> &body)
     blockDim_ = Idx{block, 1, 1};
     gridDim_ = Idx{grid, 1, 1};
     g_stats.launches++;
-    for (unsigned b = 0; b < grid; b++) {
+    std::vector<unsigned> blocks;
+    order().fill(blocks, grid);
+    for (unsigned k = 0; k < grid; k++) {
+        const unsigned b = blocks[k];
         blockIdx_ = Idx{b, 0, 0};
         g_stats.blocks++;
         run_block(block);
