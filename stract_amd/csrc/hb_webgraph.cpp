@@ -665,7 +665,13 @@ int hb_load_webgraph(hb_ctx *ctx, const char *edges_dir, uint32_t flags)
     std::unique_ptr<hbw_reader, CloseInBackground> guard(raw);
     hbw_reader *r = raw;
     return guarded(r, [&]() -> int {
-        const uint64_t slab = 1ull << 22; // 4 Mi records (160 MiB) per hand-over
+        // 4 Mi records (160 MiB) per hand-over.  HB_WEBGRAPH_SLAB_RECORDS (tests): a small slab makes a small store take the
+        // many-slab path - the alternating pinned buffers, the reader thread waiting for a free one, this thread for a full one
+        uint64_t slab = 1ull << 22;
+        if (const char *e = std::getenv("HB_WEBGRAPH_SLAB_RECORDS")) {
+            const uint64_t v = std::strtoull(e, nullptr, 10);
+            if (v >= 1 && v <= (1ull << 24)) slab = v;
+        }
         if (flags & HBW_PAGE_IDS) {
             // page-level records need a context in reference-tail mode: find out before the whole store is ingested
             int rc0 = hb_load_tail_edges(ctx, nullptr, 0);

@@ -35,6 +35,14 @@ asm(".text\n"
 #endif
 #endif
 
+// ThreadSanitizer build (`make tsan`): every lane is a fiber the runtime must know about
+#if defined(__has_feature)
+#if __has_feature(thread_sanitizer)
+#define SIMT_TSAN 1
+#include <sanitizer/tsan_interface.h>
+#endif
+#endif
+
 namespace simt {
 thread_local Idx threadIdx_, blockIdx_, blockDim_, gridDim_;
 
@@ -42,6 +50,9 @@ namespace {
 constexpr size_t kStack = 512 * 1024;
 enum State { RUN, WAIT, DONE };
 struct Lane {
+#ifdef SIMT_TSAN
+    void *tsan_fiber = nullptr;
+#endif
     void *sp = nullptr;
     State st = DONE;
     int kind = 0;
@@ -53,6 +64,9 @@ struct Run {
     char *stacks = nullptr;
     size_t nstacks = 0;
     void *sched_sp = nullptr;
+#ifdef SIMT_TSAN
+    void *sched_fiber = nullptr;
+#endif
     int cur = -1;
     const std::function<void()> *body = nullptr;
 };
@@ -75,6 +89,9 @@ void to_scheduler(void **save_sp, bool final_switch)
 #ifdef SIMT_ASAN
     void *fake = nullptr;
     __sanitizer_start_switch_fiber(final_switch ? nullptr : &fake, g_sched_bottom, g_sched_size);
+#endif
+#ifdef SIMT_TSAN
+    __tsan_switch_to_fiber(g.sched_fiber, 0);
 #endif
     simt_switch(save_sp, g.sched_sp);
 #ifdef SIMT_ASAN
@@ -107,6 +124,9 @@ void prepare_lane(int i)
     for (int k = 0; k < 6; k++) *--sp = 0; // rbp rbx r12 r13 r14 r15
     g.lanes[i].sp = sp;
     g.lanes[i].st = RUN;
+#ifdef SIMT_TSAN
+    g.lanes[i].tsan_fiber = __tsan_create_fiber(0);
+#endif
 }
 
 // serve the lanes of wave [w0, w1) that wait at the lowest code address
@@ -204,7 +224,21 @@ Order &order()
     return o;
 }
 
+void run_block_inner(unsigned nthreads);
 void run_block(unsigned nthreads)
+{
+#ifdef SIMT_TSAN
+    g.sched_fiber = __tsan_get_current_fiber();
+#endif
+    run_block_inner(nthreads);
+#ifdef SIMT_TSAN
+    for (unsigned i = 0; i < nthreads; i++) {
+        if (g.lanes[i].tsan_fiber) __tsan_destroy_fiber(g.lanes[i].tsan_fiber);
+        g.lanes[i].tsan_fiber = nullptr;
+    }
+#endif
+}
+void run_block_inner(unsigned nthreads)
 {
     for (unsigned i = 0; i < nthreads; i++) prepare_lane((int)i);
     thread_local std::vector<unsigned> turn;
@@ -220,6 +254,9 @@ void run_block(unsigned nthreads)
 #ifdef SIMT_ASAN
             void *fake = nullptr;
             __sanitizer_start_switch_fiber(&fake, g.stacks + (size_t)i * kStack, kStack);
+#endif
+#ifdef SIMT_TSAN
+            __tsan_switch_to_fiber(g.lanes[i].tsan_fiber, 0);
 #endif
             simt_switch(&g.sched_sp, g.lanes[i].sp);
 #ifdef SIMT_ASAN

@@ -327,6 +327,18 @@ def test_load_webgraph_from_edge_store(gpu_ctx_factory, tmp_path):
             ids, vals = ctx.results()
         assert st["n"] == fst["n"] and st["m_unique"] == fst["m_unique"] and st["m_eff"] == fst["m_eff"] and st["passes"] == fst["passes"]
         assert np.array_equal(ids, fids) and np.array_equal(vals.view(np.uint64), fvals.view(np.uint64))
+    # the many-slab hand-over (two alternating pinned buffers, reader thread ahead of the thread that feeds the library) on the same
+    # small store: 1000-record slabs instead of 4 Mi (BASELINE-size stores take this path under bench.py's end-to-end leg)
+    os.environ["HB_WEBGRAPH_SLAB_RECORDS"] = "1000"
+    try:
+        with gpu_ctx_factory() as ctx:
+            webgraph.load_webgraph(ctx, str(tmp_path / "edges"), verify_crc=True)
+            st = ctx.run()
+            ids, vals = ctx.results()
+        assert st["n"] == fst["n"] and st["m_input"] == len(e) and st["m_eff"] == fst["m_eff"] and st["passes"] == fst["passes"]
+        assert np.array_equal(ids, fids) and np.array_equal(vals.view(np.uint64), fvals.view(np.uint64))
+    finally:
+        del os.environ["HB_WEBGRAPH_SLAB_RECORDS"]
     with gpu_ctx_factory() as ctx:
         with pytest.raises(_lib.HyperballError):
             webgraph.load_webgraph(ctx, str(tmp_path / "nothing_here"))

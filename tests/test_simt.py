@@ -133,3 +133,22 @@ def test_device_sources_under_undefined_behaviour_sanitizer(simt_lib):
                        capture_output=True, text=True, env=env, cwd=ROOT, timeout=3400)
     tail = "\n".join((r.stdout + r.stderr).splitlines()[-40:])
     assert r.returncode == 0 and "runtime error" not in r.stdout + r.stderr, tail
+
+
+@pytest.mark.skipif(os.environ.get("HB_SIMT_TSAN") != "1", reason="opt-in (HB_SIMT_TSAN=1, ~2 min): the webgraph loader's threads under ThreadSanitizer")
+def test_webgraph_loader_threads_under_thread_sanitizer(simt_lib):
+    """`make tsan`: hb_load_webgraph runs three threads (a reader gathering slab k + 1 from the mapped column files, a checker
+    computing the CRC-32 of every file, the caller's thread handing slab k to the library); with HB_WEBGRAPH_SLAB_RECORDS=1000 the
+    small test store takes the many-slab path.  The interpreted kernels run on the caller's thread (lanes announced to the runtime
+    as fibers).  Round 4: no report; the runtime was checked to be live with a deliberate race."""
+    rt = _asan_runtime()
+    if rt is None:
+        pytest.skip("no sanitizer runtimes next to clang")
+    ts = os.path.join(os.path.dirname(rt), "libclang_rt.tsan-x86_64.so")
+    subprocess.check_call(["make", "-s", "-j8", "-C", SIMT, "tsan"])
+    lib = os.path.join(SIMT, "_build_tsan", "libhyperball_simt_tsan.so")
+    env = dict(_child_env(lib), LD_PRELOAD=ts, TSAN_OPTIONS="halt_on_error=1:abort_on_error=1")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu.py"), "-m", "gpu", "-q", "-x", "-s", "-k",
+                        "test_load_webgraph_from_edge_store", "-p", "no:cacheprovider"], capture_output=True, text=True, env=env, cwd=ROOT, timeout=3400)
+    tail = "\n".join((r.stdout + r.stderr).splitlines()[-40:])
+    assert r.returncode == 0 and "ThreadSanitizer" not in r.stdout + r.stderr, tail
