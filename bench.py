@@ -432,6 +432,8 @@ def main():
         td.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     from stract_amd import _lib, dist, synth
+    if hasattr(_lib.load(), "hb_simt_interpreter"):
+        raise SystemExit("bench.py measures the gfx950 library only (tests/simt is CPU-side test infrastructure, never a compute path)")
 
     if world == 1 and _lib.device_count() < 1:
         sys.exit("bench.py needs a GPU: the HyperBall library has no CPU fallback")
