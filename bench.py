@@ -103,6 +103,11 @@ def parse():
     ap.add_argument("--no-supervisor", action="store_true", help="accepted and ignored (round 3 measured in a restartable child process)")
     ap.add_argument("--legs-timeout", type=int, default=300,
                     help="N > 1, --partition both: seconds the extra partition legs may take before the line is printed without them")
+    ap.add_argument("--collectives", default="rccl", choices=["rccl", "host-staged"],
+                    help="N > 1 only.  rccl (default): one rank per GPU, the library's own RCCL exchanges = the measurement.  host-staged: "
+                         "a FUNCTIONAL run of the same N > 1 code path where N GPUs do not exist - torch.distributed over gloo, the per-pass "
+                         "exchanges through hb_set_collectives on host-staged buffers (stract_amd.dist.HostStagedCollectives), ranks share "
+                         "the devices there are; the line says so and its numbers are not a measurement")
     ap.add_argument("--flags", type=int, default=0)
     ap.add_argument("--chunk", type=int, default=0)
     ap.add_argument("--tune", default="", help="comma separated hb_options.tune values")
@@ -155,7 +160,7 @@ def measure(ctx, steps, warmup, barrier, td, torch):
     barrier()
     dt = time.perf_counter() - t0
     if td is not None:
-        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda" if td.get_backend() == "nccl" else "cpu")
         td.all_reduce(tt, op=td.ReduceOp.MAX)
         dt = float(tt.item())
     r["dt"] = dt
@@ -425,24 +430,36 @@ def main():
         import torch
         import torch.distributed as td
 
-        if not torch.cuda.is_available():
-            sys.exit("bench.py needs a GPU: the HyperBall library has no CPU fallback")
-        torch.cuda.set_device(local_rank)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        td.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if a.collectives == "host-staged":
+            td.init_process_group("gloo")
+        else:
+            if not torch.cuda.is_available():
+                sys.exit("bench.py needs a GPU: the HyperBall library has no CPU fallback")
+            torch.cuda.set_device(local_rank)
+            td.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    staged = world > 1 and a.collectives == "host-staged"
 
     from stract_amd import _lib, dist, synth
-    if hasattr(_lib.load(), "hb_simt_interpreter"):
+    if hasattr(_lib.load(), "hb_simt_interpreter") and not (staged and os.environ.get("HB_BENCH_FUNCTIONAL") == "1"):
+        # (tests/test_simt.py drives the N > 1 CONTROL FLOW of this script on the interpreted test build: functional, never a number)
         raise SystemExit("bench.py measures the gfx950 library only (tests/simt is CPU-side test infrastructure, never a compute path)")
+    ndev = _lib.device_count()
+    device = local_rank % max(ndev, 1) if staged else local_rank
+    on_cuda = torch is not None and not staged
 
     if world == 1 and _lib.device_count() < 1:
         sys.exit("bench.py needs a GPU: the HyperBall library has no CPU fallback")
     live_ctx = [None]  # the context whose stream the N = 1 barrier synchronises
 
     def barrier():
-        if torch is None:
+        if not on_cuda:
             if live_ctx[0] is not None:
                 live_ctx[0].synchronize()
+            if td is not None:
+                td.barrier()
+                if live_ctx[0] is not None:
+                    live_ctx[0].synchronize()
             return
         torch.cuda.synchronize()
         if td is not None:
@@ -462,12 +479,17 @@ def main():
         flags = a.flags
         rccl_id = None
         if world > 1:
-            rccl_id = dist.torch_unique_id(rank, world)
+            if staged:
+                flags |= _lib.HB_FLAG_NO_RCCL
+            else:
+                rccl_id = dist.torch_unique_id(rank, world)
             if partition == "dest":
                 flags |= _lib.HB_FLAG_DEST_PARTITION
             if changed_only:
                 flags |= _lib.HB_FLAG_CHANGED_ONLY
-        ctx = _lib.Context(device=local_rank, flags=flags, chunk=a.chunk, rank=rank, world_size=world, rccl_id=rccl_id, tune=tune)
+        ctx = _lib.Context(device=device, flags=flags, chunk=a.chunk, rank=rank, world_size=world, rccl_id=rccl_id, tune=tune)
+        if staged:
+            ctx._staged_collectives = dist.HostStagedCollectives(ctx)  # (kept alive with the context: it owns the callbacks)
         t0 = time.perf_counter()
         info = {"path": "hb_load_dense (bench-only export: pre-reduced CSR)"}
         if world > 1:
@@ -517,7 +539,7 @@ def main():
             "scaling": "strong",
             "vs_baseline": None,
             "dtype": "u8",
-            "data": "synthetic",
+            "data": "synthetic" if not staged else "synthetic; FUNCTIONAL RUN (--collectives host-staged: gloo + host-staged exchanges, %d device(s) for %d ranks): not a measurement" % (max(ndev, 1), world),
             "config": {"workload": "%s %s" % (a.config, label),
                        "n_hosts": n, "m_eff": m_eff, "passes_T": passes,
                        "parallelism": ("1 GPU" if world == 1 else
@@ -601,7 +623,7 @@ def main():
         g.close()
         del g
         live_ctx[0] = None
-        if torch is not None:
+        if on_cuda:
             torch.cuda.empty_cache()
         try:
             c4 = c4_leg(a)
@@ -786,7 +808,7 @@ def cpu_and_parity(a, g, ctx, td, rank, world, gpu_passes, gpu_ids, gpu_vals, gp
     k = done if (rank == 0 and parity is None) else 0
     if td is not None:
         import torch
-        need = torch.tensor([k], dtype=torch.int64, device="cuda")
+        need = torch.tensor([k], dtype=torch.int64, device="cuda" if td.get_backend() == "nccl" else "cpu")
         td.broadcast(need, src=0)
         k = int(need.item())
     if k > 0:

@@ -78,6 +78,34 @@ def test_no_dependence_on_workgroup_or_lane_order(simt_lib):
     assert r.returncode == 0 and " passed" in tail and "failed" not in tail, tail
 
 
+def test_bench_multi_rank_control_flow_on_the_interpreter(simt_lib, tmp_path):
+    """`bench.py --gpus N` for N > 1 is the script the driver launches on an 8-GPU node - a node this repository has never had.
+    `--collectives host-staged` runs the SAME code path (rendezvous, one context per rank, W + K runs bracketed by barriers, max over
+    ranks, parity at N > 1 with the collective checksum re-run, the three extra decompositions under their watchdog, the JSON line)
+    with gloo and host-staged exchanges in place of RCCL; here on the interpreted build with 2 ranks and the smallest BASELINE
+    config.  Functional only - the line says so - but a Python-level mistake in the N > 1 path would show up here."""
+    import json
+    env = dict(_child_env(simt_lib), HB_BENCH_FUNCTIONAL="1", OMP_NUM_THREADS="2")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29631",
+                        os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--config", "C1", "--collectives", "host-staged",
+                        "--cpu-seconds", "5"], capture_output=True, text=True, env=env, cwd=str(tmp_path), timeout=1500)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert r.returncode == 0 and len(lines) == 1, r.stdout[-1500:] + r.stderr[-3000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 1 and d["warmup"] == 1 and d["metric"].startswith("HyperBall") and "FUNCTIONAL RUN" in d["data"]
+    assert d["parity_bit_exact"] is True and d["config"]["parallelism"].startswith("edge-partition x2")
+    legs = d["detail"]["partitions"]
+    assert set(legs) == {"edge_changed_only", "dest_allgather", "dest_changed_only"}
+    assert all(v["same_result_as_edge_partition"] is True for v in legs.values()), legs
+    assert d["detail"]["collective"]["ran"] == "edge" and d["cpu_baseline"] is None
+    # and the script still refuses the interpreted build for anything that would look like a measurement
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--config", "C1", "--steps", "1", "--c4-leg", "off"], capture_output=True, text=True,
+                       env=_child_env(simt_lib), cwd=str(tmp_path), timeout=600)
+    assert r.returncode != 0 and "gfx950 library only" in (r.stdout + r.stderr) and not any(ln.startswith("{") for ln in r.stdout.splitlines())
+
+
 def _asan_runtime():
     r = subprocess.run([os.environ.get("CLANG", "/opt/rocm/lib/llvm/bin/clang++"), "-print-file-name=libclang_rt.asan-x86_64.so"], capture_output=True, text=True)
     path = r.stdout.strip()
