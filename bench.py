@@ -23,6 +23,8 @@ torch.distributed.run, one rank per GPU).  Prints ONE JSON line on rank 0.
               partition + ncclAllReduce(max, u8); with --partition both (default) its changed-only form, the
               destination partition (+ ncclAllGather) and its changed-only variant run as extra legs under
               detail.partitions, each with GTEPS, ms_collective, wire bytes and a same-result field.
+              --collectives host-staged: the same N > 1 path as a FUNCTIONAL run where N GPUs do not exist (gloo, host-staged
+              exchanges through hb_set_collectives, ranks share the devices there are); the line says so, its numbers are no measurement.
   c4 leg    = with the default config at N = 1 the line also carries detail.c4: BASELINE configs[3]
               (100M hosts / 2B edges) on one GPU - GTEPS, roofline fractions, parity (~2-3 min).
   end to end= N = 1, record input (default): detail.end_to_end (and detail.c4.end_to_end) = the reference command's whole chain
