@@ -5,7 +5,7 @@ Runs against whatever library HB_LIB_PATH names: the gfx950 library on a GPU box
 interpreted test build of the device sources (tests/simt, with HB_ALLOW_SIMT_INTERPRETER=1; add the AddressSanitizer preload
 for the `make asan` build).  A failure prints the seed and case that reproduce it and makes the exit code non-zero.
 
-usage: tools/diff_fuzz.py [--mode passes|records|mixed] [--seconds S] [--seed N] [--max-nodes N]"""
+usage: tools/diff_fuzz.py [--mode passes|records|tail|mixed] [--seconds S] [--seed N] [--max-nodes N]"""
 import argparse
 import json
 import os
@@ -18,6 +18,7 @@ import numpy as np  # noqa: E402
 
 from oracle import hbo  # noqa: E402
 from stract_amd import _lib  # noqa: E402
+from stract_amd.harmonic import EdgeListGraph  # noqa: E402
 from tests import graphs  # noqa: E402
 
 FLAG_POOL = ["NO_REORDER", "NO_XCD_MAP", "UNFUSED", "NO_SPARSE", "NO_FRONTIER", "PASS_STATS", "HOST_PLAN", "NO_INIT_PASS"]
@@ -152,9 +153,48 @@ def records_case(rng, max_nodes, case):
     return what
 
 
+def tail_case(rng, case):
+    """HB_FLAG_REFERENCE_TAIL: the reference's changed-node machinery as written (bloom filter, exact-counting switch, sqrt(n) tail over
+    page-level records replayed through the query's per-segment LinksScorer) on random tailed graphs (a core feeding a chain with side
+    branches, so that 0 < |changed| <= sqrt(n) happens), with a random share of the host links present at page level, duplicates of
+    documents under conflicting flags, foreign page ids, and random segment cuts; ids, values, pass count and the NUMBER OF TAIL PASSES
+    against the faithful oracle given the same records."""
+    core = int(rng.integers(20, 400))
+    host = graphs.tailed_graph(core=core, core_edges=int(rng.integers(core, min(2000, core * (core - 1) // 3))), chain=int(rng.integers(5, 160)),
+                               seed=int(rng.integers(1, 1 << 30)), branch=int(rng.integers(0, 5)))
+    e = EdgeListGraph.from_tuples(host).host_edges()
+    keep = rng.random(len(host)) < rng.choice([0.0, 0.3, 0.7, 1.0])
+    pages = [host[i] for i in np.nonzero(keep)[0].tolist()]
+    for i in np.nonzero(rng.random(len(host)) < 0.1)[0].tolist():  # duplicates of a document, some flagged, placed somewhere else
+        f, t, _ = host[i]
+        pages.insert(int(rng.integers(0, len(pages) + 1)), (f, t, int(rng.choice([0, graphs.NOFOLLOW, graphs.TAG]))))
+    for k in range(int(rng.integers(0, 6))):  # documents whose endpoints are not hosts of the graph
+        pages.append((0xDEAD0000 + k, host[int(rng.integers(0, len(host)))][1], 0))
+    recs = EdgeListGraph.from_tuples(pages).host_edges() if pages else np.zeros(0, dtype=_lib.EDGE)
+    cuts = sorted(set(int(x) for x in rng.integers(0, len(recs) + 1, int(rng.integers(0, 4)))) | {0, len(recs)})
+    segs = [b - a for a, b in zip(cuts, cuts[1:])] or [0]
+    fids, fvals, fst = hbo.faithful_run(e, recs, segs)
+    what = dict(case=case, kind="tail", hosts=int(fst["n"]), host_edges=int(len(e)), page_records=int(len(recs)), segments=segs)
+    with _lib.Context(flags=_lib.HB_FLAG_REFERENCE_TAIL | int(rng.choice([0, _lib.HB_FLAG_HOST_PLAN]))) as ctx:
+        ctx.load_edges(e)
+        at = 0
+        for length in segs:
+            for part in np.array_split(recs[at:at + length], int(rng.integers(1, 4))):
+                ctx.append_tail_edges(part)
+            ctx.tail_segment_end()
+            at += length
+        st = ctx.run()
+        ids, vals = ctx.results()
+        modes = [ps["mode"] for ps in ctx.pass_stats()]
+    assert st["passes"] == fst["passes"] and modes.count(3) == fst["passes_exact"], ("pass / tail-pass count", what, modes, fst)
+    assert np.array_equal(ids, fids) and np.array_equal(vals.view(np.uint64), fvals.view(np.uint64)), ("final list", what)
+    what.update(m=int(len(e)), passes=int(fst["passes"]), tail_passes=int(fst["passes_exact"]))
+    return what
+
+
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--mode", choices=["passes", "records", "mixed"], default="passes")
+    ap.add_argument("--mode", choices=["passes", "records", "tail", "mixed"], default="passes")
     ap.add_argument("--seconds", type=float, default=60.0)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--max-nodes", type=int, default=6000)
@@ -165,7 +205,9 @@ def main():
     case = 0
     while time.time() - t0 < a.seconds:
         try:
-            if a.mode == "records" or (a.mode == "mixed" and case % 3 == 2):
+            if a.mode == "tail" or (a.mode == "mixed" and case % 6 == 5):
+                w = tail_case(rng, case)
+            elif a.mode == "records" or (a.mode == "mixed" and case % 3 == 2):
                 w = records_case(rng, a.max_nodes, case)
             else:
                 w = one_case(rng, a.max_nodes, case)
