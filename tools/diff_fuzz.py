@@ -5,7 +5,7 @@ Runs against whatever library HB_LIB_PATH names: the gfx950 library on a GPU box
 interpreted test build of the device sources (tests/simt, with HB_ALLOW_SIMT_INTERPRETER=1; add the AddressSanitizer preload
 for the `make asan` build).  A failure prints the seed and case that reproduce it and makes the exit code non-zero.
 
-usage: tools/diff_fuzz.py [--mode passes|records|tail|mixed] [--seconds S] [--seed N] [--max-nodes N]"""
+usage: tools/diff_fuzz.py [--mode passes|records|tail|ranks|mixed] [--seconds S] [--seed N] [--max-nodes N]"""
 import argparse
 import json
 import os
@@ -192,9 +192,60 @@ def tail_case(rng, case):
     return what
 
 
+def ranks_case(rng, max_nodes, case):
+    """The multi-rank decompositions with R = 2..5 LOGICAL ranks on one device (the collective emulated by hb_debug_exchange): edge
+    partition (all-reduce(max)), its changed-only form, destination partition (all-gather of the owned slices), its changed-only form;
+    random graphs and layout knobs; after every pass all ranks must hold the oracle's registers, at the end the oracle's final list."""
+    from stract_amd import dist
+    kind, edges = graphs.random_graph(rng) if rng.random() < 0.5 else big_graph(rng, max(200, max_nodes // 3))
+    if not edges:
+        return None
+    ids, row_ptr, src = graphs.dense_from_tuples(edges)
+    world = int(rng.integers(2, 6))
+    mode = str(rng.choice(["edge", "edge_changed", "dest", "dest_changed"]))
+    flags = _lib.HB_FLAG_NO_RCCL | (_lib.HB_FLAG_DEST_PARTITION if mode.startswith("dest") else 0) | (_lib.HB_FLAG_CHANGED_ONLY if mode.endswith("_changed") else 0)
+    chunk = int(rng.choice([8, 16, 64]))
+    tune = (0, 0, int(rng.choice([0, 101])), int(rng.integers(4, 9)), int(rng.integers(1, 9)))
+    what = dict(case=case, kind="ranks:" + kind, n=int(len(ids)), m=int(len(src)), world=world, mode=mode, chunk=chunk, tune=tune)
+    o = hbo.Dense(ids["lo"].copy(), row_ptr, src)
+    split = dist.partition_dense_by_dest if mode.startswith("dest") else dist.partition_dense
+    ctxs = []
+    try:
+        for r in range(world):
+            c = _lib.Context(rank=r, world_size=world, flags=flags, chunk=chunk, tune=tune)
+            ctxs.append(c)
+            rp, sr = split(row_ptr, src, r, world)
+            c.load_dense(ids, rp, sr)
+            c.begin()
+        has, t = True, 0
+        while has:
+            for c in ctxs:
+                c.step_local()
+            _lib.Context.exchange(ctxs, 0)
+            out = [c.step_finish() for c in ctxs]
+            ohas, _ = o.step(hbo.FRONTIER)
+            assert len(set(out)) == 1 and out[0] == ohas, ("has_changes after pass %d" % t, what)
+            has = out[0]
+            want = o.registers()
+            for r, c in enumerate(ctxs):
+                assert np.array_equal(c.registers(), want), ("registers of rank %d after pass %d" % (r, t), what)
+            t += 1
+        _lib.Context.exchange(ctxs, 1)
+        vals, keep, k = o.finish()
+        for r, c in enumerate(ctxs):
+            c.finish()
+            gids, gvals = c.results()
+            assert len(gvals) == k and np.array_equal(gids, ids[keep]) and np.array_equal(gvals.view(np.uint64), vals[keep].view(np.uint64)), ("final list of rank %d" % r, what)
+    finally:
+        for c in ctxs:
+            c.close()
+    what["passes"] = t
+    return what
+
+
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--mode", choices=["passes", "records", "tail", "mixed"], default="passes")
+    ap.add_argument("--mode", choices=["passes", "records", "tail", "ranks", "mixed"], default="passes")
     ap.add_argument("--seconds", type=float, default=60.0)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--max-nodes", type=int, default=6000)
@@ -205,7 +256,9 @@ def main():
     case = 0
     while time.time() - t0 < a.seconds:
         try:
-            if a.mode == "tail" or (a.mode == "mixed" and case % 6 == 5):
+            if a.mode == "ranks" or (a.mode == "mixed" and case % 6 == 4):
+                w = ranks_case(rng, a.max_nodes, case)
+            elif a.mode == "tail" or (a.mode == "mixed" and case % 6 == 5):
                 w = tail_case(rng, case)
             elif a.mode == "records" or (a.mode == "mixed" and case % 3 == 2):
                 w = records_case(rng, a.max_nodes, case)
