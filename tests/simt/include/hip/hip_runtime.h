@@ -96,7 +96,7 @@ static __forceinline__ int __ffsll(long long v) { return __builtin_ffsll(v); }
 static __forceinline__ int __clz(int v) { return v ? __builtin_clz((unsigned)v) : 32; }
 static __forceinline__ int __clzll(long long v) { return v ? __builtin_clzll((unsigned long long)v) : 64; }
 
-// ---- atomics (one OS thread runs a launch: plain read-modify-write) -----------------------------------------------
+// ---- atomics ----------------------------------------------------------------------------------------------------------
 #ifndef __HIP_MEMORY_SCOPE_AGENT
 #define __HIP_MEMORY_SCOPE_SINGLETHREAD 1
 #define __HIP_MEMORY_SCOPE_WAVEFRONT 2
@@ -118,47 +118,35 @@ static __forceinline__ T simt_lds_fetch_max(T *p, U v)
     return old;
 }
 #define __hip_atomic_fetch_max(p, v, order, scope) simt_lds_fetch_max((p), (v))
+// real (relaxed) atomics: the workgroups of a launch may run on several host threads (HB_SIMT_THREADS, simt_core.cpp)
 template <class T, class U>
-static __forceinline__ T atomicAdd(T *p, U v)
-{
-    const T old = *p;
-    *p = old + (T)v;
-    return old;
-}
+static __forceinline__ T atomicAdd(T *p, U v) { return __atomic_fetch_add(p, (T)v, __ATOMIC_RELAXED); }
 template <class T, class U>
-static __forceinline__ T atomicOr(T *p, U v)
-{
-    const T old = *p;
-    *p = old | (T)v;
-    return old;
-}
+static __forceinline__ T atomicOr(T *p, U v) { return __atomic_fetch_or(p, (T)v, __ATOMIC_RELAXED); }
 template <class T, class U>
-static __forceinline__ T atomicAnd(T *p, U v)
-{
-    const T old = *p;
-    *p = old & (T)v;
-    return old;
-}
+static __forceinline__ T atomicAnd(T *p, U v) { return __atomic_fetch_and(p, (T)v, __ATOMIC_RELAXED); }
 template <class T, class U>
 static __forceinline__ T atomicMax(T *p, U v)
 {
-    const T old = *p;
-    if ((T)v > old) *p = (T)v;
+    T old = __atomic_load_n(p, __ATOMIC_RELAXED);
+    while ((T)v > old && !__atomic_compare_exchange_n(p, &old, (T)v, true, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {
+    }
     return old;
 }
 template <class T, class U>
 static __forceinline__ T atomicMin(T *p, U v)
 {
-    const T old = *p;
-    if ((T)v < old) *p = (T)v;
+    T old = __atomic_load_n(p, __ATOMIC_RELAXED);
+    while ((T)v < old && !__atomic_compare_exchange_n(p, &old, (T)v, true, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {
+    }
     return old;
 }
 template <class T, class U, class V>
 static __forceinline__ T atomicCAS(T *p, U cmp, V v)
 {
-    const T old = *p;
-    if (old == (T)cmp) *p = (T)v;
-    return old;
+    T expected = (T)cmp;
+    __atomic_compare_exchange_n(p, &expected, (T)v, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED);
+    return expected; // the value found
 }
 template <class T>
 static __forceinline__ T __builtin_nontemporal_load_simt(const T *p) { return *p; }

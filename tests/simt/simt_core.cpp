@@ -6,7 +6,10 @@
 #include <cstdio>
 #include <cstdlib>
 #include <algorithm>
+#include <condition_variable>
 #include <cstring>
+#include <mutex>
+#include <thread>
 #include <vector>
 
 #if !defined(__x86_64__)
@@ -35,14 +38,6 @@ asm(".text\n"
 #endif
 #endif
 
-// ThreadSanitizer build (`make tsan`): every lane is a fiber the runtime must know about
-#if defined(__has_feature)
-#if __has_feature(thread_sanitizer)
-#define SIMT_TSAN 1
-#include <sanitizer/tsan_interface.h>
-#endif
-#endif
-
 namespace simt {
 thread_local Idx threadIdx_, blockIdx_, blockDim_, gridDim_;
 
@@ -50,9 +45,6 @@ namespace {
 constexpr size_t kStack = 512 * 1024;
 enum State { RUN, WAIT, DONE };
 struct Lane {
-#ifdef SIMT_TSAN
-    void *tsan_fiber = nullptr;
-#endif
     void *sp = nullptr;
     State st = DONE;
     int kind = 0;
@@ -64,9 +56,6 @@ struct Run {
     char *stacks = nullptr;
     size_t nstacks = 0;
     void *sched_sp = nullptr;
-#ifdef SIMT_TSAN
-    void *sched_fiber = nullptr;
-#endif
     int cur = -1;
     const std::function<void()> *body = nullptr;
 };
@@ -89,9 +78,6 @@ void to_scheduler(void **save_sp, bool final_switch)
 #ifdef SIMT_ASAN
     void *fake = nullptr;
     __sanitizer_start_switch_fiber(final_switch ? nullptr : &fake, g_sched_bottom, g_sched_size);
-#endif
-#ifdef SIMT_TSAN
-    __tsan_switch_to_fiber(g.sched_fiber, 0);
 #endif
     simt_switch(save_sp, g.sched_sp);
 #ifdef SIMT_ASAN
@@ -124,9 +110,6 @@ void prepare_lane(int i)
     for (int k = 0; k < 6; k++) *--sp = 0; // rbp rbx r12 r13 r14 r15
     g.lanes[i].sp = sp;
     g.lanes[i].st = RUN;
-#ifdef SIMT_TSAN
-    g.lanes[i].tsan_fiber = __tsan_create_fiber(0);
-#endif
 }
 
 // serve the lanes of wave [w0, w1) that wait at the lowest code address
@@ -150,8 +133,8 @@ bool serve_wave(int w0, int w1)
             members++;
         }
     }
-    if (members < live) g_stats.partial_groups++;
-    g_stats.collectives++;
+    if (members < live) __atomic_fetch_add(&g_stats.partial_groups, 1, __ATOMIC_RELAXED);
+    __atomic_fetch_add(&g_stats.collectives, 1, __ATOMIC_RELAXED);
     uint64_t ballot = 0;
     if (kind == K_BALLOT)
         for (int i = w0; i < w1; i++)
@@ -176,7 +159,7 @@ bool serve_wave(int w0, int w1)
             res[l] = g.lanes[w0 + src].value;
         } else { // the machine returns 0 for a DPP read of an inactive lane (bound_ctrl) and the own value for a shuffle out of range
             res[l] = kind == K_DPP ? 0 : L.value;
-            if (src != l) g_stats.reads_of_inactive_lanes++;
+            if (src != l) __atomic_fetch_add(&g_stats.reads_of_inactive_lanes, 1, __ATOMIC_RELAXED);
         }
     }
     for (int i = w0; i < w1; i++)
@@ -203,20 +186,22 @@ struct Order {
             if (e[7] == ':') state ^= std::strtoull(e + 8, nullptr, 10) * 0xD1B54A32D192ED03ull;
         }
     }
-    uint64_t next()
+    static uint64_t next(uint64_t &st)
     {
-        state ^= state << 13;
-        state ^= state >> 7;
-        state ^= state << 17;
-        return state;
+        st ^= st << 13;
+        st ^= st >> 7;
+        st ^= st << 17;
+        return st;
     }
-    void fill(std::vector<unsigned> &v, unsigned n)
+    // `st`: the generator to draw from (the launching thread's for the workgroup order, every host thread's own for the lanes)
+    void fill(std::vector<unsigned> &v, unsigned n, uint64_t &st) const
     {
         v.resize(n);
         for (unsigned i = 0; i < n; i++) v[i] = mode == 1 ? n - 1 - i : i;
         if (mode == 2)
-            for (unsigned i = n; i > 1; i--) std::swap(v[i - 1], v[(unsigned)(next() % i)]);
+            for (unsigned i = n; i > 1; i--) std::swap(v[i - 1], v[(unsigned)(next(st) % i)]);
     }
+    void fill(std::vector<unsigned> &v, unsigned n) { fill(v, n, state); }
 };
 Order &order()
 {
@@ -224,28 +209,15 @@ Order &order()
     return o;
 }
 
-void run_block_inner(unsigned nthreads);
 void run_block(unsigned nthreads)
-{
-#ifdef SIMT_TSAN
-    g.sched_fiber = __tsan_get_current_fiber();
-#endif
-    run_block_inner(nthreads);
-#ifdef SIMT_TSAN
-    for (unsigned i = 0; i < nthreads; i++) {
-        if (g.lanes[i].tsan_fiber) __tsan_destroy_fiber(g.lanes[i].tsan_fiber);
-        g.lanes[i].tsan_fiber = nullptr;
-    }
-#endif
-}
-void run_block_inner(unsigned nthreads)
 {
     for (unsigned i = 0; i < nthreads; i++) prepare_lane((int)i);
     thread_local std::vector<unsigned> turn;
-    order().fill(turn, nthreads);
+    thread_local uint64_t lane_rng = order().state ^ ((uint64_t)(uintptr_t)&turn * 0x9E3779B97F4A7C15ull) ^ 0x1234567ull;
+    order().fill(turn, nthreads, lane_rng);
     for (;;) {
         bool ran = false;
-        if (order().mode == 2) order().fill(turn, nthreads);
+        if (order().mode == 2) order().fill(turn, nthreads, lane_rng);
         for (unsigned k = 0; k < nthreads; k++) {
             const unsigned i = turn[k];
             if (g.lanes[i].st != RUN) continue;
@@ -254,9 +226,6 @@ void run_block_inner(unsigned nthreads)
 #ifdef SIMT_ASAN
             void *fake = nullptr;
             __sanitizer_start_switch_fiber(&fake, g.stacks + (size_t)i * kStack, kStack);
-#endif
-#ifdef SIMT_TSAN
-            __tsan_switch_to_fiber(g.lanes[i].tsan_fiber, 0);
 #endif
             simt_switch(&g.sched_sp, g.lanes[i].sp);
 #ifdef SIMT_ASAN
@@ -297,10 +266,11 @@ uint64_t collective(int kind, uint64_t value, uint64_t arg)
     return g.lanes[g.cur].result;
 }
 
-void launch(unsigned grid, unsigned block, const std::function<void()> &body)
+namespace {
+// the workgroups [next, grid) of one launch, drawn by whoever is free
+void run_blocks(unsigned grid, unsigned block, const std::function<void()> &body, const std::vector<unsigned> &blocks, unsigned *next)
 {
     if (g.cur >= 0) die("nested launch");
-    if (block == 0 || grid == 0) return;
     if (g.nstacks < block) {
         if (g.stacks) munmap(g.stacks, g.nstacks * kStack);
         g.stacks = (char *)mmap(nullptr, (size_t)block * kStack, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
@@ -312,13 +282,11 @@ void launch(unsigned grid, unsigned block, const std::function<void()> &body)
     const Idx keep_t = threadIdx_, keep_b = blockIdx_, keep_bd = blockDim_, keep_gd = gridDim_;
     blockDim_ = Idx{block, 1, 1};
     gridDim_ = Idx{grid, 1, 1};
-    g_stats.launches++;
-    std::vector<unsigned> blocks;
-    order().fill(blocks, grid);
-    for (unsigned k = 0; k < grid; k++) {
-        const unsigned b = blocks[k];
-        blockIdx_ = Idx{b, 0, 0};
-        g_stats.blocks++;
+    for (;;) {
+        const unsigned k = __atomic_fetch_add(next, 1u, __ATOMIC_RELAXED);
+        if (k >= grid) break;
+        blockIdx_ = Idx{blocks[k], 0, 0};
+        __atomic_fetch_add(&g_stats.blocks, 1, __ATOMIC_RELAXED);
         run_block(block);
     }
     g.cur = -1;
@@ -327,6 +295,89 @@ void launch(unsigned grid, unsigned block, const std::function<void()> &body)
     blockIdx_ = keep_b;
     blockDim_ = keep_bd;
     gridDim_ = keep_gd;
+}
+} // namespace
+
+// HB_SIMT_THREADS=N (default 1): the workgroups of a launch are shared out among N host threads, i.e. they really run at the same
+// time - with the ThreadSanitizer build (`make tsan`) every pair of conflicting non-atomic accesses of two workgroups of one
+// launch is reported as the data race it would be on the machine.  (The launch still returns only when all its workgroups are done.)
+// The N - 1 helpers are started once and wait for work.
+namespace {
+struct Pool {
+    std::mutex mu;
+    std::condition_variable cv_work, cv_done;
+    std::vector<std::thread> threads;
+    uint64_t generation = 0;
+    unsigned busy = 0;
+    // the current launch
+    unsigned grid = 0, block = 0, next = 0;
+    const std::function<void()> *body = nullptr;
+    const std::vector<unsigned> *blocks = nullptr;
+
+    void helper()
+    {
+        uint64_t seen = 0;
+        for (;;) {
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv_work.wait(lk, [&] { return generation != seen; });
+                seen = generation;
+            }
+            run_blocks(grid, block, *body, *blocks, &next);
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                if (--busy == 0) cv_done.notify_all();
+            }
+        }
+    }
+    void run(unsigned helpers, unsigned g_, unsigned b_, const std::function<void()> &f, const std::vector<unsigned> &order_)
+    {
+        while (threads.size() < helpers) {
+            threads.emplace_back([this] { helper(); });
+            threads.back().detach();
+        }
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            grid = g_;
+            block = b_;
+            next = 0;
+            body = &f;
+            blocks = &order_;
+            busy = (unsigned)threads.size();
+            generation++;
+        }
+        cv_work.notify_all();
+        run_blocks(g_, b_, f, order_, &next);
+        std::unique_lock<std::mutex> lk(mu);
+        cv_done.wait(lk, [&] { return busy == 0; });
+    }
+};
+Pool &pool()
+{
+    static Pool *p = new Pool(); // never destroyed: its detached helpers outlive main()
+    return *p;
+}
+} // namespace
+
+void launch(unsigned grid, unsigned block, const std::function<void()> &body)
+{
+    if (block == 0 || grid == 0) return;
+    static const unsigned nthreads = [] {
+        const char *e = std::getenv("HB_SIMT_THREADS");
+        const long v = e ? std::atol(e) : 1;
+        return (unsigned)(v < 1 ? 1 : v > 64 ? 64 : v);
+    }();
+    __atomic_fetch_add(&g_stats.launches, 1, __ATOMIC_RELAXED);
+    std::vector<unsigned> blocks;
+    order().fill(blocks, grid);
+    if (nthreads == 1) {
+        unsigned next = 0;
+        run_blocks(grid, block, body, blocks, &next);
+        return;
+    }
+    static std::mutex one_launch_at_a_time; // (host threads of the library may launch concurrently; the pool serves one launch)
+    std::lock_guard<std::mutex> lk(one_launch_at_a_time);
+    pool().run(nthreads - 1, grid, block, body, blocks);
 }
 
 Stats &stats() { return g_stats; }

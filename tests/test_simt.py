@@ -70,7 +70,7 @@ def test_no_dependence_on_workgroup_or_lane_order(simt_lib):
     workgroup consuming what another has not produced yet, a lane reading LDS before its neighbour wrote it - would differ from the
     oracle here.  All per-pass variants under a shuffled order (the whole interpretable suite was run under reverse, shuffle:1 and
     shuffle:2 in round 4: 69 passed each)."""
-    env = dict(_child_env(simt_lib), HB_SIMT_ORDER="shuffle:7")
+    env = dict(_child_env(simt_lib), HB_SIMT_ORDER="shuffle:7", HB_SIMT_THREADS="3")  # ... and three host threads share the workgroups: they overlap in time
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu.py"), "-m", "gpu", "-q", "-x", "-k",
                         "test_per_pass_state_matches_oracle or test_sweep_seeds_with_very_long_reader_lists or test_gpu_ingest_equals_host_ingest",
                         "-p", "no:cacheprovider"], capture_output=True, text=True, env=env, cwd=ROOT, timeout=1700)
@@ -163,20 +163,37 @@ def test_device_sources_under_undefined_behaviour_sanitizer(simt_lib):
     assert r.returncode == 0 and "runtime error" not in r.stdout + r.stderr, tail
 
 
-@pytest.mark.skipif(os.environ.get("HB_SIMT_TSAN") != "1", reason="opt-in (HB_SIMT_TSAN=1, ~2 min): the webgraph loader's threads under ThreadSanitizer")
-def test_webgraph_loader_threads_under_thread_sanitizer(simt_lib):
-    """`make tsan`: hb_load_webgraph runs three threads (a reader gathering slab k + 1 from the mapped column files, a checker
-    computing the CRC-32 of every file, the caller's thread handing slab k to the library); with HB_WEBGRAPH_SLAB_RECORDS=1000 the
-    small test store takes the many-slab path.  The interpreted kernels run on the caller's thread (lanes announced to the runtime
-    as fibers).  Round 4: no report; the runtime was checked to be live with a deliberate race."""
+@pytest.mark.skipif(os.environ.get("HB_SIMT_TSAN") != "1", reason="opt-in (HB_SIMT_TSAN=1, ~10 min): ThreadSanitizer over concurrently running workgroups and the loader's threads")
+def test_kernels_and_loader_under_thread_sanitizer(simt_lib):
+    """`make tsan` + HB_SIMT_THREADS=4: the workgroups of every launch are shared out among four host threads, i.e. they really run at
+    the same time, and ThreadSanitizer sees every access of every kernel: two workgroups touching one address without atomics would
+    be reported as the data race it is on the machine (workgroups run in no order and share nothing but global memory).  First the
+    detector itself (tests/simt/race_selftest.cpp: a plain read-modify-write of one counter by all workgroups must be reported, the
+    atomicAdd form must not).  Then the interpretable GPU suite.  The same build covers hb_load_webgraph's own threads (reader /
+    checksum / hand-over, many-slab path).  Round 4: no report in any kernel or in the loader (libgomp-run test-support code is
+    suppressed: tests/simt/tsan.supp)."""
     rt = _asan_runtime()
     if rt is None:
         pytest.skip("no sanitizer runtimes next to clang")
     ts = os.path.join(os.path.dirname(rt), "libclang_rt.tsan-x86_64.so")
     subprocess.check_call(["make", "-s", "-j8", "-C", SIMT, "tsan"])
-    lib = os.path.join(SIMT, "_build_tsan", "libhyperball_simt_tsan.so")
-    env = dict(_child_env(lib), LD_PRELOAD=ts, TSAN_OPTIONS="halt_on_error=1:abort_on_error=1")
+    clang = os.environ.get("CLANG", "/opt/rocm/lib/llvm/bin/clang++")
+    bdir = os.path.join(SIMT, "_build_tsan")
+    subprocess.check_call([clang, "-x", "c++", "-std=c++17", "-O0", "-g", "-fsanitize=thread", "-fno-omit-frame-pointer", "-I", os.path.join(SIMT, "include"),
+                           "-c", os.path.join(SIMT, "race_selftest.cpp"), "-o", os.path.join(bdir, "race_selftest.o")])
+    exe = os.path.join(bdir, "race_selftest")
+    subprocess.check_call([clang, "-fsanitize=thread", "-shared-libsan", os.path.join(bdir, "race_selftest.o"), os.path.join(bdir, "simt_core.o"),
+                           os.path.join(bdir, "simt_runtime.o"), "-o", exe, "-Wl,-rpath," + os.path.dirname(rt), "-lpthread"])
+    env = dict(os.environ, HB_SIMT_THREADS="4")
+    quiet = subprocess.run([exe], capture_output=True, text=True, env=env, timeout=300)
+    assert quiet.returncode == 0 and "ThreadSanitizer" not in quiet.stderr and quiet.stdout.strip() == "atomic 327680", quiet.stdout + quiet.stderr[-2000:]
+    loud = subprocess.run([exe, "racy"], capture_output=True, text=True, env=env, timeout=300)
+    assert "ThreadSanitizer: data race" in loud.stderr and "count_kernel" in loud.stderr, loud.stderr[-2000:]
+    lib = os.path.join(bdir, "libhyperball_simt_tsan.so")
+    env = dict(_child_env(lib), LD_PRELOAD=ts, HB_SIMT_THREADS="4", HB_SIMT_CUS="4",
+               TSAN_OPTIONS="halt_on_error=1:abort_on_error=1:suppressions=" + os.path.join(SIMT, "tsan.supp"))
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu.py"), "-m", "gpu", "-q", "-x", "-s", "-k",
-                        "test_load_webgraph_from_edge_store", "-p", "no:cacheprovider"], capture_output=True, text=True, env=env, cwd=ROOT, timeout=3400)
+                        "not test_c2 and not test_caching_allocator_under_memory_pressure and not test_multi_process", "-p", "no:cacheprovider"],
+                       capture_output=True, text=True, env=env, cwd=ROOT, timeout=3400)
     tail = "\n".join((r.stdout + r.stderr).splitlines()[-40:])
     assert r.returncode == 0 and "ThreadSanitizer" not in r.stdout + r.stderr, tail
