@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define HB_ABI_VERSION 4
+#define HB_ABI_VERSION 5
 
 /* ---- error codes -------------------------------------------------------------- */
 #define HB_OK 0
@@ -163,6 +163,10 @@ typedef struct hb_stats {
                                    from the runtime during the load: the live bytes plus freed extents it kept for reuse
                                    (kept only while the device has room: above half of the device memory - or
                                    HB_POOL_LIMIT_BYTES - free blocks go back to the runtime before a new one is taken) */
+    uint64_t result_stages;     /* [ABI 5] snapshots of the per-node sums that went to the host WHILE the passes of the last run
+                                   were still running (second stream; single rank, n >= 2^20): hb_finish then ships only ... */
+    uint64_t result_list;       /* [ABI 5] ... this many (node, value) entries that still moved afterwards (0 stages: the whole
+                                   n x 8-byte image is downloaded by hb_finish, as before)                                      */
 } hb_stats;
 
 typedef struct hb_pass_stats {

@@ -88,6 +88,8 @@ class HbStats(ctypes.Structure):
         ("wire_bytes", ctypes.c_uint64),
         ("ingest_peak_bytes", ctypes.c_uint64),
         ("pool_peak_bytes", ctypes.c_uint64),
+        ("result_stages", ctypes.c_uint64),
+        ("result_list", ctypes.c_uint64),
     ]
 
     def as_dict(self):

@@ -14,6 +14,7 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "hb_internal.h"
@@ -136,6 +137,23 @@ struct hb_ctx {
     double *h_out = nullptr; // pinned, n entries
     uint64_t h_out_len = 0;
     uint64_t res_count = 0;
+    // results that travel while the passes still run (results_stage below; hb_aux.hip.h results_sync_kernel)
+    struct ResultSync {
+        bool on = false;          // this graph ships its results in stages (single rank, large enough or forced by tune[1] bit 15)
+        bool valid = false;       // d_out / d_sent (and h_out, once `copied` has fired) hold one consistent snapshot of the sums
+        uint64_t changed_since = 0; // counters changed since that snapshot (= sums that moved, give or take a `+= 0.0` flush)
+        uint32_t stages = 0;      // snapshots shipped during the current run
+        double *d_sent = nullptr; // device order: the sum out[] was last built from
+        uint32_t *d_sid = nullptr; // the final list: (sid, value) of what moved after the last snapshot
+        double *d_val = nullptr;
+        unsigned long long *d_count = nullptr;
+        uint32_t *h_sid = nullptr; // pinned
+        double *h_val = nullptr;
+        unsigned long long *h_count = nullptr;
+        uint64_t cap = 0;
+        hipStream_t stream = nullptr;                 // the snapshots' downloads run here, beside the passes
+        hipEvent_t ready = nullptr, copied = nullptr; // out[] built (main stream) / downloaded (side stream)
+    } rs;
 };
 
 namespace {
@@ -222,6 +240,18 @@ void free_graph_buffers(hb_ctx *c)
     if (c->h_out) (void)hipHostFree(c->h_out);
     c->h_out = nullptr;
     c->h_out_len = 0;
+    if (c->rs.stream) (void)hipStreamSynchronize(c->rs.stream);
+    for (void *q : {(void *)c->rs.h_sid, (void *)c->rs.h_val, (void *)c->rs.h_count})
+        if (q) (void)hipHostFree(q);
+    c->rs.h_sid = nullptr;
+    c->rs.h_val = nullptr;
+    c->rs.h_count = nullptr;
+    c->rs.d_sent = nullptr;
+    c->rs.d_sid = nullptr;
+    c->rs.d_val = nullptr;
+    c->rs.d_count = nullptr;
+    c->rs.cap = 0;
+    c->rs.on = c->rs.valid = false;
 }
 
 // hb_options.chunk / tune[3..5] -> planner knobs
@@ -465,6 +495,9 @@ int hb_create(const hb_options *opt, hb_ctx **out)
         for (int i = 0; i < 6; i++)
             if (hipEventCreate(&ctx->ev[i]) != hipSuccess) { ctx->err = "hipEventCreate failed"; return bail(HB_ERR_HIP); }
         if (hipHostMalloc((void **)&ctx->h_counters, hbk::kCounterWords * sizeof(unsigned long long)) != hipSuccess) { ctx->err = "hipHostMalloc failed"; return bail(HB_ERR_NOMEM); }
+        if (hipStreamCreateWithFlags(&ctx->rs.stream, hipStreamNonBlocking) != hipSuccess ||
+            hipEventCreateWithFlags(&ctx->rs.ready, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&ctx->rs.copied, hipEventDisableTiming) != hipSuccess) { ctx->err = "hipStreamCreate / hipEventCreate failed"; return bail(HB_ERR_HIP); }
         if ((o.world_size > 1 && !(o.flags & HB_FLAG_NO_RCCL)) || (o.flags & HB_FLAG_RCCL_SELF)) {
             if (hipStreamCreateWithFlags(&ctx->comm_stream, hipStreamNonBlocking) != hipSuccess) { ctx->err = "hipStreamCreate failed"; return bail(HB_ERR_HIP); }
             for (int i = 0; i < hb_ctx::kOverlap; i++)
@@ -509,6 +542,9 @@ void hb_destroy(hb_ctx *ctx)
         (void)hipStreamSynchronize(ctx->comm_stream);
         (void)hipStreamDestroy(ctx->comm_stream);
     }
+    if (ctx->rs.ready) (void)hipEventDestroy(ctx->rs.ready);
+    if (ctx->rs.copied) (void)hipEventDestroy(ctx->rs.copied);
+    if (ctx->rs.stream) (void)hipStreamDestroy(ctx->rs.stream);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -890,6 +926,10 @@ int hb_begin(hb_ctx *c)
             c->exact_counting = c->exact_valid = c->stale = false;
         }
         HB_HIP(hipStreamSynchronize(c->stream));
+        if (c->rs.stream) HB_HIP(hipStreamSynchronize(c->rs.stream)); // (a download of an abandoned run)
+        c->rs.valid = false;
+        c->rs.changed_since = 0;
+        c->rs.stages = 0;
         c->t = 0;
         c->cur = 0;
         c->wire_bytes = 0;
@@ -954,15 +994,62 @@ int hb_finish(hb_ctx *c)
         const double norm = (double)(p.n ? p.n - 1 : 0);
         unsigned long long *cnt = c->d_counters + (size_t)c->max_passes * hbk::kCounterWords; // the spare slot
         HB_HIP(hipMemsetAsync(cnt, 0, hbk::kCounterWords * sizeof(unsigned long long), c->stream));
-        if (p.n) {
+        bool shipped = false;
+        if (p.n && c->rs.on && c->rs.valid) {
+            // the bulk is already on the host (results_stage): what moved since follows as a (sid, value) list
+            auto &rs = c->rs;
+            HB_HIP(hipMemsetAsync(rs.d_count, 0, sizeof(unsigned long long), c->stream));
+            HB_HIP(hipStreamWaitEvent(c->stream, rs.copied, 0)); // out[] is rewritten: its download must be over
+            const unsigned blocks = (unsigned)std::min<uint64_t>((p.n_pad + 2047) / 2048, (uint64_t)c->num_cu * 8);
+            hipLaunchKernelGGL(hbk::results_sync_kernel, dim3(blocks), dim3(256), 0, c->stream, (const double *)c->d_ksum, rs.d_sent,
+                               (const uint32_t *)c->d_sid_of, p.n_pad, norm, 0, c->d_out, rs.d_sid, rs.d_val, (unsigned long long)rs.cap, rs.d_count, cnt);
+            HB_HIP(hipGetLastError());
+            HB_HIP(hipMemcpyAsync(rs.h_count, rs.d_count, sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+            HB_HIP(hipMemcpyAsync(c->h_counters, cnt, hbk::kCounterWords * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+            HB_HIP(hipStreamSynchronize(c->stream));
+            const uint64_t moved = *rs.h_count;
+            if (moved <= rs.cap) {
+                if (moved) {
+                    HB_HIP(hipMemcpyAsync(rs.h_sid, rs.d_sid, moved * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+                    HB_HIP(hipMemcpyAsync(rs.h_val, rs.d_val, moved * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+                    HB_HIP(hipStreamSynchronize(c->stream));
+                }
+                // (the snapshot's download is over: the main stream waited for `copied` above)
+                double *out = c->h_out;
+                const uint32_t *ls = rs.h_sid;
+                const double *lv = rs.h_val;
+                auto apply = [out, ls, lv](uint64_t lo, uint64_t hi) {
+                    for (uint64_t k = lo; k < hi; k++) out[ls[k]] = lv[k];
+                };
+                const uint64_t nthr = moved >= (1u << 16) ? std::min<uint64_t>(8, std::max(1u, std::thread::hardware_concurrency())) : 1;
+                if (nthr > 1) { // every sid occurs once: the shares are independent
+                    std::vector<std::thread> pool;
+                    for (uint64_t k = 1; k < nthr; k++) pool.emplace_back(apply, moved * k / nthr, moved * (k + 1) / nthr);
+                    apply(0, moved / nthr);
+                    for (auto &th : pool) th.join();
+                } else {
+                    apply(0, moved);
+                }
+            } else { // more moved than the list holds: out[] on the device is complete anyway, ship it whole
+                HB_HIP(hipMemcpyAsync(c->h_out, c->d_out, p.n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+                HB_HIP(hipStreamSynchronize(c->stream));
+            }
+            shipped = true;
+        }
+        if (p.n && !shipped) {
             unsigned blocks = (unsigned)std::min<uint64_t>((p.n + 255) / 256, (uint64_t)c->num_cu * 8);
             hipLaunchKernelGGL(hbk::finish_kernel, dim3(blocks), dim3(256), 0, c->stream, (const double *)c->d_ksum,
                                (const uint32_t *)c->d_dev_of, p.n, norm, c->d_out, cnt);
             HB_HIP(hipGetLastError());
             HB_HIP(hipMemcpyAsync(c->h_out, c->d_out, p.n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
         }
-        HB_HIP(hipMemcpyAsync(c->h_counters, cnt, hbk::kCounterWords * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
-        HB_HIP(hipStreamSynchronize(c->stream));
+        if (!shipped) {
+            HB_HIP(hipMemcpyAsync(c->h_counters, cnt, hbk::kCounterWords * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+            HB_HIP(hipStreamSynchronize(c->stream));
+        }
+        c->stats.result_stages = c->rs.stages;
+        c->stats.result_list = shipped ? *c->rs.h_count : 0;
+        c->rs.valid = false;
         c->res_count = 0;
         for (int s = 0; s < hbk::kStripes; s++) c->res_count += c->h_counters[4 * s];
         c->stats.ms_d2h = now_ms() - t0;

@@ -209,26 +209,112 @@ __global__ __launch_bounds__(256) void tail_merge_kernel(const uint32_t *list, c
 }
 
 // ---- normalize_centralities (harmonic.rs:178-195) -----------------------------------------
-// out[sid] for sid in ascending-NodeID order: f64::from(KahanSum) = sum (kahan_sum.rs:35-39);
-// kept iff > 0.0, then / norm, non-finite -> 0.0; absent nodes are marked -1.0.
+// f64::from(KahanSum) = sum (kahan_sum.rs:35-39); kept iff > 0.0, then / norm, non-finite -> 0.0; absent nodes are marked -1.0.
+__device__ __forceinline__ double normalized_centrality(double s, double norm, bool &kept)
+{
+    double v = -1.0;
+    kept = s > 0.0;
+    if (kept) {
+        v = s / norm;
+        if (!(fabs(v) <= 1.7976931348623157e308)) v = 0.0; // is_finite
+    }
+    return v;
+}
+// out[sid] for sid in ascending-NodeID order
 __global__ __launch_bounds__(256) void finish_kernel(const double *ksum, const uint32_t *dev_of, uint64_t n,
                                                      double norm, double *out, unsigned long long *count)
 {
     unsigned long long kept = 0;
     for (uint64_t sid = (uint64_t)blockIdx.x * 256 + threadIdx.x; sid < n; sid += (uint64_t)gridDim.x * 256) {
-        const double s = ksum[dev_of[sid]];
-        double v = -1.0;
-        if (s > 0.0) {
-            v = s / norm;
-            if (!(fabs(v) <= 1.7976931348623157e308)) v = 0.0; // is_finite
-            kept++;
-        }
-        out[sid] = v;
+        bool k;
+        out[sid] = normalized_centrality(ksum[dev_of[sid]], norm, k);
+        kept += k;
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) kept += __shfl_down(kept, off);
     const unsigned long long v[4] = {kept, 0, 0, 0};
     block_add_counters(count, v, 0x1u); // striped: the host sums word 0 of every stripe
+}
+
+// ---- results that travel while the passes still run (hb_api.hip: results_stage / hb_finish) --------------------------------
+// The host needs one f64 per node at the end (HarmonicCentrality's map); a download of n x 8 bytes AFTER the last pass is
+// 7-8 % of a whole run at BASELINE sizes (C4: 794 MB = 14 ms over the link against 212 ms).  Most nodes' sums are final long
+// before the loop ends (a node's sum stops moving one pass after its counter does), so the bulk is shipped on a second stream
+// while the next pass runs, and what still moved afterwards follows as a short list.  `sent[row]` = the sum (device order)
+// the host-bound image `out` (ascending-NodeID order, normalised) was last built from.  One streaming pass in DEVICE order:
+// rows whose sum differs bitwise from sent[] (all rows when `all`) refresh out[sid] and sent[], and - if a list is wanted - are
+// appended as (sid, value); a block reserves list space once per 2048 rows (same-address atomics sustain ~90/us).
+// counts[0] = entries appended (may exceed cap: the list is then incomplete and the caller ships `out` whole).
+// kept (word 0 of the striped `count`) = nodes with centrality > 0 among ALL rows = the result count.
+constexpr int kSyncPerThread = 8;
+__global__ __launch_bounds__(256) void results_sync_kernel(const double *ksum, double *sent, const uint32_t *sid_of, uint64_t n_pad, double norm,
+                                                           int all, double *out, uint32_t *list_sid, double *list_val, unsigned long long cap,
+                                                           unsigned long long *counts, unsigned long long *count)
+{
+    __shared__ uint32_t s_wave[4];
+    __shared__ unsigned long long s_base;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    unsigned long long kept = 0;
+    const uint64_t span = 256ull * kSyncPerThread;
+    for (uint64_t base = (uint64_t)blockIdx.x * span; base < n_pad; base += (uint64_t)gridDim.x * span) { // block-uniform trip count
+        uint32_t mask = 0, sid[kSyncPerThread];
+        double val[kSyncPerThread];
+#pragma unroll
+        for (int j = 0; j < kSyncPerThread; j++) {
+            const uint64_t row = base + (uint64_t)j * 256 + threadIdx.x;
+            sid[j] = kNone;
+            val[j] = 0.0;
+            if (row < n_pad) {
+                const uint32_t sd = sid_of[row];
+                if (sd != kNone) {
+                    const double s = ksum[row];
+                    bool k;
+                    const double v = normalized_centrality(s, norm, k);
+                    kept += k;
+                    if (all || __double_as_longlong(s) != __double_as_longlong(sent[row])) {
+                        sent[row] = s;
+                        out[sd] = v;
+                        mask |= 1u << j;
+                        sid[j] = sd;
+                        val[j] = v;
+                    }
+                }
+            }
+        }
+        if (list_sid) {
+            const uint32_t mine = __popc(mask);
+            uint32_t incl = mine;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const uint32_t a = __shfl_up(incl, off);
+                if (lane >= off) incl += a;
+            }
+            if (lane == 63) s_wave[wave] = incl;
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                const uint32_t tot = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+                s_base = tot ? atomicAdd(counts, (unsigned long long)tot) : 0ull;
+            }
+            __syncthreads();
+            unsigned long long pos = s_base + (incl - mine);
+            for (int w = 0; w < wave; w++) pos += s_wave[w];
+#pragma unroll
+            for (int j = 0; j < kSyncPerThread; j++) {
+                if ((mask >> j) & 1u) {
+                    if (pos < cap) {
+                        list_sid[pos] = sid[j];
+                        list_val[pos] = val[j];
+                    }
+                    pos++;
+                }
+            }
+            __syncthreads(); // s_wave / s_base are rewritten by the next iteration
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) kept += __shfl_down(kept, off);
+    const unsigned long long v[4] = {kept, 0, 0, 0};
+    block_add_counters(count, v, 0x1u);
 }
 
 // Order-independent checksums of the state (hb_debug_state_hash; same function as

@@ -102,7 +102,8 @@ unsigned grid_for(uint64_t count) { return (unsigned)std::min<uint64_t>(std::max
 // slot state lives in the pid array: kEmpty, kBusy (claimed, key not yet published), else the pid.  An insert claims an
 // empty slot with ONE compare-and-swap, writes the key, then publishes the pid; a reader that sees a pid may read the key.
 // Nothing ever spins INSIDE an iteration: a lane that finds kBusy simply goes round the loop again, by which time the
-// claiming lane - which runs straight-line code to the publishing store - is done even if it sits in the same wave.
+// claiming lane - which runs straight-line code to the publishing store inside the same iteration - is done even if it sits
+// in the same wave (the loop's only exit is wave-uniform, see table_get).
 //
 // Visibility across the 8 XCDs (their L2s are not coherent with each other, /opt/skills/guides/MI355X_MICROARCH.md
 // "inter-workgroup visibility"): EVERY access to a slot - id word and both key halves, readers and writers - is an 8-byte-or-
@@ -136,32 +137,46 @@ struct Table {
     unsigned long long *counter; // pids handed out so far
 };
 
-// pid of `key`, inserted with the next free pid if absent (want_pid == kEmpty) or with want_pid (rehash)
+// pid of `key`, inserted with the next free pid if absent (want_pid == kEmpty) or with want_pid (rehash).
+// Progress does not depend on where the compiler places a block: the loop has ONE exit and its condition is
+// wave-uniform (a ballot over the lanes still searching), so no lane leaves early and there is no exit block the publishing
+// stores could be sunk into - a lane that claimed a slot publishes it inside the iteration, in straight-line code in front of the
+// ballot every lane of the wave takes part in, and a lane of the same wave that saw kBusy finds the pid on its next turn.
+// (The earlier form returned from inside the loop; that it worked rested on the publishing block staying in the loop body.)
 __device__ __forceinline__ uint32_t table_get(const Table &t, u128 key, uint32_t want_pid)
 {
     const unsigned long long klo = (unsigned long long)key, khi = (unsigned long long)(key >> 64);
     unsigned long long *halves = (unsigned long long *)t.keys; // slot s: halves[2 s] = low, halves[2 s + 1] = high 64 bits
     uint64_t slot = slot_hash(key) & t.mask;
-    for (;;) {
-        const uint32_t s = __hip_atomic_load(&t.pids[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (s == kEmpty) {
-            const uint32_t old = atomicCAS(&t.pids[slot], kEmpty, kBusy);
-            if (old == kEmpty) {
-                __hip_atomic_store(&halves[2 * slot], klo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(&halves[2 * slot + 1], khi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const uint32_t pid = want_pid != kEmpty ? want_pid : (uint32_t)atomicAdd(t.counter, 1ull);
-                HB_DRAIN_VMEM(); // the key has left this CU before the id does
-                __hip_atomic_store(&t.pids[slot], pid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                return pid;
+    uint32_t result = kEmpty;
+    bool searching = true;
+    do {
+        if (searching) {
+            const uint32_t s = __hip_atomic_load(&t.pids[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (s == kEmpty) {
+                // (a lost race: somebody else claimed it first - read the slot again on the next turn)
+                if (atomicCAS(&t.pids[slot], kEmpty, kBusy) == kEmpty) {
+                    __hip_atomic_store(&halves[2 * slot], klo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(&halves[2 * slot + 1], khi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const uint32_t pid = want_pid != kEmpty ? want_pid : (uint32_t)atomicAdd(t.counter, 1ull);
+                    HB_DRAIN_VMEM(); // the key has left this CU before the id does
+                    __hip_atomic_store(&t.pids[slot], pid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    result = pid;
+                    searching = false;
+                }
+            } else if (s != kBusy) { // (kBusy = being published: the same slot again on the next turn)
+                const unsigned long long lo = __hip_atomic_load(&halves[2 * slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const unsigned long long hi = __hip_atomic_load(&halves[2 * slot + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (lo == klo && hi == khi) {
+                    result = s;
+                    searching = false;
+                } else {
+                    slot = (slot + 1) & t.mask;
+                }
             }
-            continue; // somebody else claimed it first: read the slot again
         }
-        if (s == kBusy) continue; // being published: same slot again
-        const unsigned long long lo = __hip_atomic_load(&halves[2 * slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const unsigned long long hi = __hip_atomic_load(&halves[2 * slot + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (lo == klo && hi == khi) return s;
-        slot = (slot + 1) & t.mask;
-    }
+    } while (__ballot(searching) != 0ull);
+    return result;
 }
 
 __global__ __launch_bounds__(256) void table_clear_kernel(uint32_t *pids, uint64_t slots)

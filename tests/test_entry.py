@@ -36,6 +36,33 @@ def test_bench_help_lists_the_contract_flags():
         assert flag in r.stdout
 
 
+def test_bench_line_at_one_gpu_is_the_scaling_runs_first_point(monkeypatch):
+    """The driver takes BENCH from `bench.py --steps K --warmup W` and the first point of the scaling curve from `bench.py --gpus 1
+    --steps K --warmup W`; efficiency at N > 1 is computed against that point.  Both must be the SAME measurement of the SAME
+    workload - BASELINE.json configs[3] (C4: the graph the north-star target is quoted on, 100M hosts / 2B edges) - and N > 1 must
+    run that workload too (strong scaling), with the north-star decomposition (edge partition + all-reduce) as `value`."""
+    import json
+
+    import bench
+    from stract_amd import synth
+
+    monkeypatch.delenv("HB_BENCH_CONFIG", raising=False)
+    monkeypatch.delenv("HB_BENCH_INPUT", raising=False)
+
+    def args(*argv):
+        monkeypatch.setattr(sys, "argv", ["bench.py", *argv])
+        return vars(bench.parse())
+
+    plain, one, eight = args("--steps", "20", "--warmup", "5"), args("--gpus", "1", "--steps", "20", "--warmup", "5"), args("--gpus", "8", "--steps", "20", "--warmup", "5")
+    assert plain == one
+    assert {k: v for k, v in eight.items() if k != "gpus"} == {k: v for k, v in one.items() if k != "gpus"}
+    assert one["config"] == "C4" and one["partition"] == "both" and one["parity"] == "auto" and one["input"] == "records"
+    base = json.load(open(os.path.join(ROOT, "BASELINE.json")))
+    assert "100M-host / 2B-edge" in base["configs"][3] and synth.CONFIGS["C4"]["label"] == "100M-host / 2B-edge"
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert 'main_part = "single" if world == 1 else ("dest" if a.partition == "dest" else "edge")' in src  # `value` at N > 1 = edge partition
+
+
 @pytest.mark.gpu
 def test_smoke_entry_point():
     import __graft_entry__ as g

@@ -197,10 +197,18 @@ VARIANTS = {
 }
 
 
+# round 5: the results travel in stages while the passes run (hb_api_pass.inc results_stage); bit 15 = a snapshot after EVERY pass
+# whatever the graph's size, bit 17 = only the first snapshot, bit 16 = a final list of 16 entries (with bit 17: it overflows and the
+# whole image is shipped instead)
+VARIANTS["staged_results_every_pass"] = dict(tune=(0, 0x8000))
+VARIANTS["staged_results_one_snapshot"] = dict(tune=(0, 0x28000))
+VARIANTS["staged_results_sweep_tiny_list"] = dict(chunk=8, tune=(0, 0x38000, 101, 0, 0, 0, 1))
+VARIANTS["staged_results_off"] = dict(tune=(0, 0x4000))
 EXPECT_MODES = {"frontier_always": {0, 1}, "frontier_always_slot_by_slot": {0, 1}, "frontier_always_multilevel": {0, 1}, "sparse_always_multilevel": {0, 2},
                 "long_tail_default": {0, 2}}
 VARIANTS["long_tail_default"] = dict()
 VARIANTS["long_tail_chunk8"] = dict(chunk=8)
+VARIANTS["long_tail_staged_results"] = dict(tune=(0, 0x8000))
 
 
 @pytest.mark.parametrize("variant", sorted(VARIANTS))
@@ -241,7 +249,19 @@ def test_per_pass_state_matches_oracle(gpu_ctx_factory, variant):
             t += 1
         ctx.finish()
         vals, keep, k = o.finish()
-        _check_final(ctx, g.ids, t, vals, keep, ctx.stats())
+        st = ctx.stats()
+        _check_final(ctx, g.ids, t, vals, keep, st)
+        if "staged_results" in variant:
+            on = variant != "staged_results_off"
+            assert (st["result_stages"] >= 1) == on, st
+            if "every_pass" in variant or variant == "long_tail_staged_results":
+                assert st["result_stages"] == t - 1 and st["result_list"] <= g.n, st  # (no snapshot after the pass that ends the loop)
+            if "one_snapshot" in variant:
+                assert st["result_stages"] == 1 and 16 < st["result_list"] <= g.n, st  # everything that moved after pass 0
+            if "tiny_list" in variant:
+                assert st["result_stages"] == 1 and st["result_list"] > 16, st         # ... and did not fit: the image went whole
+            ranks = ctx.ranks()
+            assert np.array_equal(ranks, hbo.rank_results(vals[keep])), variant          # the device image the ranks are cut from is final too
         if variant in EXPECT_MODES:
             assert EXPECT_MODES[variant] <= modes, (variant, modes)
 

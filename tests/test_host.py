@@ -26,7 +26,7 @@ def test_header_symbols_all_exported():
     assert not missing, missing
     # and the Python binding covers exactly the declared set
     assert declared == set(_lib.SYMBOLS)
-    assert _lib.load().hb_abi_version() == 4
+    assert _lib.load().hb_abi_version() == 5
 
 
 def test_headers_are_plain_c99_and_struct_sizes_agree(tmp_path):
@@ -50,7 +50,7 @@ def test_headers_are_plain_c99_and_struct_sizes_agree(tmp_path):
 def test_struct_layouts_match_header():
     assert ctypes.sizeof(_lib.HbOptions) == 4 * 7 + 128 + 32
     assert _lib.EDGE.itemsize == 40 and _lib.U128.itemsize == 16
-    assert ctypes.sizeof(_lib.HbStats) == 25 * 8  # ABI 4: + pool_peak_bytes
+    assert ctypes.sizeof(_lib.HbStats) == 27 * 8  # ABI 5: + result_stages, result_list
     assert ctypes.sizeof(_lib.HbPassStats) == 4 * 8 + 6 * 4
 
 

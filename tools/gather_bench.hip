@@ -52,7 +52,27 @@ __global__ __launch_bounds__(256) void gather_kernel(const uint32_t *idx, const 
             uint4 r[UNROLL][4];
 #pragma unroll
             for (int u = 0; u < UNROLL; u++) {
-                if (MODE == 2) { // two adjacent counters (one 128-B line) per index: idx pairs (2k, 2k+1)
+                if (MODE == 5) { // round 5: HALF a counter per gather (32 B per quad, 8 B per lane): is the miss path a request limit
+                                 // whatever the size (then a 32-B compressed counter buys nothing), or does 32 B go faster?
+                    const uint2 *h = (const uint2 *)regs;
+                    const uint2 v0 = h[(uint64_t)qb<0>(id[u]) * 8 + q], v1 = h[(uint64_t)qb<1>(id[u]) * 8 + q];
+                    const uint2 v2 = h[(uint64_t)qb<2>(id[u]) * 8 + q], v3 = h[(uint64_t)qb<3>(id[u]) * 8 + q];
+                    r[u][0] = make_uint4(v0.x, v0.y, 0, 0);
+                    r[u][1] = make_uint4(v1.x, v1.y, 0, 0);
+                    r[u][2] = make_uint4(v2.x, v2.y, 0, 0);
+                    r[u][3] = make_uint4(v3.x, v3.y, 0, 0);
+                } else if (MODE == 6) { // round 5: NEIGHBOURING QUADS of a wave gather the two halves of one 128-B line in the same
+                                        // instruction (quad 2k takes the even counter of quad 2k's index, quad 2k+1 its line mate):
+                                        // does the texture addresser merge them into one request like the same-quad pair of MODE 2?
+                    const uint32_t odd = (lane >> 2) & 1u;
+                    uint32_t a[4] = {qb<0>(id[u]), qb<1>(id[u]), qb<2>(id[u]), qb<3>(id[u])};
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        const uint32_t mine = a[j], other = (uint32_t)__shfl_xor((int)mine, 4); // the neighbouring quad's index
+                        const uint32_t base = (odd ? other : mine) & ~1u;
+                        r[u][j] = regs[(uint64_t)(base | odd) * 4 + q];
+                    }
+                } else if (MODE == 2) { // two adjacent counters (one 128-B line) per index: idx pairs (2k, 2k+1)
                     const uint32_t a0 = qb<0>(id[u]) & ~1u, a1 = qb<2>(id[u]) & ~1u;
                     r[u][0] = regs[(uint64_t)a0 * 4 + q];
                     r[u][1] = regs[(uint64_t)a0 * 4 + 4 + q];
@@ -122,7 +142,7 @@ int main(int argc, char **argv)
                     {"window_4MiB_in_8GiB", 1ull << 16, 4}, {"window_32MiB_in_8GiB", 1ull << 19, 4}, {"window_256MiB_in_8GiB", 1ull << 22, 4},
                     {"window_1GiB_in_8GiB", 1ull << 24, 4}};
     for (const Case &c : cases) {
-        if (only[0] && strcmp(only, c.name)) continue;
+        if (only[0] && !strstr(only, c.name)) continue; // argv[1]: comma-separated case names; argv[2]: first variant
         uint64_t s = 42;
         if (c.perm == 1) {
             // exactly-once: a random permutation of all 2^27 blocks (multiplicative + xor shuffle)
@@ -143,7 +163,7 @@ int main(int argc, char **argv)
             for (uint64_t i = 0; i < rows * deg; i++) idx[i] = (uint32_t)(sm(s) & (c.region - 1));
         }
         CK(hipMemcpy(d_idx, idx.data(), rows * deg * 4, hipMemcpyHostToDevice));
-        for (int variant = 0; variant < 6; variant++) {
+        for (int variant = (argc > 2 ? atoi(argv[2]) : 0); variant < 8; variant++) {
             const int unroll = variant;
             float best = 1e9f;
             for (int it = 0; it < 3; it++) {
@@ -154,7 +174,9 @@ int main(int argc, char **argv)
                 else if (variant == 2) hipLaunchKernelGGL((gather_kernel<8, 0>), g, b2, 0, 0, d_idx, regs, out, rows, deg);
                 else if (variant == 3) hipLaunchKernelGGL((gather_kernel<4, 1>), g, b2, 0, 0, d_idx, regs, out, rows, deg);
                 else if (variant == 4) hipLaunchKernelGGL((gather_kernel<4, 2>), g, b2, 0, 0, d_idx, regs, out, rows, deg);
-                else hipLaunchKernelGGL((gather_kernel<4, 0>), dim3(4096), b2, 0, 0, d_idx, regs, out, rows, deg);
+                else if (variant == 5) hipLaunchKernelGGL((gather_kernel<4, 0>), dim3(4096), b2, 0, 0, d_idx, regs, out, rows, deg);
+                else if (variant == 6) hipLaunchKernelGGL((gather_kernel<4, 5>), g, b2, 0, 0, d_idx, regs, out, rows, deg);
+                else hipLaunchKernelGGL((gather_kernel<4, 6>), g, b2, 0, 0, d_idx, regs, out, rows, deg);
                 CK(hipEventRecord(b));
                 CK(hipEventSynchronize(b));
                 float ms;
@@ -162,7 +184,7 @@ int main(int argc, char **argv)
                 if (ms < best) best = ms;
             }
             double gathered = (double)rows * deg * 64, index = (double)rows * deg * 4, wr = (double)rows * 64;
-            static const char *vn[] = {"u2", "u4", "u8", "u4-nt", "u4-pair128", "u4-grid4096"};
+            static const char *vn[] = {"u2", "u4", "u8", "u4-nt", "u4-pair128", "u4-grid4096", "u4-half32", "u4-quadpair128"};
             printf("%-16s %-12s (%d): %8.3f ms  gathered %7.1f GB/s  (+idx+out %7.1f GB/s)  %.2f Ggather/s\n", c.name, vn[variant], unroll,
                    best, gathered / best / 1e6, (gathered + index + wr) / best / 1e6, rows * deg / best / 1e6);
         }

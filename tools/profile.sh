@@ -12,7 +12,7 @@ OUT=$ROOT/gpurun_out/prof_${TAG}_${CFG}
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 # the resident-graph loop only: pre-reduced input, no C4 leg, no CPU baseline
-BENCH="python $ROOT/bench.py --config $CFG --steps 2 --warmup 1 --cpu-seconds 0 --input dense --c4-leg off $*"
+BENCH="python $ROOT/bench.py --config $CFG --steps 2 --warmup 1 --cpu-seconds 0 --input dense --c4-leg off --c3-leg off $*"
 timeout 900 rocprofv3 --kernel-trace --stats -d "$OUT/trace" -o trace -- $BENCH > "$OUT/trace.log" 2>&1
 # SQ pass (8 slots): issue / wait breakdown of every kernel (quad-cycles; WAIT_ANY + WAIT_INST_ANY + ACTIVE_INST_ANY ~ WAVE_CYCLES)
 # PMC_SMALL=1: only the HBM bytes and the L2 hit rate (big configs: every pass re-runs the whole bench)
