@@ -11,7 +11,7 @@
  * (register-wise max, hyperloglog.rs:4531-4535) and the action is `Merged` iff the stored value changed, else
  * `NoChange`.  This header is the C ABI a GPU worker would put behind those three calls: the counters of a shard
  * live in HBM as one 64-byte block each, the merge / changed detection runs in a HIP kernel (one quad per key,
- * the key's pairs applied in batch order), the key -> slot map stays on the host.
+ * the key's pairs applied in batch order), the key -> slot index is a device hash table (hb_table.hip.h) since round 5.
  * Raft replication, the network protocol and the other upsert operators are out of scope.
  *
  * extern "C", never unwinds, 0 = ok, negative = HB_ERR_* of hyperball.h; needs a gfx950 device (no CPU fallback).

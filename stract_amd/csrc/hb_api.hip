@@ -1115,16 +1115,38 @@ int hb_result_copy(hb_ctx *c, hb_u128 *ids, double *vals, uint64_t cap)
     return guarded(c, [&]() -> int {
         if (!c) return HB_ERR_INVALID;
         if (!c->finished) return fail(c, HB_ERR_INVALID, "no results: hb_run / hb_finish not called");
-        // compaction of the per-node array (absent = negative) into the caller's buffers
+        // compaction of the per-node array (absent = negative) into the caller's buffers, on the host cores the process may use
+        // (C4: 99 M nodes -> 79 M results = 1.9 GB written; one thread took 1.3 s of the 15 s chain store -> load -> run -> store)
         const uint64_t n = c->plan.n;
-        uint64_t k = 0;
-        for (uint64_t sid = 0; sid < n && k < cap; sid++) {
-            const double v = c->h_out[sid];
-            if (v < 0.0) continue;
-            if (ids) ids[k] = c->g.ids[sid];
-            if (vals) vals[k] = v;
-            k++;
-        }
+        const double *src = c->h_out;
+        const hb_u128 *idsrc = c->g.ids.data();
+        const uint64_t nthr = n >= (1u << 18) ? std::min<uint64_t>(16, std::max(1u, std::thread::hardware_concurrency())) : 1;
+        std::vector<uint64_t> first(nthr + 1, 0);
+        auto share = [&](uint64_t k) { return n * k / nthr; };
+        auto count_share = [&](uint64_t k) {
+            uint64_t kept = 0;
+            for (uint64_t sid = share(k); sid < share(k + 1); sid++) kept += src[sid] >= 0.0;
+            first[k + 1] = kept;
+        };
+        auto copy_share = [&](uint64_t k) {
+            uint64_t at = first[k];
+            for (uint64_t sid = share(k); sid < share(k + 1) && at < cap; sid++) {
+                const double v = src[sid];
+                if (v < 0.0) continue;
+                if (ids) ids[at] = idsrc[sid];
+                if (vals) vals[at] = v;
+                at++;
+            }
+        };
+        auto on_all = [&](auto &&f) {
+            std::vector<std::thread> pool;
+            for (uint64_t k = 1; k < nthr; k++) pool.emplace_back(f, k);
+            f(0);
+            for (auto &th : pool) th.join();
+        };
+        on_all(count_share);
+        for (uint64_t k = 0; k < nthr; k++) first[k + 1] += first[k];
+        on_all(copy_share);
         return HB_OK;
     });
 }

@@ -591,6 +591,55 @@ def test_ampc_counter_table_upsert_semantics(gpu_ctx_factory):
         assert np.array_equal(changed, np.any(o.registers() != regs0, axis=1))
 
 
+def test_ampc_device_key_index_growth_duplicates_and_absent_keys(gpu_ctx_factory):
+    """Round 5: the key -> slot index of the counter shard is a device hash table (hb_table.hip.h, the ingest's endpoint table).
+    A table created for 4 keys takes 40 000 (the index is rebuilt several times, ids kept), batches in which one key occurs
+    hundreds of times (its pairs must be applied in batch order: the action codes say so), keys that differ in one half only,
+    consecutive small integers (no clustering), lookups of keys that were never stored, an empty batch, and - after all that -
+    every stored counter equals the model's."""
+    from stract_amd import ampc
+    rng = np.random.default_rng(5)
+    kid = lambda k: (int(k["hi"]) << 64) | int(k["lo"])
+    space = np.zeros(40_000, dtype=_lib.U128)
+    space["lo"][:20_000] = np.arange(20_000, dtype=np.uint64)            # consecutive integers
+    space["lo"][20_000:30_000] = 7                                        # same low half, different high halves
+    space["hi"][20_000:30_000] = np.arange(1, 10_001, dtype=np.uint64)
+    space["lo"][30_000:] = rng.integers(0, 1 << 63, 10_000, dtype=np.uint64)
+    space["hi"][30_000:] = rng.integers(0, 1 << 63, 10_000, dtype=np.uint64)
+    model = {}
+    with ampc.CounterTable(capacity_hint=4) as tab:
+        assert len(tab) == 0
+        tab.batch_set(space[:0], np.zeros((0, 64), np.uint8))             # an empty batch is fine
+        got, found = tab.batch_get(space[:100])
+        assert not found.any() and not got.any()                           # nothing stored yet: default counters
+        for step, n in enumerate((1, 70, 5_000, 60_000, 9_000)):
+            hot = rng.integers(0, len(space), 3)                           # three keys take a fifth of the batch
+            idx = np.where(rng.random(n) < 0.2, hot[rng.integers(0, 3, n)], rng.integers(0, min(len(space), 40 * n + 10), n))
+            keys, vals = space[idx], graphs.random_registers(rng, n)
+            acts = tab.batch_upsert(keys, vals)
+            want = np.empty(n, dtype=np.uint8)
+            for j, (k, v) in enumerate(zip(keys, vals)):
+                old = model.get(kid(k))
+                if old is None:
+                    model[kid(k)] = v.copy()
+                    want[j] = ampc.INSERTED
+                else:
+                    merged = np.maximum(old, v)
+                    want[j] = ampc.MERGED if not np.array_equal(merged, old) else ampc.NO_CHANGE
+                    model[kid(k)] = merged
+            assert np.array_equal(acts, want), step
+            assert len(tab) == len(model), step
+        got, found = tab.batch_get(space)
+        stored = np.array([kid(k) in model for k in space])
+        assert np.array_equal(found, stored)
+        want = np.stack([model.get(kid(k), np.zeros(64, np.uint8)) for k in space])
+        assert np.array_equal(got, want)
+        with pytest.raises(_lib.HyperballError):
+            tab.lib.hbu_batch_upsert.argtypes  # noqa: B018 (attribute exists)
+            tab._check(tab.lib.hbu_batch_upsert(tab.h, None, None, 5, None))  # NULL with a count: refused, table untouched
+        assert len(tab) == len(model)
+
+
 # ---- device planner ------------------------------------------------------------------------------
 def test_device_plan_equals_host_plan(gpu_ctx_factory):
     """hb_plan.hip (rocPRIM sorts / scans on the device) must reproduce build_plan() of hb_host.cpp entry for entry:

@@ -145,6 +145,38 @@ def test_random_dictionaries_and_segmentations(tmp_path):
             assert np.array_equal(r.read(a, b - a), e[a:b])
 
 
+def test_u128_raw_codec_datasets_of_the_reference(tmp_path):
+    """crates/tantivy/src/columnar/column_values/u128_based/tests.rs: the value sets the reference runs through its `Raw` u128
+    codec (the only codec its columnar writer emits for NodeID columns, column/serialize.rs:23,51) - test_serialize_and_load_simple
+    (:5-14), test_empty_column_u128 (:17-32), test_small_raw_example (:123-126), get_codec_test_datasets (:150-172) and the three
+    families of num_strategy (:136-142: values hugging u128::MAX, values hugging 0, anything) - as NodeID columns of an edge store,
+    read back by the native reader.  The reference holds no byte vectors for this codec (its tests are round trips through its
+    own reader), so this pins coverage, not bytes: every value class its tests name must survive OUR writer restatement + reader."""
+    rng = np.random.default_rng(17)
+    top = (1 << 128) - 1
+    datasets = [[1, 2, 5], [], [9223372036854775808, 9223370937344622593], list(range(10, 10_001)), [5, 6, 7, 8, 9, 10, 99, 100],
+                [5, 50, 3, 13, 1, 1000, 35], [10], [1572656989877777, 1170935903116329, 720575940379279, 0],
+                [top - int(x) % 10 for x in rng.integers(0, 1 << 62, 40)], [int(x) % 10 for x in rng.integers(0, 1 << 62, 40)],
+                [(int(a) << 64) | int(b) for a, b in zip(rng.integers(0, 1 << 63, 5000, dtype=np.uint64) * 2 + 1, rng.integers(0, 1 << 63, 5000, dtype=np.uint64))]]
+    parts = []
+    for vals in datasets:
+        e = np.zeros(len(vals), dtype=_lib.EDGE)
+        for i, v in enumerate(vals):
+            w = vals[len(vals) - 1 - i]
+            e["from"]["lo"][i], e["from"]["hi"][i] = v & 0xFFFFFFFFFFFFFFFF, v >> 64
+            e["to"]["lo"][i], e["to"]["hi"][i] = w & 0xFFFFFFFFFFFFFFFF, w >> 64
+            e["rel_flags"][i] = (v ^ (v >> 64)) & 0xFFFFFFFFFFFFFFFF
+        parts.append(e)
+    tf.write_edge_store(str(tmp_path / "edges"), parts)
+    with webgraph.EdgeStoreReader(str(tmp_path / "edges"), verify_crc=True) as r:
+        assert r.num_segments() == len(parts) and r.total_rows() == sum(len(p_) for p_ in parts)
+        got = r.read()
+    at = 0
+    for e in parts:
+        assert np.array_equal(got[at:at + len(e)], e)
+        at += len(e)
+
+
 def test_page_level_id_columns(tmp_path):
     """HBW_PAGE_IDS: the documents' page-level `from_id` / `to_id` (webgraph/schema.rs:132-180) next to the host-level
     ids - what the reference's tail mode queries (harmonic.rs:82-87)."""
