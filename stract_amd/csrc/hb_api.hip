@@ -147,12 +147,13 @@ struct hb_ctx {
         uint32_t *d_sid = nullptr; // the final list: (sid, value) of what moved after the last snapshot
         double *d_val = nullptr;
         unsigned long long *d_count = nullptr;
+        unsigned long long *d_kept = nullptr; // kCounterWords scratch words of the snapshots' kernel (side stream)
         uint32_t *h_sid = nullptr; // pinned
         double *h_val = nullptr;
         unsigned long long *h_count = nullptr;
         uint64_t cap = 0;
-        hipStream_t stream = nullptr;                 // the snapshots' downloads run here, beside the passes
-        hipEvent_t ready = nullptr, copied = nullptr; // out[] built (main stream) / downloaded (side stream)
+        hipStream_t stream = nullptr;                 // the snapshots (kernel + download) run here, beside the passes
+        hipEvent_t ready = nullptr, copied = nullptr; // copied: the last snapshot is on the host (ready: unused since the kernel moved to the side stream)
     } rs;
 };
 
@@ -250,6 +251,7 @@ void free_graph_buffers(hb_ctx *c)
     c->rs.d_sid = nullptr;
     c->rs.d_val = nullptr;
     c->rs.d_count = nullptr;
+    c->rs.d_kept = nullptr;
     c->rs.cap = 0;
     c->rs.on = c->rs.valid = false;
 }
