@@ -353,15 +353,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((REAL && UN
         const bool self_prev = (prev16 >> g) & 1u;
         const bool kd = (kd16 >> g) & 1u;
         const bool need = valid;
-        (void)self_prev;
         const uint4 accv = acc_value(acc);
         const bool lane_diff = need && (!REAL || u4_ne(accv, selfv));
         const uint64_t bal = __ballot(lane_diff);
         const bool changed = ((bal >> qshift) & 0xFull) != 0;
         if (REAL) {
-            // lazy double buffer: wr[row] already holds the right value unless the row changed
-            // in this or in the previous pass
-            if (need) st_stream(&p.wr[row * 4 + q], accv);
+            // lazy double buffer: wr[row] already holds the right value unless the row changed in this or in the previous pass
+            // [r5: used by the fused dense pass too - a fifth of the hosts of an R-MAT graph have no in-link at all and never
+            // change: 64 B per such row and pass that nobody needs; the unfused forms store every row: the exchanges read them]
+            if (need && (!FUSED || INIT || changed || self_prev || p.t_plus_1 == 1.0)) st_stream(&p.wr[row * 4 + q], accv); // (pass 0 fills the other buffer)
         } else {
             if (changed) st_stream(&p.part[(row - p.n_pad) * 4 + q], accv);
         }
