@@ -194,6 +194,11 @@ int  hb_create(const hb_options *opt, hb_ctx **out);
 void hb_destroy(hb_ctx *ctx);
 /* Message of the last failing call on ctx (or of hb_create when ctx == NULL). */
 const char *hb_last_error(const hb_ctx *ctx);
+/* [ABI 5] The library allocates device memory through a caching allocator (freed extents are kept for the next load: hipMalloc /
+ * hipFree cost ~60 ms per GB cycled on these boxes); other allocators in the process (RCCL, torch, rocPRIM users) cannot reclaim
+ * what it holds on their own out-of-memory.  This returns every cached block of the CURRENT device that no context uses to the
+ * runtime (hb_destroy does the same); *released = bytes given back (may be NULL). */
+int hb_release_cached_memory(uint64_t *released);
 
 /* ---- graph input --------------------------------------------------------------------- */
 /* Replaces the per-pass `graph.host_nodes()` / `graph.host_edges()` streaming

@@ -121,6 +121,7 @@ _P = ctypes.c_void_p
 _U64 = ctypes.c_uint64
 _SIGNATURES = [
     ("hb_abi_version", ctypes.c_int, []),
+    ("hb_release_cached_memory", ctypes.c_int, [ctypes.c_void_p]),
     ("hb_create", ctypes.c_int, [ctypes.POINTER(HbOptions), ctypes.POINTER(_P)]),
     ("hb_destroy", None, [_P]),
     ("hb_last_error", ctypes.c_char_p, [_P]),

@@ -152,8 +152,8 @@ struct hb_ctx {
         double *h_val = nullptr;
         unsigned long long *h_count = nullptr;
         uint64_t cap = 0;
-        hipStream_t stream = nullptr;                 // the snapshots (kernel + download) run here, beside the passes
-        hipEvent_t ready = nullptr, copied = nullptr; // copied: the last snapshot is on the host (ready: unused since the kernel moved to the side stream)
+        hipStream_t stream = nullptr;                 // the snapshots' downloads run here, beside the passes
+        hipEvent_t ready = nullptr, copied = nullptr; // out[] built (main stream) / downloaded (side stream)
     } rs;
 };
 
@@ -551,6 +551,18 @@ void hb_destroy(hb_ctx *ctx)
     delete ctx;
 }
 
+int hb_release_cached_memory(uint64_t *released)
+{
+    try {
+        const size_t before = HB_POOL_RESERVED();
+        HB_POOL_TRIM();
+        if (released) *released = (uint64_t)(before - std::min<size_t>(before, HB_POOL_RESERVED()));
+        return HB_OK;
+    } catch (...) {
+        return HB_ERR_NOMEM;
+    }
+}
+
 int hb_device_name(const hb_ctx *ctx, char *name, uint64_t cap)
 {
     if (!ctx || !name || !cap) return HB_ERR_INVALID;
@@ -586,7 +598,11 @@ int hb_load_edges(hb_ctx *c, const hb_u128 *node_ids, uint64_t n, const hb_edge 
         if (!on_host) {
             size_t free_b = 0, total_b = 0;
             // held: 9 B per record + the endpoint table; sort: 16 B per record; ~60 B per node while the ids are sorted
-            const double need = 18.0 * (double)m + 48.0 * (double)((node_ids && n) ? n : 0) + 1024e6;
+            // + the endpoint table: 20 B per slot at a load factor of 1/4 .. 1/2 = up to 160 B per distinct endpoint;
+            // their number is not known before the records are read - the caller's node list if there is one, else at most
+            // two per record and (what every graph this library is meant for satisfies) no more than a tenth of the records
+            const double endpoints = (node_ids && n) ? (double)n : std::min(2.0 * (double)m, std::max(0.1 * (double)m, 1e6));
+            const double need = 18.0 * (double)m + 48.0 * (double)((node_ids && n) ? n : 0) + 160.0 * endpoints + 1024e6;
             if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && need > (double)free_b + (double)HB_POOL_CACHED_FREE()) on_host = true;
         }
         DeviceCsr csr;
@@ -594,7 +610,10 @@ int hb_load_edges(hb_ctx *c, const hb_u128 *node_ids, uint64_t n, const hb_edge 
         uint64_t peak = 0;
         std::string e = on_host ? ingest_edges(node_ids, n, edges, m, &c->g)
                                 : gpu_ingest_edges((void *)c->stream, node_ids, n, edges, m, &c->g, keep_on_device ? &csr : nullptr, &peak);
-        if (!on_host && !e.empty() && (e.find("out of memory") != std::string::npos || e.find("OutOfMemory") != std::string::npos)) {
+        // (the id space of the device table exhausted is a limit of the DEVICE ingest only: endpoints outside a caller-supplied
+        // node list are legal and ignored by the reference, store.rs:338-357 - the host path takes over, like for memory)
+        if (!on_host && !e.empty() && (e.find("out of memory") != std::string::npos || e.find("OutOfMemory") != std::string::npos ||
+                                       e.find("too many nodes for the device ingest") != std::string::npos)) {
             (void)hipGetLastError(); // clear the sticky allocation error
             peak = 0;
             e = ingest_edges(node_ids, n, edges, m, &c->g);
@@ -634,7 +653,9 @@ int hb_append_edges(hb_ctx *c, const hb_edge *edges, uint64_t m)
             c->app.chunk_records = c->lim_chunk;
             const std::string err = gpu_ingest_append((void *)c->stream, &c->app, edges, m);
             if (err.empty()) return HB_OK;
-            if (err.find("out of memory") == std::string::npos && err.find("too many records") == std::string::npos) return fail(c, HB_ERR_HIP, err);
+            if (err.find("out of memory") == std::string::npos && err.find("too many records") == std::string::npos &&
+                err.find("too many nodes for the device ingest") == std::string::npos)
+                return fail(c, HB_ERR_HIP, err);
             // the device cannot hold the stream (memory, or the 2^32-record limit of the device reduction): bring back
             // what is there and continue on the host
             rc = spill_appended_to_host(c);

@@ -13,8 +13,13 @@
 //                 extent goes back to its base block's free list (neighbours coalesce)
 //   pool_trim     base blocks that are entirely free go back to the runtime (end of a load, hb_destroy): what stays
 //                 allocated is what the context really holds (hb_stats.device_bytes)
-// One pool per process and device.  Debug builds (-DHB_GUARD_ALLOC, hb_guard_alloc.h) and memory-checker builds (-DHB_EXACT_ALLOC:
-// tests/simt under AddressSanitizer) bypass it: there every buffer must be its own allocation of its exact size.  Include after hb_guard_alloc.h, before any other header of the translation unit.
+// One pool per process; the accounting (bytes held, high-water mark, hoarding limit) is kept PER DEVICE [r5, ADVICE r4], and an
+// extent is released under its own device's synchronisation whichever device is current.  hb_release_cached_memory()
+// (include/hyperball.h) is pool_trim() for callers that share the device with other allocators (RCCL, torch, rocPRIM users),
+// which cannot reclaim what this cache holds on their own out-of-memory.
+// Debug builds (-DHB_GUARD_ALLOC, hb_guard_alloc.h) and memory-checker builds (-DHB_EXACT_ALLOC: tests/simt under
+// AddressSanitizer) bypass it: there every buffer must be its own allocation of its exact size.  Include after
+// hb_guard_alloc.h, before any other header of the translation unit.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -48,7 +53,8 @@ public:
         // No cached extent fits.  While the device has room the cache may keep growing (its free extents are what makes the
         // next loads cheap); once what it holds plus this request passes the limit - half of the device memory, or
         // HB_POOL_LIMIT_BYTES - the blocks nobody uses go back to the runtime first: the footprint then stays near what is live.
-        if (reserved_ + need > limit()) trim_locked(dev);
+        Dev &d = dev_[dev];
+        if (d.reserved + need > limit(d)) trim_locked(dev);
         void *base = nullptr;
         hipError_t e = (hipMalloc)(&base, need);
         if (e != hipSuccess) { // make room: give back what nobody uses, try once more
@@ -63,18 +69,24 @@ public:
         b.dev = dev;
         b.ext[0] = Extent{need, false};
         bases_.push_back(std::move(b));
-        reserved_ += need;
-        if (reserved_ > peak_reserved_) peak_reserved_ = reserved_;
+        d.reserved += need;
+        if (d.reserved > d.peak) d.peak = d.reserved;
         *out = base;
         return hipSuccess;
     }
     hipError_t free(void *p)
     {
         if (!p) return hipSuccess;
-        (void)hipDeviceSynchronize(); // what hipFree does implicitly: nothing in flight may still use the extent
         std::lock_guard<std::mutex> g(mu_);
         for (Base &b : bases_) {
             if ((char *)p < b.ptr || (char *)p >= b.ptr + b.bytes) continue;
+            {   // what hipFree does implicitly: nothing in flight ON THE EXTENT'S DEVICE may still use it
+                int cur = b.dev;
+                (void)hipGetDevice(&cur);
+                if (cur != b.dev) (void)hipSetDevice(b.dev);
+                (void)hipDeviceSynchronize();
+                if (cur != b.dev) (void)hipSetDevice(cur);
+            }
             const size_t off = (size_t)((char *)p - b.ptr);
             auto it = b.ext.find(off);
             if (it == b.ext.end() || it->second.free) return hipErrorInvalidValue; // not the start of a live extent
@@ -93,6 +105,7 @@ public:
             }
             return hipSuccess;
         }
+        (void)hipDeviceSynchronize();
         return (hipFree)(p); // not ours (allocated before the pool existed, or by someone else)
     }
     void trim()
@@ -103,31 +116,34 @@ public:
         std::lock_guard<std::mutex> g(mu_);
         trim_locked(dev);
     }
-    // bytes held from the runtime now / at most since the last reset_peak()
+    // the CURRENT device's: bytes held from the runtime now / at most since the last reset_peak()
     size_t reserved()
     {
         std::lock_guard<std::mutex> g(mu_);
-        return reserved_;
+        return dev_[current()].reserved;
     }
     size_t peak_reserved()
     {
         std::lock_guard<std::mutex> g(mu_);
-        return peak_reserved_;
+        return dev_[current()].peak;
     }
-    // free bytes inside the cached blocks (what a request could get without asking the runtime)
+    // free bytes inside the current device's cached blocks (what a request could get without asking the runtime)
     size_t cached_free()
     {
         std::lock_guard<std::mutex> g(mu_);
+        const int dev = current();
         size_t f = 0;
         for (const Base &b : bases_)
-            for (const auto &e : b.ext)
-                if (e.second.free) f += e.second.size;
+            if (b.dev == dev)
+                for (const auto &e : b.ext)
+                    if (e.second.free) f += e.second.size;
         return f;
     }
     void reset_peak()
     {
         std::lock_guard<std::mutex> g(mu_);
-        peak_reserved_ = reserved_;
+        Dev &d = dev_[current()];
+        d.peak = d.reserved;
     }
 
 private:
@@ -143,16 +159,27 @@ private:
         int dev = 0;
         std::map<size_t, Extent> ext; // offset -> extent, covering the block
     };
+    struct Dev {
+        size_t reserved = 0, peak = 0;
+        size_t limit = 0; // 0 = not asked yet (the device must be current when it is)
+    };
     static size_t round_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
-    static size_t limit()
+    static int current()
     {
-        static const size_t lim = [] {
-            if (const char *e = std::getenv("HB_POOL_LIMIT_BYTES")) return (size_t)std::strtoull(e, nullptr, 10);
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        return dev;
+    }
+    // hoarding limit of the device that is current (alloc() runs on the device it allocates for): half of ITS memory
+    static size_t limit(Dev &d)
+    {
+        if (!d.limit) {
+            if (const char *e = std::getenv("HB_POOL_LIMIT_BYTES")) d.limit = (size_t)std::strtoull(e, nullptr, 10);
             size_t free_b = 0, total_b = 0;
-            if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && total_b) return total_b / 2;
-            return (size_t)64 << 30;
-        }();
-        return lim;
+            if (!d.limit && hipMemGetInfo(&free_b, &total_b) == hipSuccess && total_b) d.limit = total_b / 2;
+            if (!d.limit) d.limit = (size_t)64 << 30;
+        }
+        return d.limit;
     }
     void *take(int dev, size_t need)
     {
@@ -185,7 +212,7 @@ private:
             Base &b = bases_[i];
             if (b.dev == dev && b.ext.size() == 1 && b.ext.begin()->second.free) {
                 (void)(hipFree)(b.ptr);
-                reserved_ -= b.bytes;
+                dev_[dev].reserved -= b.bytes;
                 bases_.erase(bases_.begin() + (long)i);
             } else {
                 i++;
@@ -194,7 +221,7 @@ private:
     }
     std::mutex mu_;
     std::vector<Base> bases_;
-    size_t reserved_ = 0, peak_reserved_ = 0;
+    std::map<int, Dev> dev_;
 };
 inline hipError_t pool_malloc(void **out, size_t bytes) { return DevPool::get().alloc(out, bytes); }
 inline hipError_t pool_free(void *p) { return DevPool::get().free(p); }
@@ -206,8 +233,10 @@ inline void pool_trim() { DevPool::get().trim(); }
 #define HB_POOL_TRIM() hb::pool_trim()
 #define HB_POOL_RESET_PEAK() hb::DevPool::get().reset_peak()
 #define HB_POOL_PEAK() hb::DevPool::get().peak_reserved()
+#define HB_POOL_RESERVED() hb::DevPool::get().reserved()
 #define HB_POOL_CACHED_FREE() hb::DevPool::get().cached_free()
 #else
+#define HB_POOL_RESERVED() ((size_t)0)
 #define HB_POOL_TRIM() ((void)0)
 #define HB_POOL_RESET_PEAK() ((void)0)
 #define HB_POOL_PEAK() ((size_t)0)

@@ -863,8 +863,23 @@ int write_dbs(const std::vector<Target> &targets, const hb_u128 *ids, uint64_t c
     const char *mode = std::getenv("HB_STORE_FST");
     const bool sequential = mode && std::strcmp(mode, "sequential") == 0;
     std::string first_ids;
+    // A call that fails leaves nothing behind: every file it wrote is removed again, and the meta.json files - what makes a
+    // directory a database, and what makes this writer refuse it next time - are written only after the segment files of ALL targets
+    // are complete (hb_store_harmonic: a failure in `harmonic_rank` must not leave a `harmonic` that blocks the retry).
+    struct Undo {
+        std::vector<std::string> paths;
+        bool armed = true;
+        ~Undo()
+        {
+            if (armed)
+                for (const std::string &f : paths) (void)::unlink(f.c_str());
+        }
+    } undo;
+    std::vector<std::string> uuids;
     for (const Target &t : targets) {
         const std::string uuid = uuid_v4(), base = t.dir + "/" + uuid;
+        uuids.push_back(uuid);
+        for (const char *ext : {".blobs", ".bid", ".ids", ".blm"}) undo.paths.push_back(base + ext);
         std::string why;
         if (!write_blobs(entries, t.values, t.kind, base, &why)) return fail(err, err_len, HB_ERR_IO, "hb_store_write: " + why);
         lap(".blobs + .bid");
@@ -878,11 +893,15 @@ int write_dbs(const std::vector<Target> &targets, const hb_u128 *ids, uint64_t c
         }
         lap(".ids copy");
         if (!write_file(base + ".blm", blm)) return fail(err, err_len, HB_ERR_IO, "hb_store_write: write failed on " + base + ".blm");
-        // Meta { segments: [uuid] } through serde_json::to_string_pretty (lib.rs:292-297); last, so that a database whose
-        // meta.json exists is complete
-        if (!write_meta(t.dir, "{\n  \"segments\": [\n    \"" + uuid + "\"\n  ]\n}"))
-            return fail(err, err_len, HB_ERR_IO, "hb_store_write: cannot write " + t.dir + "/meta.json");
     }
+    // Meta { segments: [uuid] } through serde_json::to_string_pretty (lib.rs:292-297); last, so that a database whose
+    // meta.json exists is complete
+    for (size_t k = 0; k < targets.size(); k++) {
+        undo.paths.push_back(targets[k].dir + "/meta.json"); // (it replaces at most an empty `{"segments": []}`: removing it again loses nothing)
+        if (!write_meta(targets[k].dir, "{\n  \"segments\": [\n    \"" + uuids[k] + "\"\n  ]\n}"))
+            return fail(err, err_len, HB_ERR_IO, "hb_store_write: cannot write " + targets[k].dir + "/meta.json");
+    }
+    undo.armed = false;
     return HB_OK;
 }
 

@@ -29,7 +29,6 @@ struct SweepParams {
     uint32_t *heavy;           // seeds with very long reader lists (expanded by the whole grid)
     unsigned int *counts;      // this pass' slot: [0] seeds, [1] heavy seeds
     unsigned int *counts_next; // the other slot (zeroed by this pass' first kernel for the next sweep pass)
-    int cheap_done;            // sweep_cheap_kernel has run: sweep_rows_kernel<true> leaves the rows no changed source reaches alone
 };
 
 __device__ __forceinline__ void touch_set(uint32_t *touch, uint32_t r, uint64_t rows_total)
@@ -251,7 +250,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void s
         // reference adds +0.0 to every node in every pass): cheap path below, no index or counter gathers
         const uint32_t pw = (REAL && in_range) ? p.bits_rd[w] : 0u;
         const uint32_t kw = (REAL && in_range) ? p.kdirty[w] : 0u;
-        uint32_t cheap = sp.cheap_done ? 0u : ((pw | kw) & ~word);
+        // ([r5] the same rows as a streaming kernel of their own - 128 rows per wave step, 32 rows' loads in flight - was measured at C4,
+        // where the first sweep pass revisits 35 M of them: node-row launch 3.67 -> 3.81 ms, and every later pass pays a scan of three
+        // bitmaps: profiles/r05d_*; removed)
+        uint32_t cheap = (pw | kw) & ~word;
         uint32_t total = 0;
         const uint32_t incl = wave_scan(__popc(word), total);
         const bool any_cheap = REAL && __ballot(cheap != 0) != 0;
@@ -461,78 +463,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void s
         }
         const unsigned long long v[4] = {cnt_changed, 0, cnt_rows, cnt_out};
         block_add_counters(p.counters, v, 0xDu);
-    }
-}
-
-// The cheap path of sweep_rows_kernel<true> as a STREAMING kernel [r5], for passes with many such rows (the first sweep pass of a
-// BASELINE-size graph: C4 revisits 35 M rows that changed in the last dense pass - carry their counter over to the other buffer
-// (lazy double buffer), `+= 0.0` on the Kahan-dirty ones, harmonic.rs:159-176 - next to 9 M touched rows; inside the list-driven
-// kernel that was two dependent round trips per row at a few rows per quad).  Runs AFTER the virtual levels (the touch bits of
-// the node rows are complete) and BEFORE sweep_rows_kernel<true> (which consumes them): a wave takes 128 rows = 4 words of the
-// three bitmaps, one quad per row, 32 rows' loads in flight before their stores.  Rows a changed source reaches are left to the
-// row kernel; the Kahan-dirty bits this kernel clears are stored 16 rows at a time (a wave owns its rows' half-words).
-__global__ __launch_bounds__(256) void sweep_cheap_kernel(const SweepParams sp)
-{
-    const PassParams &p = sp.p;
-    const int lane = threadIdx.x & 63, g = lane >> 2, q = lane & 3;
-    const uint64_t nwaves = (uint64_t)gridDim.x * 4, wid = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    const uint64_t ngroups = p.n_pad >> 7; // n_pad is a multiple of 128? no: of 64 - the last half group is handled below
-    const uint64_t words = p.n_pad >> 5;
-    for (uint64_t gi = wid; gi * 4 < words; gi += nwaves) { // wave-uniform trip count
-        (void)ngroups;
-        uint32_t pw[4], kw[4], tw[4];
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const uint64_t w = gi * 4 + k;
-            const bool in = w < words;
-            pw[k] = in ? p.bits_rd[w] : 0u;
-            kw[k] = in ? p.kdirty[w] : 0u;
-            tw[k] = in ? sp.touch[w] : 0u;
-        }
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const uint32_t cheap = (pw[k] | kw[k]) & ~tw[k];
-            if (!cheap) continue; // wave-uniform
-            const uint64_t row0 = (gi * 4 + k) << 5;
-            // two half-words (16 rows each): both halves' loads are issued before either's stores
-            bool cp[2], kd[2];
-            uint4 cv[2];
-            double ks[2], ke[2];
-#pragma unroll
-            for (int h = 0; h < 2; h++) {
-                const uint32_t bit = 1u << (16 * h + g);
-                const bool mine = (cheap & bit) != 0;
-                cp[h] = mine && (pw[k] & bit);
-                kd[h] = mine && (kw[k] & bit);
-                const uint64_t row = row0 + 16 * h + g;
-                cv[h] = make_uint4(0, 0, 0, 0);
-                ks[h] = ke[h] = 0.0;
-                if (cp[h]) cv[h] = p.rd[row * 4 + q];
-                if (kd[h] && q == 0) {
-                    ks[h] = p.ksum[row];
-                    ke[h] = p.kerr[row];
-                }
-            }
-            uint32_t clr = 0;
-#pragma unroll
-            for (int h = 0; h < 2; h++) {
-                const uint64_t row = row0 + 16 * h + g;
-                if (cp[h]) p.wr[row * 4 + q] = cv[h]; // unchanged: carried over to the other buffer
-                bool settled = false;
-                if (kd[h] && q == 0) {
-                    // update_centralities with size(new) == size(old): `+= 0.0` (harmonic.rs:159-176)
-                    const bool moved = kahan_update(ks[h], ke[h], 0, 0, p.t_plus_1);
-                    if (moved) {
-                        p.ksum[row] = ks[h];
-                        p.kerr[row] = ke[h];
-                    } else {
-                        settled = true;
-                    }
-                }
-                clr |= pack16(__ballot(settled)) << (16 * h);
-            }
-            if (clr && lane == 0) p.kdirty[(gi * 4 + k)] = kw[k] & ~clr;
-        }
     }
 }
 

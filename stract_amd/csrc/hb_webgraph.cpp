@@ -695,6 +695,7 @@ int hb_load_webgraph(hb_ctx *ctx, const char *edges_dir, uint32_t flags)
             void *q = nullptr;
             if (hb_pinned_alloc(cap * sizeof(hb_edge), &q) != HB_OK) {
                 r->err = "hb_load_webgraph: cannot allocate the pinned record slabs";
+                g_open_error = r->err; // (the reader is freed on return: hbw_last_error(NULL) keeps the text)
                 return HB_ERR_NOMEM;
             }
             pin.p[k] = (hb_edge *)q;
@@ -748,6 +749,23 @@ int hb_load_webgraph(hb_ctx *ctx, const char *edges_dir, uint32_t flags)
                 if (rc != HB_OK) return;
             }
         });
+        // whatever leaves this scope - a return, an exception out of hb_append_edges' guard - first stops and joins the reader
+        // thread (a joinable std::thread that is destroyed calls std::terminate, past every catch handler)
+        struct JoinProducer {
+            std::thread &t;
+            std::mutex &mu;
+            std::condition_variable &cv;
+            bool &stop;
+            ~JoinProducer()
+            {
+                {
+                    std::lock_guard<std::mutex> lk(mu);
+                    stop = true;
+                }
+                cv.notify_all();
+                if (t.joinable()) t.join();
+            }
+        } join_producer{producer, mu, cv, stop};
         int rc2 = HB_OK;
         for (uint64_t k = 0; k < nslabs && rc2 == HB_OK; k++) {
             {

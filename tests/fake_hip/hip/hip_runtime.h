@@ -15,6 +15,9 @@ struct Device {
     size_t in_use = 0;
     long mallocs = 0, frees = 0, syncs = 0;
     std::map<void *, size_t> live;
+    int current = 0;               // hipSetDevice / hipGetDevice (the fake devices share one capacity)
+    std::map<int, long> syncs_on;  // hipDeviceSynchronize calls per device that was current
+    std::map<void *, int> dev_of;  // the device that was current when the block was allocated
 };
 inline Device &dev()
 {
@@ -35,6 +38,7 @@ inline hipError_t hipMalloc(void **p, size_t n)
     *p = next;
     next += (n + 4095) / 4096 * 4096 + 4096;
     d.live[*p] = n;
+    d.dev_of[*p] = d.current;
     d.in_use += n;
     d.mallocs++;
     return hipSuccess;
@@ -51,12 +55,18 @@ inline hipError_t hipFree(void *p)
 }
 inline hipError_t hipGetDevice(int *dv)
 {
-    *dv = 0;
+    *dv = fake_hip::dev().current;
+    return hipSuccess;
+}
+inline hipError_t hipSetDevice(int dv)
+{
+    fake_hip::dev().current = dv;
     return hipSuccess;
 }
 inline hipError_t hipDeviceSynchronize()
 {
     fake_hip::dev().syncs++;
+    fake_hip::dev().syncs_on[fake_hip::dev().current]++;
     return hipSuccess;
 }
 inline hipError_t hipGetLastError() { return hipSuccess; }

@@ -88,6 +88,26 @@ int main()
     CHECK((hipMalloc)(&foreign, MB) == hipSuccess && hipFree(foreign) == hipSuccess && d.live.empty());
     // zero bytes is a valid request, a null free a no-op
     CHECK(hipMalloc(&b, 0) == hipSuccess && b && hipFree(b) == hipSuccess && hipFree(nullptr) == hipSuccess);
+    // [r5, ADVICE r4] several devices in one process: accounting and limit per device; an extent is released under ITS device's
+    // synchronisation whichever device is current, and the current device is left as it was
+    HB_POOL_TRIM();
+    CHECK(pool.reserved() == 0);
+    void *on0 = nullptr, *on1 = nullptr, *again1 = nullptr;
+    CHECK(hipSetDevice(0) == hipSuccess && hipMalloc(&on0, 200 * MB) == hipSuccess && pool.reserved() == 200 * MB);
+    CHECK(hipSetDevice(1) == hipSuccess && pool.reserved() == 0);                        // device 1 holds nothing yet
+    CHECK(hipMalloc(&on1, 300 * MB) == hipSuccess && pool.reserved() == 300 * MB && d.dev_of[on1] == 1);
+    CHECK(hipSetDevice(0) == hipSuccess && pool.reserved() == 200 * MB);                // 200 + 300 < 512 would have tripped ONE shared limit at the next block
+    const long s0 = d.syncs_on[0], s1 = d.syncs_on[1];
+    CHECK(hipFree(on1) == hipSuccess);                                                   // freed while device 0 is current ...
+    CHECK(d.syncs_on[1] == s1 + 1 && d.syncs_on[0] == s0 && d.current == 0);             // ... synchronised on device 1, device 0 current again
+    CHECK(pool.cached_free() == 0);                                                      // (device 0's view: its only block is live)
+    CHECK(hipMalloc(&again1, 300 * MB) == hipSuccess && again1 != on1 && d.dev_of[again1] == 0); // device 0 does not get device 1's extent
+    CHECK(hipSetDevice(1) == hipSuccess && pool.cached_free() == 300 * MB);
+    HB_POOL_TRIM();                                                                      // trims the CURRENT device only
+    CHECK(pool.reserved() == 0 && hipSetDevice(0) == hipSuccess && pool.reserved() == 500 * MB);
+    CHECK(hipFree(on0) == hipSuccess && hipFree(again1) == hipSuccess);
+    HB_POOL_TRIM();
+    CHECK(pool.reserved() == 0 && d.live.empty() && d.in_use == 0);
     std::printf("ok\n");
     return 0;
 }

@@ -204,16 +204,11 @@ VARIANTS["staged_results_every_pass"] = dict(tune=(0, 0x8000))
 VARIANTS["staged_results_one_snapshot"] = dict(tune=(0, 0x28000))
 VARIANTS["staged_results_sweep_tiny_list"] = dict(chunk=8, tune=(0, 0x38000, 101, 0, 0, 0, 1))
 VARIANTS["staged_results_off"] = dict(tune=(0, 0x4000))
-# round 5: the carry-over / `+= 0.0` rows of a sweep pass as a streaming kernel of their own (default when the previous pass changed
-# > 4096 nodes); bit 19 = always, bit 18 = never
-VARIANTS["sweep_cheap_rows_streamed"] = dict(chunk=8, tune=(0, 0x80000, 101, 0, 0, 0, 1))
-VARIANTS["sweep_cheap_rows_in_the_row_kernel"] = dict(tune=(0, 0x40000, 101, 0, 0, 0, 1))
 EXPECT_MODES = {"frontier_always": {0, 1}, "frontier_always_slot_by_slot": {0, 1}, "frontier_always_multilevel": {0, 1}, "sparse_always_multilevel": {0, 2},
                 "long_tail_default": {0, 2}}
 VARIANTS["long_tail_default"] = dict()
 VARIANTS["long_tail_chunk8"] = dict(chunk=8)
 VARIANTS["long_tail_staged_results"] = dict(tune=(0, 0x8000))
-VARIANTS["long_tail_cheap_rows_streamed"] = dict(tune=(0, 0x80000))
 
 
 @pytest.mark.parametrize("variant", sorted(VARIANTS))

@@ -215,6 +215,26 @@ def test_store_never_reports_ok_without_a_meta(tmp_path):
     assert kv.Db(str(empty), "f64", str(tmp_path)).get(3) == 0.5
 
 
+def test_failed_store_harmonic_leaves_nothing_and_can_be_retried(tmp_path):
+    """a call that fails removes the segment files it wrote, and no meta.json appears before the files of BOTH databases
+    are complete - a failure while `harmonic_rank` is written must not leave a finished `harmonic` behind that makes the retry into
+    the same output directory fail with "already lists segments" (Db::open_or_create would simply have gone on)."""
+    ids = kv.ints_to_ids([5, 9, 1 << 100, (1 << 127) + 3], _lib.U128)
+    vals = np.array([0.5, 0.25, 0.125, 1.0])
+    ranks = np.array([1, 2, 3, 0], dtype=np.uint64)
+    out = tmp_path / "centrality"
+    (out / "harmonic_rank" / "meta.json").mkdir(parents=True)  # the SECOND database cannot get its meta.json
+    with pytest.raises(_lib.HyperballError) as e:
+        _lib.store_harmonic(str(out), ids, vals, ranks)
+    assert e.value.code == _lib.HB_ERR_IO
+    assert os.listdir(out / "harmonic") == []                                   # no segment files, no meta.json
+    assert os.listdir(out / "harmonic_rank") == ["meta.json"]                   # only the obstacle itself
+    os.rmdir(out / "harmonic_rank" / "meta.json")
+    _lib.store_harmonic(str(out), ids, vals, ranks)                             # the retry into the same directory succeeds
+    assert kv.Db(str(out / "harmonic"), "f64", str(tmp_path)).get(9) == 0.25
+    assert kv.Db(str(out / "harmonic_rank"), "u64", str(tmp_path)).get(1 << 100) == 3
+
+
 def test_published_vectors_of_the_restated_formats(tmp_path):
     """Pins that do not come from this repository's own reading of the formats:
       * bincode's documented variable-length integer encoding (bincode docs, `config::standard()` / VarintEncoding: u < 251 one
