@@ -30,8 +30,8 @@ torch.distributed.run, one rank per GPU).  Prints ONE JSON line on rank 0.
               (--c4-leg on: the same for configs[3] under detail.c4 when another config is the main one.)
   end to end= N = 1, record input (default): detail.end_to_end (and detail.c4.end_to_end) = the reference command's whole chain
               on the same graph (entrypoint/centrality.rs:41-71): an on-disk edge store (written by the harness, untimed) ->
-              hb_load_webgraph (CRC-32 checked, native column reader, GPU ingest) -> hb_run -> hb_result_copy + hb_result_ranks
-              -> hb_store_harmonic (both speedy_kv databases), seconds per stage, records/s of the load, entries/s of the
+              hb_load_webgraph (CRC-32 checked, native column reader, GPU ingest) -> hb_run -> hb_store_harmonic_results (the result
+              list, the ranks and the key order of both speedy_kv databases from the device, then the files), seconds per stage, records/s of the load, entries/s of the
               store emission, compute share of the total, and three checks (graph = clean graph, result = the record leg's,
               a sample of keys read back from the written databases); a failed check makes the exit code non-zero.
   roofline  = SURVEY.md §8(d): HBM-bound.  Headline `achieved`/`frac` = the WHOLE generic dense pass
@@ -224,8 +224,8 @@ def end_to_end(a, g, ref_sig, ref_passes, salt=2, seg_records=1 << 24):
         open the webgraph's edge store + stream it   hb_load_webgraph (CRC-32 of every .col file checked; native column reader,
                                                       pinned double buffer, GPU ingest, device planner)
         HarmonicCentrality::calculate                 hb_run
-        the (NodeID, f64) list + harmonic_rank        hb_result_copy + hb_result_ranks
-        store_harmonic                                hb_store_harmonic (both speedy_kv databases)
+        the (NodeID, f64) list + harmonic_rank + store_harmonic   hb_store_harmonic_results (both speedy_kv databases; result list, ranks and
+                                                      key order from the device)
     Harness (not timed): the record stream is written as an edge store by tests/tantivy_fixture.py (a Python restatement of the
     tantivy serialisers: format unpinned), segment by segment; a sample of keys is read back from the written databases with
     tests/speedy_kv_reader.py."""
@@ -281,13 +281,16 @@ def end_to_end(a, g, ref_sig, ref_passes, salt=2, seg_records=1 << 24):
             st = ctx.stats()
             run = ctx.run()
             t2 = time.perf_counter()
-            ids, vals = ctx.results()
-            ranks = ctx.ranks()
-            t3 = time.perf_counter()
-            _lib.store_harmonic(os.path.join(work, "centrality"), ids, vals, ranks)
+            # [r5] hb_store_harmonic_results: the (NodeID, f64) list, the ranks (device sort), the key order of both databases (device
+            # sort) and the files, in one call on the context; rounds 3-4 timed hb_result_copy + hb_result_ranks and the host-sorted
+            # hb_store_harmonic apart (C4: 0.9-2.2 s + 6.7 s)
+            ctx.store_harmonic(os.path.join(work, "centrality"))
             t4 = time.perf_counter()
+            ids, vals = ctx.results()  # (harness: the checks below)
+            ranks = ctx.ranks()
         sig = (len(vals), int(vals.view(np.uint64).sum() & 0xFFFFFFFFFFFFFFFF)) if len(vals) else (0, 0)
-        stages = {"s_load_webgraph": t1 - t0, "s_run": t2 - t1, "s_results_and_ranks": t3 - t2, "s_store_harmonic": t4 - t3}
+        stages = {"s_load_webgraph": t1 - t0, "s_run": t2 - t1, "s_store_harmonic": t4 - t2}
+        out["s_results_and_ranks"] = "inside s_store_harmonic (hb_store_harmonic_results: results + ranks + device key sort + both databases)"
         tot = t4 - t0
         out.update({k: round(v, 3) for k, v in stages.items()})
         out.update({"s_total": round(tot, 3), "compute_share": round(stages["s_run"] / tot, 4),

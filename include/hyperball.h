@@ -167,6 +167,9 @@ typedef struct hb_stats {
                                    were still running (second stream; single rank, n >= 2^20): hb_finish then ships only ... */
     uint64_t result_list;       /* [ABI 5] ... this many (node, value) entries that still moved afterwards (0 stages: the whole
                                    n x 8-byte image is downloaded by hb_finish, as before)                                      */
+    uint64_t pipelined_passes;  /* [ABI 5] passes of the last hb_run that were queued BEFORE the host had read the previous pass'
+                                   counters (convergence tail, one rank: a pass that changed <= 4096 nodes in sweep mode is
+                                   followed by passes guarded on the device; the pass behind the loop's last one does nothing) */
 } hb_stats;
 
 typedef struct hb_pass_stats {

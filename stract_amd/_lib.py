@@ -90,6 +90,7 @@ class HbStats(ctypes.Structure):
         ("pool_peak_bytes", ctypes.c_uint64),
         ("result_stages", ctypes.c_uint64),
         ("result_list", ctypes.c_uint64),
+        ("pipelined_passes", ctypes.c_uint64),
     ]
 
     def as_dict(self):
@@ -196,6 +197,7 @@ _SIGNATURES += [
 _SIGNATURES += [
     ("hb_store_write", ctypes.c_int, [ctypes.c_char_p, _P, _P, ctypes.c_int, _U64, ctypes.c_char_p, ctypes.c_size_t]),
     ("hb_store_harmonic", ctypes.c_int, [ctypes.c_char_p, _P, _P, _P, _U64, ctypes.c_char_p, ctypes.c_size_t]),
+    ("hb_store_harmonic_results", ctypes.c_int, [_P, ctypes.c_char_p, ctypes.c_char_p, _U64]),
 ]
 SYMBOLS = [s[0] for s in _SIGNATURES]
 
@@ -474,6 +476,13 @@ class Context:
         out = np.zeros(k.value, dtype=np.uint64)
         self._check(self.lib.hb_result_ranks(self.h, _ptr(out), k.value))
         return out
+
+    def store_harmonic(self, output):
+        """store_harmonic (centrality/mod.rs:72-114) from the results this context holds; key order sorted on the device."""
+        err = ctypes.create_string_buffer(512)
+        rc = self.lib.hb_store_harmonic_results(self.h, os.fsencode(output), err, len(err))
+        if rc != HB_OK:
+            raise HyperballError(rc, err.value.decode(errors="replace"))
 
     def top(self, k):
         """top_nodes(TopNodes::Top(k)) (centrality/mod.rs:33-52): (ids, vals), largest centrality first."""

@@ -94,6 +94,22 @@ struct hb_ctx {
     uint64_t co_rows = 0;     // rows in the union of this pass
     bool ubits_valid = false; // d_ubits holds this pass' union (set by the exchange, consumed by the epilogue)
     std::vector<uint64_t> ex_off; // world + 1: first packed position of every rank's slice
+    unsigned long long *d_rank_cnt = nullptr; // world words: every rank's changed rows of this pass (summed over the ranks)
+    unsigned long long *h_rank_cnt = nullptr; // pinned
+    // destination partition + changed-only: the pass' only host round trip sits in the MIDDLE of the pass (counters + run lengths,
+    // before the broadcasts); what follows it is left in flight, so the pass' timing events are read later (resolve_pass_times)
+    struct EvSet {
+        hipEvent_t e[6];
+    };
+    std::vector<EvSet> ev_pool;         // one set per pass of a run (created on demand, kept)
+    std::vector<uint64_t> pending_times; // passes whose ms_* fields still have to be read from their events
+    // hb_run's tail pipeline: pass q + 1 is queued (guarded on the device by pass q's changed count) before pass q's counters are
+    // read, so the convergence tail runs without a host round trip between passes
+    const unsigned long long *spec_guard = nullptr; // set while step_local queues a guarded pass
+    bool pipelined = false;                         // step_local: take this pass' events from ev_pool
+    uint64_t pipelined_passes = 0;                  // passes of this run queued ahead of their predecessor's read-back
+    unsigned long long *h_slot = nullptr;           // pinned, 2 x kCounterWords: the counters of the two passes in flight
+    hipEvent_t slot_done[2] = {nullptr, nullptr};   // pass q's counters have arrived in h_slot[q & 1]
     uint64_t wire_bytes = 0;      // counter bytes this rank received over the run (changed-only accounting)
     // reference-tail mode (HB_FLAG_REFERENCE_TAIL): the reference's changed-node machinery as written
     uint64_t *d_tail_ptr = nullptr; // page-level records by source device row (hb_load_tail_edges), n_pad + 1
@@ -220,6 +236,7 @@ void free_graph_buffers(hb_ctx *c)
     c->d_wpop = nullptr;
     c->d_wprefix = nullptr;
     c->d_lbits = c->d_lbits_all = c->d_ubits = nullptr;
+    c->d_rank_cnt = nullptr;
     c->ubits_valid = false;
     c->d_out_ptr = nullptr;
     c->d_out_rows = nullptr;
@@ -534,6 +551,13 @@ void hb_destroy(hb_ctx *ctx)
     ctx->app.free_all();
     free_graph_buffers(ctx);
     if (ctx->h_counters) (void)hipHostFree(ctx->h_counters);
+    if (ctx->h_rank_cnt) (void)hipHostFree(ctx->h_rank_cnt);
+    if (ctx->h_slot) (void)hipHostFree(ctx->h_slot);
+    for (hipEvent_t e : ctx->slot_done)
+        if (e) (void)hipEventDestroy(e);
+    for (auto &es : ctx->ev_pool)
+        for (hipEvent_t e : es.e)
+            if (e) (void)hipEventDestroy(e);
     for (int i = 0; i < 6; i++)
         if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
     for (int i = 0; i < hb_ctx::kOverlap; i++) {
@@ -961,6 +985,8 @@ int hb_begin(hb_ctx *c)
         c->last_active = c->m_global;
         c->pending_local = false;
         c->pstats.clear();
+        c->pending_times.clear();
+        c->pipelined_passes = 0;
         c->begun = true;
         c->finished = false;
         c->res_count = 0;
@@ -1070,6 +1096,10 @@ int hb_finish(hb_ctx *c)
             HB_HIP(hipMemcpyAsync(c->h_counters, cnt, hbk::kCounterWords * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
             HB_HIP(hipStreamSynchronize(c->stream));
         }
+        if (std::getenv("HB_TRACE_RESULTS"))
+            std::fprintf(stderr, "[hb results] hb_finish: entered at %.3f ms, done at %.3f ms (host clock); %u snapshots, list %llu\n", t0, now_ms(), c->rs.stages,
+                         shipped ? (unsigned long long)*c->rs.h_count : 0ull);
+        c->stats.pipelined_passes = c->pipelined_passes;
         c->stats.result_stages = c->rs.stages;
         c->stats.result_list = shipped ? *c->rs.h_count : 0;
         c->rs.valid = false;
@@ -1078,6 +1108,7 @@ int hb_finish(hb_ctx *c)
         c->stats.ms_d2h = now_ms() - t0;
         c->stats.results = c->res_count;
         c->stats.passes = c->t;
+        if ((rc = resolve_pass_times(c))) return rc;
         double g = 0, coll = 0;
         for (auto &ps : c->pstats) { g += ps.ms_gpu; coll += ps.ms_collective; }
         c->stats.ms_loop_gpu = g;
@@ -1096,9 +1127,15 @@ int hb_run(hb_ctx *c, hb_stats *stats)
         if (rc) return rc;
         double t0 = now_ms();
         int has = 1;
+        const bool trace = std::getenv("HB_TRACE_RESULTS") != nullptr;
         // harmonic.rs:237-240: loop { if !has_changes { break } ... }
         while (has) {
+            if (tail_pipeline_ready(c)) {
+                if ((rc = tail_pipeline(c, &has))) return rc; // runs passes until the loop ends or the changed set grows again
+                continue;
+            }
             if ((rc = hb_step(c, &has))) return rc;
+            if (trace) std::fprintf(stderr, "[hb results] pass %llu returned at %.3f ms (host clock)\n", (unsigned long long)c->t - 1, now_ms());
         }
         c->stats.ms_loop = now_ms() - t0;
         if ((rc = hb_finish(c))) return rc;
@@ -1118,6 +1155,7 @@ int hb_get_stats(const hb_ctx *c, hb_stats *out)
 int hb_get_pass_stats(const hb_ctx *c, uint64_t t, hb_pass_stats *out)
 {
     if (!c || !out || t >= c->pstats.size()) return HB_ERR_INVALID;
+    if (!c->pending_times.empty() && resolve_pass_times(const_cast<hb_ctx *>(c))) return HB_ERR_HIP; // (timing left in flight: read it now)
     *out = c->pstats[t];
     return HB_OK;
 }
@@ -1214,6 +1252,36 @@ int hb_result_top(hb_ctx *c, uint64_t k, hb_u128 *ids, double *vals, uint64_t *w
         }
         return HB_OK;
     });
+}
+
+// store_harmonic (centrality/mod.rs:72-114) straight from the context that computed the results [ABI 5]
+int hb_store_harmonic_results(hb_ctx *c, const char *output, char *err, uint64_t err_len)
+{
+    if (err && err_len) err[0] = 0;
+    const int rc = guarded(c, [&]() -> int {
+        if (!c || !output || !*output) return c ? fail(c, HB_ERR_INVALID, "hb_store_harmonic_results: output is empty") : HB_ERR_INVALID;
+        if (!c->finished) return fail(c, HB_ERR_INVALID, "no results: hb_run / hb_finish not called");
+        int rc2 = set_device(c);
+        if (rc2) return rc2;
+        const uint64_t k = c->res_count;
+        // the (NodeID, f64) list and the ranks, as hb_result_copy / hb_result_ranks return them
+        std::vector<hb_u128> ids(k);
+        std::vector<double> vals(k);
+        std::vector<uint64_t> ranks(k);
+        if ((rc2 = hb_result_copy(c, ids.data(), vals.data(), k))) return rc2;
+        if ((rc2 = hb_result_ranks(c, ranks.data(), k))) return rc2;
+        // the key order of both databases: one radix sort on the device instead of a comparison sort of 24-byte records on the host
+        std::vector<StoreKey> sorted(k);
+        const std::string e = gpu_store_keys((void *)c->stream, ids.data(), k, sorted.data());
+        if (!e.empty()) return fail(c, e.find("memory") != std::string::npos ? HB_ERR_NOMEM : HB_ERR_HIP, "hb_store_harmonic_results: " + e);
+        std::vector<hb_u128>().swap(ids);
+        char msg[512] = {0};
+        const int rc3 = store_harmonic_presorted(output, &sorted, vals.data(), ranks.data(), msg, sizeof(msg));
+        if (rc3) return fail(c, rc3, msg);
+        return HB_OK;
+    });
+    if (rc && err && err_len && c) std::snprintf(err, (size_t)err_len, "%s", c->err.c_str());
+    return rc;
 }
 
 #include "hb_api_debug.inc"

@@ -92,6 +92,17 @@ __global__ __launch_bounds__(256) void popcount_words_kernel(const uint32_t *bit
 {
     for (uint64_t w = (uint64_t)blockIdx.x * 256 + threadIdx.x; w < words; w += (uint64_t)gridDim.x * 256) out[w] = __popc(bits[w]);
 }
+// [r5] rank_cnt[k] = (k == rank) ? rows this rank's fused launch changed (word 0 of its counter stripes) : 0.  Summed over the ranks next
+// to the pass counters, the host gets every rank's run length with the ONE read-back a pass has anyway - the packed runs'
+// offsets no longer cost a round trip of their own.
+__global__ __launch_bounds__(64) void rank_count_kernel(const unsigned long long *counters, unsigned long long *rank_cnt, int world, int rank)
+{
+    unsigned long long v = threadIdx.x < kStripes ? counters[4 * threadIdx.x] : 0ull;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+    v = __shfl(v, 0);
+    for (int k = threadIdx.x; k < world; k += 64) rank_cnt[k] = k == rank ? v : 0ull;
+}
 // quad per row of [row_lo, row_hi)
 __global__ __launch_bounds__(256) void pack_changed_kernel(const uint4 *wr, const uint32_t *bits, const uint64_t *prefix, uint64_t row_lo,
                                                            uint64_t row_hi, uint4 *pack)

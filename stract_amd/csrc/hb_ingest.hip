@@ -970,4 +970,84 @@ std::string gpu_rank_results(void *stream_v, const double *d_vals, uint64_t n, u
     return "";
 }
 
+
+// ---- key order of the centrality stores on the device (hb_store_harmonic_results) -----------------------------------------------
+namespace {
+// the bincode varint encoding of a u128 (serialized.rs:86-92 -> bincode standard(): < 251 one byte; 251 + u16; 252 + u32; 253 + u64;
+// 254 + u128, little endian) as hb_store.cpp holds it: 17 key bytes, zero padded, in two big-endian words + the last byte
+__global__ __launch_bounds__(256) void store_keys_kernel(const hb_u128 *ids, uint64_t count, u128 *key, uint64_t *k2_index)
+{
+    HB_GRID_STRIDE(i, count)
+    {
+        const uint64_t lo = ids[i].lo, hi = ids[i].hi;
+        uint8_t b[17];
+#pragma unroll
+        for (int k = 0; k < 17; k++) b[k] = 0;
+        int n = 0;
+        if (!hi && lo < 251) {
+            b[0] = (uint8_t)lo;
+        } else {
+            if (!hi && lo < (1ull << 16)) b[0] = 251, n = 2;
+            else if (!hi && lo < (1ull << 32)) b[0] = 252, n = 4;
+            else if (!hi) b[0] = 253, n = 8;
+            else b[0] = 254, n = 16;
+#pragma unroll
+            for (int k = 0; k < 16; k++)
+                if (k < n) b[1 + k] = (uint8_t)((k < 8 ? lo >> (8 * k) : hi >> (8 * (k - 8))) & 0xFFu);
+        }
+        uint64_t k0 = 0, k1 = 0;
+#pragma unroll
+        for (int k = 0; k < 8; k++) k0 = (k0 << 8) | b[k];
+#pragma unroll
+        for (int k = 0; k < 8; k++) k1 = (k1 << 8) | b[8 + k];
+        key[i] = ((u128)k0 << 64) | (u128)k1;
+        k2_index[i] = ((uint64_t)b[16] << 56) | i;
+    }
+}
+__global__ __launch_bounds__(256) void store_keys_pack_kernel(const u128 *key, const uint64_t *k2_index, uint64_t count, uint64_t *out3)
+{
+    HB_GRID_STRIDE(i, count)
+    {
+        const u128 k = key[i];
+        out3[3 * i] = (uint64_t)(k >> 64);
+        out3[3 * i + 1] = (uint64_t)k;
+        out3[3 * i + 2] = k2_index[i];
+    }
+}
+} // namespace
+
+std::string gpu_store_keys(void *stream_v, const hb_u128 *ids, uint64_t count, StoreKey *sorted_out)
+{
+    hipStream_t stream = (hipStream_t)stream_v;
+    if (!count) return "";
+    if (count >= (1ull << 56)) return "too many entries";
+    DevMem mem;
+    hb_u128 *d_ids = nullptr;
+    u128 *d_key = nullptr, *d_key2 = nullptr;
+    uint64_t *d_w = nullptr, *d_w2 = nullptr, *d_out = nullptr;
+    IG_HIP(mem.alloc(&d_ids, count));
+    IG_HIP(mem.alloc(&d_key, count));
+    IG_HIP(mem.alloc(&d_key2, count));
+    IG_HIP(mem.alloc(&d_w, count));
+    IG_HIP(mem.alloc(&d_w2, count));
+    IG_HIP(hipMemcpyAsync(d_ids, ids, count * sizeof(hb_u128), hipMemcpyHostToDevice, stream));
+    hipLaunchKernelGGL(store_keys_kernel, dim3(grid_for(count)), dim3(256), 0, stream, (const hb_u128 *)d_ids, count, d_key, d_w);
+    IG_HIP(hipGetLastError());
+    // LSD: first the 17th key byte (the top byte of the index word; ties keep the ascending index), then the first 16 bytes
+    size_t b1 = 0, b2 = 0;
+    IG_HIP(rocprim::radix_sort_pairs(nullptr, b1, (const uint64_t *)d_w, d_w2, (const u128 *)d_key, d_key2, (size_t)count, 56, 64, stream));
+    IG_HIP(rocprim::radix_sort_pairs(nullptr, b2, (const u128 *)d_key2, d_key, (const uint64_t *)d_w2, d_w, (size_t)count, 0, 128, stream));
+    char *tmp = nullptr;
+    IG_HIP(mem.alloc(&tmp, std::max(b1, b2)));
+    IG_HIP(rocprim::radix_sort_pairs(tmp, b1, (const uint64_t *)d_w, d_w2, (const u128 *)d_key, d_key2, (size_t)count, 56, 64, stream));
+    IG_HIP(rocprim::radix_sort_pairs(tmp, b2, (const u128 *)d_key2, d_key, (const uint64_t *)d_w2, d_w, (size_t)count, 0, 128, stream));
+    mem.release(d_ids);
+    IG_HIP(mem.alloc(&d_out, 3 * count));
+    hipLaunchKernelGGL(store_keys_pack_kernel, dim3(grid_for(count)), dim3(256), 0, stream, (const u128 *)d_key, (const uint64_t *)d_w, count, d_out);
+    IG_HIP(hipGetLastError());
+    IG_HIP(hipMemcpyAsync(sorted_out, d_out, count * sizeof(StoreKey), hipMemcpyDeviceToHost, stream));
+    IG_HIP(hipStreamSynchronize(stream));
+    return "";
+}
+
 } // namespace hb

@@ -260,5 +260,34 @@ std::string gpu_build_plan(void *stream, uint64_t n, const uint64_t *d_row_ptr, 
 
 double now_ms();
 
+// ---- store emission (hb_store.cpp; the key order may come from the device: hb_ingest.hip gpu_store_keys) ---------------------
+// one entry of the sort: the 17 key bytes as two big-endian words + the last byte, so that integer order = byte order of
+// the encodings (the first byte fixes the length: zero padding never decides an order); index into the caller's arrays
+struct StoreKey {
+    uint64_t k0, k1;
+    uint64_t k2_index; // key byte 16 << 56 | index (< 2^56)
+    bool operator<(const StoreKey &o) const
+    {
+        if (k0 != o.k0) return k0 < o.k0;
+        if (k1 != o.k1) return k1 < o.k1;
+        return k2_index < o.k2_index;
+    }
+    bool same_key(const StoreKey &o) const { return k0 == o.k0 && k1 == o.k1 && (k2_index >> 56) == (o.k2_index >> 56); }
+    uint64_t index() const { return k2_index & ((1ull << 56) - 1); }
+    static int len_of_first(uint8_t b0) { return b0 < 251 ? 1 : b0 == 251 ? 3 : b0 == 252 ? 5 : b0 == 253 ? 9 : 17; }
+    int key_len() const { return len_of_first((uint8_t)(k0 >> 56)); }
+    void key_bytes(uint8_t out[17]) const
+    {
+        for (int i = 0; i < 8; i++) out[i] = (uint8_t)(k0 >> (56 - 8 * i));
+        for (int i = 0; i < 8; i++) out[8 + i] = (uint8_t)(k1 >> (56 - 8 * i));
+        out[16] = (uint8_t)(k2_index >> 56);
+    }
+};
+
+// keys of `count` ids in ascending key-byte order (bincode varint encodings, serialized.rs:86-92), computed on the device: ids go
+// up once, (key words, index) come back sorted - a 136-bit LSD radix sort (stable: one pass on the 17th byte, then 128 bits)
+std::string gpu_store_keys(void *stream, const hb_u128 *ids, uint64_t count, StoreKey *sorted_out);
+// store_harmonic (centrality/mod.rs:72-114) from keys that are already in order; *sorted is consumed
+int store_harmonic_presorted(const char *output, std::vector<StoreKey> *sorted, const double *centralities, const uint64_t *ranks, char *err, size_t err_len);
 } // namespace hb
 #endif

@@ -36,6 +36,7 @@
 #include <unistd.h>
 
 #include "../../include/hb_store.h"
+#include "hb_internal.h"
 #include "hb_threads.h"
 
 #define XXH_INLINE_ALL
@@ -436,28 +437,7 @@ struct Bloom {
     }
 };
 
-// one entry of the sort: the 17 key bytes as two big-endian words + the last byte, so that integer order = byte order of
-// the encodings (the first byte fixes the length: zero padding never decides an order); index into the caller's arrays
-struct Entry {
-    uint64_t k0, k1;
-    uint64_t k2_index; // key byte 16 << 56 | index (< 2^56)
-    bool operator<(const Entry &o) const
-    {
-        if (k0 != o.k0) return k0 < o.k0;
-        if (k1 != o.k1) return k1 < o.k1;
-        return k2_index < o.k2_index;
-    }
-    bool same_key(const Entry &o) const { return k0 == o.k0 && k1 == o.k1 && (k2_index >> 56) == (o.k2_index >> 56); }
-    uint64_t index() const { return k2_index & ((1ull << 56) - 1); }
-    static int len_of_first(uint8_t b0) { return b0 < 251 ? 1 : b0 == 251 ? 3 : b0 == 252 ? 5 : b0 == 253 ? 9 : 17; }
-    int key_len() const { return len_of_first((uint8_t)(k0 >> 56)); }
-    void key_bytes(uint8_t out[17]) const
-    {
-        for (int i = 0; i < 8; i++) out[i] = (uint8_t)(k0 >> (56 - 8 * i));
-        for (int i = 0; i < 8; i++) out[8 + i] = (uint8_t)(k1 >> (56 - 8 * i));
-        out[16] = (uint8_t)(k2_index >> 56);
-    }
-};
+using Entry = hb::StoreKey; // (hb_internal.h: the device sort of hb_store_harmonic_results produces the same records)
 
 std::string uuid_v4()
 {
@@ -818,9 +798,9 @@ struct Target {
 };
 
 // one key set, any number of databases over it
-int write_dbs(const std::vector<Target> &targets, const hb_u128 *ids, uint64_t count, char *err, size_t err_len)
+int write_dbs(const std::vector<Target> &targets, const hb_u128 *ids, uint64_t count, char *err, size_t err_len, std::vector<Entry> *presorted = nullptr)
 {
-    if (count && !ids) return fail(err, err_len, HB_ERR_INVALID, "hb_store_write: NULL array with count > 0");
+    if (count && !ids && !presorted) return fail(err, err_len, HB_ERR_INVALID, "hb_store_write: NULL array with count > 0");
     for (const Target &t : targets) {
         if (t.dir.empty()) return fail(err, err_len, HB_ERR_INVALID, "hb_store_write: dir is empty");
         if (count && !t.values) return fail(err, err_len, HB_ERR_INVALID, "hb_store_write: NULL array with count > 0");
@@ -844,9 +824,21 @@ int write_dbs(const std::vector<Target> &targets, const hb_u128 *ids, uint64_t c
         t_lap = t;
     };
     std::vector<Entry> entries;
-    int rc = sort_entries(ids, count, &entries, err, err_len);
-    if (rc != HB_OK) return rc;
-    lap("keys + sort");
+    if (presorted) {
+        // the key order was computed elsewhere (hb_store_harmonic_results: a radix sort on the device, hb_ingest.hip gpu_store_keys):
+        // trusted for order only after the same check the host sort ends with - strictly ascending keys, every index in range
+        entries.swap(*presorted);
+        if (entries.size() != count) return fail(err, err_len, HB_ERR_INVALID, "hb_store_write: presorted key set of the wrong size");
+        bool bad = false;
+#pragma omp parallel for num_threads(hb::host_threads()) schedule(static) reduction(|| : bad)
+        for (uint64_t i = 0; i < count; i++) bad = bad || entries[i].index() >= count || (i && !(entries[i - 1] < entries[i])) || (i && entries[i].same_key(entries[i - 1]));
+        if (bad) return fail(err, err_len, HB_ERR_INVALID, "hb_store_write: duplicate NodeID (or a presorted key set that is not ascending)");
+        lap("keys (presorted) + check");
+    } else {
+        int rc = sort_entries(ids, count, &entries, err, err_len);
+        if (rc != HB_OK) return rc;
+        lap("keys + sort");
+    }
     // bloom filter: SegmentWriter::new(num_items, ..): BytesBloomFilter::new(num_items, 0.01), segment.rs:56-59
     bytes blm;
     {
@@ -919,6 +911,19 @@ int guarded(char *err, size_t err_len, F &&f)
 }
 
 } // namespace
+
+// hb_internal.h: store_harmonic with the key order already computed (StoreKey = Entry, three words)
+namespace hb {
+int store_harmonic_presorted(const char *output, std::vector<StoreKey> *sorted, const double *centralities, const uint64_t *ranks, char *err, size_t err_len)
+{
+    return guarded(err, err_len, [&]() -> int {
+        if (!output || !*output || !sorted) return fail(err, err_len, HB_ERR_INVALID, "hb_store_harmonic: output is empty");
+        const std::string out(output);
+        const uint64_t count = sorted->size();
+        return write_dbs({Target{out + "/harmonic", centralities, HB_STORE_F64}, Target{out + "/harmonic_rank", ranks, HB_STORE_U64}}, nullptr, count, err, err_len, sorted);
+    });
+}
+} // namespace hb
 
 extern "C" int hb_store_write(const char *dir, const hb_u128 *ids, const void *values, int value_kind, uint64_t count, char *err, size_t err_len)
 {

@@ -29,7 +29,19 @@ struct SweepParams {
     uint32_t *heavy;           // seeds with very long reader lists (expanded by the whole grid)
     unsigned int *counts;      // this pass' slot: [0] seeds, [1] heavy seeds
     unsigned int *counts_next; // the other slot (zeroed by this pass' first kernel for the next sweep pass)
+    // [r5] a pass queued BEFORE the host knows whether the previous one changed anything (hb_run's tail pipeline): the counter stripes
+    // of the previous pass; all zero = that pass was the loop's last one (harmonic.rs:237-240) and every kernel of this one returns
+    // at once, leaving the state exactly as that pass left it.  NULL = an ordinary pass.
+    const unsigned long long *guard;
 };
+
+// wave-uniform: did the pass whose counters `guard` points at change any node (word 0 of its 64 stripes)?
+__device__ __forceinline__ bool guard_open(const unsigned long long *guard)
+{
+    if (!guard) return true;
+    const unsigned long long v = guard[4 * (threadIdx.x & (kStripes - 1))];
+    return __ballot(v != 0ull) != 0ull;
+}
 
 __device__ __forceinline__ void touch_set(uint32_t *touch, uint32_t r, uint64_t rows_total)
 {
@@ -140,6 +152,7 @@ __global__ __launch_bounds__(256) void sweep_expand_kernel(const SweepParams sp)
 // the whole wave (a hub that still changes this late is rare but must not serialise on one lane).  No seed list, no counts.
 __global__ __launch_bounds__(256) void sweep_seed_small_kernel(const SweepParams sp)
 {
+    if (!guard_open(sp.guard)) return;
     if (blockIdx.x == 0 && threadIdx.x < 2) { // unused here: both slots are left clean for whichever pass collects seeds next
         sp.counts[threadIdx.x] = 0;
         sp.counts_next[threadIdx.x] = 0;
@@ -208,6 +221,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void s
     __shared__ uint32_t s_kdw[4][64];    // Kahan-dirty bits, per owned word (REAL)
     constexpr int kU = 2;                // index quads per gather round
     const PassParams &p = sp.p;
+    if (!guard_open(sp.guard)) return; // (block-uniform: every wave reads the same words)
     if (REAL) {
         for (int i = threadIdx.x; i < kTableLen; i += 256) {
             s_raw[i] = p.raw[i];

@@ -266,6 +266,40 @@ def test_per_pass_state_matches_oracle(gpu_ctx_factory, variant):
             assert EXPECT_MODES[variant] <= modes, (variant, modes)
 
 
+def test_run_pipelines_the_convergence_tail_and_books_it_like_single_steps(gpu_ctx_factory):
+    """hb_run keeps one pass queued ahead in the convergence tail [r5] (a pass guarded on the device by its predecessor's changed count
+    goes into the stream before the host has read that count, so no host round trip separates the tail's passes): the loop must
+    still end on the first pass that changes nothing (harmonic.rs:237-240), the guarded pass behind it must leave the state alone,
+    and what hb_run books per pass must equal what one-pass-at-a-time stepping books - on the long-tail graph (tens of tail
+    passes), with the pipeline on (default) and off (tune[1] bit 20), through sweep passes with the small and the general seed path."""
+    g = synth.RmatGraph(13, 60_000, tail=(300, 800, 10))
+    o = hbo.Dense(g.id_low64(), g.row_ptr, g.src)
+    T = o.run()
+    vals, keep, k = o.finish()
+    keys = ("pass", "changed", "active_edges", "touched", "mode")
+    seen = {}
+    for name, kw in (("pipelined", dict()), ("stepwise", dict(tune=(0, 0x100000))), ("pipelined_chunk8", dict(chunk=8)),
+                     ("pipelined_staged_every_pass", dict(tune=(0, 0x8000)))):
+        with gpu_ctx_factory(**kw) as ctx:
+            ctx.load_dense(g.ids, g.row_ptr, g.src)
+            for again in range(2):  # (a second run on the same context: the pipeline's buffers and events are reused)
+                st = ctx.run()
+                _check_final(ctx, g.ids, T, vals, keep, st)
+                assert ctx.state_hash() == o.state_hash(), name            # registers + Kahan words as the LAST REAL pass left them
+                assert (st["pipelined_passes"] > 10) == (name != "stepwise"), (name, st["pipelined_passes"])
+                seen[name] = [tuple(ps[f] for f in keys) for ps in ctx.pass_stats()]
+                assert len(seen[name]) == T and all(ps["ms_gpu"] > 0 for ps in ctx.pass_stats()), name
+    assert seen["pipelined"] == seen["stepwise"] == seen["pipelined_staged_every_pass"]
+    # ... and the same bookkeeping as stepping through the C ABI one pass at a time
+    with gpu_ctx_factory() as ctx:
+        ctx.load_dense(g.ids, g.row_ptr, g.src)
+        ctx.begin()
+        while ctx.step():
+            pass
+        ctx.finish()
+        assert [tuple(ps[f] for f in keys) for ps in ctx.pass_stats()] == seen["pipelined"]
+
+
 def test_salted_edge_records_match_faithful_oracle(gpu_ctx_factory):
     g = synth.RmatGraph(12, 30_000)
     e = g.edges(salt=1, salt_seed=3)
@@ -409,6 +443,35 @@ def test_store_harmonic_writes_readable_stores(gpu_ctx_factory, tmp_path):
     store_harmonic(fixture, str(tmp_path / "fixture"))
     r = kv.Db(str(tmp_path / "fixture" / "harmonic_rank"), "u64", str(tmp_path))
     assert (r.get(graphs.C), r.get(graphs.A), r.get(graphs.B), r.get(graphs.D)) == (0, 1, 2, None)  # harmonic.rs:465-473
+
+
+def test_store_from_the_context_equals_the_host_sorted_store(gpu_ctx_factory, tmp_path):
+    """hb_store_harmonic_results [r5]: the key order of both databases from a 136-bit radix sort on the device (bincode key BYTES: a
+    class byte, then the integer little endian - not NodeID order) must give the same files, byte for byte, as hb_store_harmonic's
+    host sort of the same arrays.  Ids of every bincode length class (1, 3, 5, 9, 17 bytes, both sides of every boundary) and an
+    R-MAT graph with hashed ids."""
+    import glob
+    special = [1, 5, 250, 251, 252, 65535, 65536, 65537, (1 << 32) - 1, 1 << 32, (1 << 32) + 9, (1 << 64) - 1, 1 << 64, (1 << 64) + 1,
+               (1 << 100) + 7, (1 << 127) + 3, (1 << 128) - 1, 254, 253, 1 << 16, 3 << 40]
+    chain = graphs.dense_from_tuples([(a, b, 0) for a, b in zip(special, special[1:])] + [(special[-1], special[0], 0), (special[3], special[9], 0)])
+    rmat = synth.RmatGraph(12, 30_000)
+    for case, (ids, row_ptr, src) in enumerate((chain, (rmat.ids, rmat.row_ptr, rmat.src))):
+        with gpu_ctx_factory() as ctx:
+            ctx.load_dense(ids, row_ptr, src)
+            ctx.run()
+            rid, rvals = ctx.results()
+            ranks = ctx.ranks()
+            a, b = tmp_path / ("dev%d" % case), tmp_path / ("host%d" % case)
+            ctx.store_harmonic(str(a))
+            _lib.store_harmonic(str(b), rid, rvals, ranks)
+            assert len(rid) > (10 if case == 0 else 1000)
+            for db in ("harmonic", "harmonic_rank"):
+                for ext in ("blobs", "bid", "ids", "blm"):
+                    fa, fb = glob.glob(str(a / db / ("*." + ext))), glob.glob(str(b / db / ("*." + ext)))
+                    assert len(fa) == 1 and len(fb) == 1, (db, ext)
+                    assert open(fa[0], "rb").read() == open(fb[0], "rb").read(), (case, db, ext)
+            with pytest.raises(_lib.HyperballError):
+                ctx.store_harmonic(str(a))  # the directory holds databases now: refused like the host entry point
 
 
 def test_result_ranks_match_store_harmonic_order(gpu_ctx_factory):
