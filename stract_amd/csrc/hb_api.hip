@@ -1265,16 +1265,25 @@ int hb_store_harmonic_results(hb_ctx *c, const char *output, char *err, uint64_t
         if (rc2) return rc2;
         const uint64_t k = c->res_count;
         // the (NodeID, f64) list and the ranks, as hb_result_copy / hb_result_ranks return them
-        std::vector<hb_u128> ids(k);
-        std::vector<double> vals(k);
-        std::vector<uint64_t> ranks(k);
+        RawVec<hb_u128> ids(k); // (uninitialised: hb_result_copy fills them on all host cores, the ranks come off the device)
+        RawVec<double> vals(k);
+        RawVec<uint64_t> ranks(k);
+        const bool trace = std::getenv("HB_TRACE_STORE") != nullptr;
+        double t_lap = now_ms();
+        auto lap = [&](const char *what) {
+            if (trace) std::fprintf(stderr, "[hb store] %-28s %8.3f s\n", what, (now_ms() - t_lap) * 1e-3);
+            t_lap = now_ms();
+        };
         if ((rc2 = hb_result_copy(c, ids.data(), vals.data(), k))) return rc2;
+        lap("result list (host cores)");
         if ((rc2 = hb_result_ranks(c, ranks.data(), k))) return rc2;
+        lap("ranks (device sort)");
         // the key order of both databases: one radix sort on the device instead of a comparison sort of 24-byte records on the host
-        std::vector<StoreKey> sorted(k);
+        StoreKeyVec sorted(k);
         const std::string e = gpu_store_keys((void *)c->stream, ids.data(), k, sorted.data());
         if (!e.empty()) return fail(c, e.find("memory") != std::string::npos ? HB_ERR_NOMEM : HB_ERR_HIP, "hb_store_harmonic_results: " + e);
-        std::vector<hb_u128>().swap(ids);
+        lap("key order (device sort)");
+        RawVec<hb_u128>().swap(ids);
         char msg[512] = {0};
         const int rc3 = store_harmonic_presorted(output, &sorted, vals.data(), ranks.data(), msg, sizeof(msg));
         if (rc3) return fail(c, rc3, msg);

@@ -5,7 +5,10 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <memory>
 #include <string>
+#include <type_traits>
+#include <utility>
 #include <vector>
 
 #include "../../include/hyperball.h"
@@ -284,10 +287,33 @@ struct StoreKey {
     }
 };
 
+// std::vector whose resize / sized constructor leaves trivially-constructible elements UNINITIALISED: the arrays of the store path are
+// filled at once by a copy from the device or by all host cores (value-initialising 4.4 GB on one thread first cost C4 two seconds)
+template <class T>
+struct DefaultInitAllocator : std::allocator<T> {
+    template <class U>
+    struct rebind {
+        using other = DefaultInitAllocator<U>;
+    };
+    using std::allocator<T>::allocator;
+    template <class U>
+    void construct(U *p) noexcept(std::is_nothrow_default_constructible<U>::value)
+    {
+        ::new (static_cast<void *>(p)) U;
+    }
+    template <class U, class... Args>
+    void construct(U *p, Args &&...args)
+    {
+        ::new (static_cast<void *>(p)) U(std::forward<Args>(args)...);
+    }
+};
+template <class T>
+using RawVec = std::vector<T, DefaultInitAllocator<T>>;
+using StoreKeyVec = RawVec<StoreKey>;
 // keys of `count` ids in ascending key-byte order (bincode varint encodings, serialized.rs:86-92), computed on the device: ids go
 // up once, (key words, index) come back sorted - a 136-bit LSD radix sort (stable: one pass on the 17th byte, then 128 bits)
 std::string gpu_store_keys(void *stream, const hb_u128 *ids, uint64_t count, StoreKey *sorted_out);
 // store_harmonic (centrality/mod.rs:72-114) from keys that are already in order; *sorted is consumed
-int store_harmonic_presorted(const char *output, std::vector<StoreKey> *sorted, const double *centralities, const uint64_t *ranks, char *err, size_t err_len);
+int store_harmonic_presorted(const char *output, StoreKeyVec *sorted, const double *centralities, const uint64_t *ranks, char *err, size_t err_len);
 } // namespace hb
 #endif

@@ -438,6 +438,7 @@ struct Bloom {
 };
 
 using Entry = hb::StoreKey; // (hb_internal.h: the device sort of hb_store_harmonic_results produces the same records)
+using EntryVec = hb::StoreKeyVec; // (elements left uninitialised on resize: every user fills them at once)
 
 std::string uuid_v4()
 {
@@ -506,7 +507,7 @@ int existing_segments(const std::string &dir)
     return s.find('"', open) < close ? 1 : 0;
 }
 
-bool fst_sequential(const std::vector<Entry> &e, const std::string &path, std::string *why)
+bool fst_sequential(const EntryVec &e, const std::string &path, std::string *why)
 {
     FileSink out(path);
     if (!out.ok()) {
@@ -531,7 +532,7 @@ bool fst_sequential(const std::vector<Entry> &e, const std::string &path, std::s
 }
 
 // the .ids file, sub-tries in parallel (see the top of the file)
-bool fst_parallel(const std::vector<Entry> &e, const std::string &path, std::string *why)
+bool fst_parallel(const EntryVec &e, const std::string &path, std::string *why)
 {
     const size_t n = e.size();
     // group = maximal run of keys of length >= 4 with the same first three bytes; shorter keys go through insert()
@@ -635,7 +636,7 @@ bool pwrite_all(int fd, const uint8_t *p, size_t n, uint64_t off)
 // buckets), then every bucket is sorted on its own, buckets shared out dynamically.  Skewed key sets (tests: small
 // integers) only lose balance, never correctness.  (libstdc++'s parallel-mode multiway merge sort took 1.1 s for 5 M
 // entries on 8 cores - more than everything else together.)
-void parallel_sort(std::vector<Entry> &e)
+void parallel_sort(EntryVec &e)
 {
     const size_t n = e.size();
     if (n < (1u << 16)) {
@@ -658,7 +659,7 @@ void parallel_sort(std::vector<Entry> &e)
     const size_t nb = (size_t)mask + 1;
     const int nt = hb::host_threads();
     std::vector<std::vector<size_t>> hist((size_t)nt, std::vector<size_t>(nb, 0));
-    std::vector<Entry> tmp(n);
+    EntryVec tmp(n);
     std::vector<size_t> start(nb + 1, 0);
 #pragma omp parallel num_threads(nt)
     {
@@ -694,10 +695,10 @@ void parallel_sort(std::vector<Entry> &e)
 }
 
 // keys of all entries in key-byte order; duplicate ids are an error
-int sort_entries(const hb_u128 *ids, uint64_t count, std::vector<Entry> *out, char *err, size_t err_len)
+int sort_entries(const hb_u128 *ids, uint64_t count, EntryVec *out, char *err, size_t err_len)
 {
     if (count >= (1ull << 56)) return fail(err, err_len, HB_ERR_INVALID, "hb_store_write: too many entries");
-    std::vector<Entry> &e = *out;
+    EntryVec &e = *out;
     e.resize(count);
 #pragma omp parallel for num_threads(hb::host_threads()) schedule(static)
     for (uint64_t i = 0; i < count; i++) {
@@ -718,7 +719,7 @@ int sort_entries(const hb_u128 *ids, uint64_t count, std::vector<Entry> *out, ch
 }
 
 // .blobs and .bid of one database from the sorted entries (SegmentWriter::insert, segment.rs:66-75)
-bool write_blobs(const std::vector<Entry> &e, const void *values, int value_kind, const std::string &base, std::string *why)
+bool write_blobs(const EntryVec &e, const void *values, int value_kind, const std::string &base, std::string *why)
 {
     const uint64_t count = e.size();
     const uint64_t block = 1ull << 16;
@@ -798,7 +799,7 @@ struct Target {
 };
 
 // one key set, any number of databases over it
-int write_dbs(const std::vector<Target> &targets, const hb_u128 *ids, uint64_t count, char *err, size_t err_len, std::vector<Entry> *presorted = nullptr)
+int write_dbs(const std::vector<Target> &targets, const hb_u128 *ids, uint64_t count, char *err, size_t err_len, EntryVec *presorted = nullptr)
 {
     if (count && !ids && !presorted) return fail(err, err_len, HB_ERR_INVALID, "hb_store_write: NULL array with count > 0");
     for (const Target &t : targets) {
@@ -823,7 +824,7 @@ int write_dbs(const std::vector<Target> &targets, const hb_u128 *ids, uint64_t c
         std::fprintf(stderr, "[hb store] %-28s %8.3f s  (%d threads)\n", what, t - t_lap, hb::host_threads());
         t_lap = t;
     };
-    std::vector<Entry> entries;
+    EntryVec entries;
     if (presorted) {
         // the key order was computed elsewhere (hb_store_harmonic_results: a radix sort on the device, hb_ingest.hip gpu_store_keys):
         // trusted for order only after the same check the host sort ends with - strictly ascending keys, every index in range
@@ -914,7 +915,7 @@ int guarded(char *err, size_t err_len, F &&f)
 
 // hb_internal.h: store_harmonic with the key order already computed (StoreKey = Entry, three words)
 namespace hb {
-int store_harmonic_presorted(const char *output, std::vector<StoreKey> *sorted, const double *centralities, const uint64_t *ranks, char *err, size_t err_len)
+int store_harmonic_presorted(const char *output, StoreKeyVec *sorted, const double *centralities, const uint64_t *ranks, char *err, size_t err_len)
 {
     return guarded(err, err_len, [&]() -> int {
         if (!output || !*output || !sorted) return fail(err, err_len, HB_ERR_INVALID, "hb_store_harmonic: output is empty");
