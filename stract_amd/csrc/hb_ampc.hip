@@ -256,7 +256,8 @@ int apply(hbu_table *t, const hb_u128 *keys, const uint8_t *counters, uint64_t c
     // ---- everything that can fail for lack of memory comes BEFORE the index changes: room for count new keys (every pair might
     // bring one), their counters, the batch's work memory
     int rc;
-    if (2 * (t->committed + count) > t->slots && (rc = rebuild_index(t, 2 * (t->committed + count), t->committed))) return rc;
+    // (slots = the power of two >= 2 x keys: the rounding is what makes repeated growth geometric)
+    if (2 * (t->committed + count) > t->slots && (rc = rebuild_index(t, t->committed + count, t->committed))) return rc;
     if ((rc = reserve(t, t->committed + count))) return rc;
     size_t sort_bytes = 0, select_bytes = 0;
     const uint32_t n32 = (uint32_t)count;

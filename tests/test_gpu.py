@@ -112,6 +112,24 @@ def test_empty_and_singleton_graphs(gpu_ctx_factory):
             ctx.results()
 
 
+def test_release_cached_memory(gpu_ctx_factory):
+    """hb_release_cached_memory [ABI 5, ADVICE r4]: what the caching allocator keeps after a context is gone goes back to the runtime on
+    request (other allocators in the process cannot reclaim it themselves); contexts that are alive keep what they hold."""
+    import ctypes
+    lib = _lib.load()
+    g = synth.RmatGraph(13, 60_000)
+    with gpu_ctx_factory() as ctx:
+        ctx.load_edges(g.edges(salt=1, salt_seed=5))   # the ingest's and the planner's work memory is cached after this
+        held = ctypes.c_uint64(0)
+        assert lib.hb_release_cached_memory(ctypes.byref(held)) == _lib.HB_OK
+        st = ctx.run()                                  # the context's own buffers were not touched
+        assert st["passes"] > 0
+    assert lib.hb_release_cached_memory(ctypes.byref(held)) == _lib.HB_OK
+    again = ctypes.c_uint64(1)
+    assert lib.hb_release_cached_memory(ctypes.byref(again)) == _lib.HB_OK and again.value == 0  # nothing left to give back
+    assert lib.hb_release_cached_memory(None) == _lib.HB_OK
+
+
 def test_error_behaviour_of_the_boundary(gpu_ctx_factory):
     """Call-order and argument errors come back as negative codes with a message (include/hyperball.h: nothing unwinds, nothing
     computes on bad input) and leave the context usable."""
@@ -903,6 +921,10 @@ def test_c2_config_bit_exact_and_properties(gpu_ctx_factory):
             ctx.load_dense(g.ids, g.row_ptr, g.src)
             st = ctx.run()
             _check_final(ctx, g.ids, T, vals, keep, st)
+            # [r5] at this size (n >= 2^20) the results travel while the passes run under the DEFAULT policy (first snapshot when the
+            # frontier starts to shrink) and the tail passes are queued ahead: both on, both exact
+            assert g.n >= (1 << 20) and st["result_stages"] >= 1 and 0 < st["result_list"] < g.n // 8 + 4096, (g.n, st["result_stages"], st["result_list"])
+            assert st["pipelined_passes"] >= 1, st["pipelined_passes"]
             regs = ctx.registers()
             assert np.array_equal(regs, o.registers())
             st2 = ctx.run()  # re-running the loaded graph gives the same answer
