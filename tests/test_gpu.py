@@ -318,6 +318,39 @@ def test_run_pipelines_the_convergence_tail_and_books_it_like_single_steps(gpu_c
         assert [tuple(ps[f] for f in keys) for ps in ctx.pass_stats()] == seen["pipelined"]
 
 
+def test_tail_pipeline_when_a_late_change_would_ask_for_a_dense_pass(gpu_ctx_factory):
+    """Found by tools/diff_fuzz.py on the MI355X (round 5): deep in the convergence tail ONE node with a large share of all out-links
+    changes (a chain trickling into a hub whose counter is already large, so that it moves only now and then) - A_{t+1} jumps above
+    the bitmap / dense thresholds, and the one-pass-at-a-time driver answers with a dense pass.  A pass of hb_run's pipeline is
+    queued before that is known and must be a (device-guarded) sweep pass whatever the thresholds say; same values, same pass
+    count, same per-pass changed counts."""
+    chain = [(1000 + i, 1001 + i, 0) for i in range(60)]
+    hub = 5000
+    leaves = [(hub, 10_000 + j, 0) for j in range(3000)]
+    background = [(20_000 + (j * 7) % 500, 20_000 + (j * 13 + 1) % 500, 0) for j in range(1500)]
+    feed = [(20_000 + j, hub, 0) for j in range(400)]
+    ids, row_ptr, src = graphs.dense_from_tuples(chain + [(1060, hub, 0)] + leaves + background + feed)
+    o = hbo.Dense(np.ascontiguousarray(ids["lo"]), row_ptr, src)
+    T = o.run()
+    vals, keep, k = o.finish()
+    seen = {}
+    for name, kw in (("pipelined", dict()), ("stepwise", dict(tune=(0, 0x100000))), ("pipelined_chunk8", dict(chunk=8))):
+        with gpu_ctx_factory(**kw) as ctx:
+            ctx.load_dense(ids, row_ptr, src)
+            st = ctx.run()
+            _check_final(ctx, ids, T, vals, keep, st)
+            assert ctx.state_hash() == o.state_hash(), name
+            ps = ctx.pass_stats()
+            seen[name] = [(p["pass"], p["changed"], p["active_edges"]) for p in ps]
+            first_sweep = min(p["pass"] for p in ps if p["mode"] == 2)
+            late = [p["mode"] for p in ps if p["pass"] > first_sweep]
+            if name == "stepwise":
+                assert st["pipelined_passes"] == 0 and any(m != 2 for m in late), late  # the hub moved: a dense pass in the middle of the tail
+            else:
+                assert st["pipelined_passes"] >= 5 and all(m == 2 for m in late), (st["pipelined_passes"], late)
+    assert seen["pipelined"] == seen["stepwise"] == seen["pipelined_chunk8"]
+
+
 def test_salted_edge_records_match_faithful_oracle(gpu_ctx_factory):
     g = synth.RmatGraph(12, 30_000)
     e = g.edges(salt=1, salt_seed=3)
