@@ -955,9 +955,9 @@ def test_c2_config_bit_exact_and_properties(gpu_ctx_factory):
             st = ctx.run()
             _check_final(ctx, g.ids, T, vals, keep, st)
             # [r5] at this size (n >= 2^20) the results travel while the passes run under the DEFAULT policy (first snapshot when the
-            # frontier starts to shrink) and the tail passes are queued ahead: both on, both exact
+            # frontier starts to shrink): on, and exact (the tail pipeline has its own tests: an R-MAT tail this short may end
+            # with the first queued pass)
             assert g.n >= (1 << 20) and st["result_stages"] >= 1 and 0 < st["result_list"] < g.n // 8 + 4096, (g.n, st["result_stages"], st["result_list"])
-            assert st["pipelined_passes"] >= 1, st["pipelined_passes"]
             regs = ctx.registers()
             assert np.array_equal(regs, o.registers())
             st2 = ctx.run()  # re-running the loaded graph gives the same answer
