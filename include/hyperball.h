@@ -170,6 +170,8 @@ typedef struct hb_stats {
     uint64_t pipelined_passes;  /* [ABI 5] passes of the last hb_run that were queued BEFORE the host had read the previous pass'
                                    counters (convergence tail, one rank: a pass that changed <= 4096 nodes in sweep mode is
                                    followed by passes guarded on the device; the pass behind the loop's last one does nothing) */
+    uint64_t tail_kernel_passes; /* [ABI 5] passes of the last run that ONE single-workgroup launch ran from work lists (the far
+                                   convergence tail: <= 4096 changed nodes with short reader lists; several passes per launch) */
 } hb_stats;
 
 typedef struct hb_pass_stats {
@@ -181,7 +183,9 @@ typedef struct hb_pass_stats {
                                row counts only when one of its partials changed); dense passes: 0   */
     uint32_t mode;          /* 0 = dense (no frontier test), 1 = frontier bitmap, 2 = sweep (touch bitmap of the rows
                                that read a changed node; only those rows run), 3 = reference tail
-                               (HB_FLAG_REFERENCE_TAIL: update_changed_counters over the page-level records)  */
+                               (HB_FLAG_REFERENCE_TAIL: update_changed_counters over the page-level records)  
+                               4 = [ABI 5] the far tail as one workgroup: the pass ran from work lists inside a launch that may
+                               hold several passes (hb_tail.hip.h); ms_gpu = the launch's time / its passes                       */
     float    ms_gpu;        /* GPU time of the pass (all its launches + collective)         */
     float    ms_main;       /* GPU time of the dominant launch (real rows)                  */
     float    ms_collective;

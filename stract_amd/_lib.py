@@ -91,6 +91,7 @@ class HbStats(ctypes.Structure):
         ("result_stages", ctypes.c_uint64),
         ("result_list", ctypes.c_uint64),
         ("pipelined_passes", ctypes.c_uint64),
+        ("tail_kernel_passes", ctypes.c_uint64),
     ]
 
     def as_dict(self):

@@ -108,6 +108,15 @@ struct hb_ctx {
     const unsigned long long *spec_guard = nullptr; // set while step_local queues a guarded pass
     bool pipelined = false;                         // step_local: take this pass' events from ev_pool
     uint64_t pipelined_passes = 0;                  // passes of this run queued ahead of their predecessor's read-back
+    // the far tail as one workgroup (hb_tail.hip.h): work lists, their counts / status words, and whether the lists describe the
+    // bitmaps as they are now (any pass run by other kernels invalidates them: the next entry collects them again)
+    uint32_t *d_tl_changed[2] = {nullptr, nullptr}, *d_tl_vchanged[2] = {nullptr, nullptr}, *d_tl_dirty[2] = {nullptr, nullptr};
+    uint32_t *d_tl_work = nullptr, *d_tl_count = nullptr;
+    uint32_t *h_tl_count = nullptr; // pinned, kTcWords
+    bool tl_valid = false;
+    bool tl_declined = false;       // the kernel found the next pass too large for its lists: do not ask again before an ordinary pass has run
+    uint64_t tail_kernel_passes = 0;
+    hipEvent_t tl_ev[2] = {nullptr, nullptr};
     unsigned long long *h_slot = nullptr;           // pinned, 2 x kCounterWords: the counters of the two passes in flight
     hipEvent_t slot_done[2] = {nullptr, nullptr};   // pass q's counters have arrived in h_slot[q & 1]
     uint64_t wire_bytes = 0;      // counter bytes this rank received over the run (changed-only accounting)
@@ -244,6 +253,9 @@ void free_graph_buffers(hb_ctx *c)
     c->d_seeds = c->d_heavy = nullptr;
     c->d_sparse_counts = nullptr;
     c->sparse_ok = false;
+    c->d_tl_changed[0] = c->d_tl_changed[1] = c->d_tl_vchanged[0] = c->d_tl_vchanged[1] = c->d_tl_dirty[0] = c->d_tl_dirty[1] = nullptr;
+    c->d_tl_work = c->d_tl_count = nullptr;
+    c->tl_valid = false;
     c->d_tail_ptr = nullptr;
     c->d_tail_to = nullptr;
     c->tail_count = 0;
@@ -372,6 +384,13 @@ int build_sparse_support(hb_ctx *c)
     if ((rc = dev_alloc(c, &c->d_seeds, p.n_pad))) return rc;
     if ((rc = dev_alloc(c, &c->d_heavy, p.n_pad))) return rc;
     if ((rc = dev_alloc(c, &c->d_sparse_counts, 64))) return rc;
+    for (int k = 0; k < 2; k++) { // the tail kernel's lists (hb_tail.hip.h): 2.7 MB in all
+        if ((rc = dev_alloc(c, &c->d_tl_changed[k], hbk::kTailCap))) return rc;
+        if ((rc = dev_alloc(c, &c->d_tl_vchanged[k], hbk::kTailCap))) return rc;
+        if ((rc = dev_alloc(c, &c->d_tl_dirty[k], hbk::kTailCap))) return rc;
+    }
+    if ((rc = dev_alloc(c, &c->d_tl_work, (size_t)(hbk::kTailLevels + 1) * hbk::kTailCap))) return rc;
+    if ((rc = dev_alloc(c, &c->d_tl_count, hbk::kTcWords))) return rc;
     if ((rc = dev_alloc(c, &d_count, rows_total))) return rc; // stays allocated (small next to out_rows)
     HB_HIP(hipMemsetAsync(c->d_touch, 0, (c->bits_words + 64) * sizeof(uint32_t), c->stream));
     HB_HIP(hipMemsetAsync(d_count, 0, rows_total * sizeof(uint32_t), c->stream));
@@ -553,6 +572,9 @@ void hb_destroy(hb_ctx *ctx)
     if (ctx->h_counters) (void)hipHostFree(ctx->h_counters);
     if (ctx->h_rank_cnt) (void)hipHostFree(ctx->h_rank_cnt);
     if (ctx->h_slot) (void)hipHostFree(ctx->h_slot);
+    if (ctx->h_tl_count) (void)hipHostFree(ctx->h_tl_count);
+    for (hipEvent_t e : ctx->tl_ev)
+        if (e) (void)hipEventDestroy(e);
     for (hipEvent_t e : ctx->slot_done)
         if (e) (void)hipEventDestroy(e);
     for (auto &es : ctx->ev_pool)
@@ -987,6 +1009,8 @@ int hb_begin(hb_ctx *c)
         c->pstats.clear();
         c->pending_times.clear();
         c->pipelined_passes = 0;
+        c->tail_kernel_passes = 0;
+        c->tl_valid = c->tl_declined = false;
         c->begun = true;
         c->finished = false;
         c->res_count = 0;
@@ -1020,6 +1044,14 @@ int hb_step(hb_ctx *c, int *has_changes)
         if (!c) return HB_ERR_INVALID;
         int rc = set_device(c);
         if (rc) return rc;
+        if (tail_kernel_ready(c)) { // the far tail: one single-workgroup launch runs the pass from work lists (hb_tail.hip.h)
+            uint32_t ran = 0;
+            if ((rc = tail_kernel_run(c, 1, &ran))) return rc;
+            if (ran) {
+                if (has_changes) *has_changes = c->has_changes ? 1 : 0;
+                return HB_OK;
+            }
+        }
         if ((rc = step_local(c))) return rc;
         return step_finish(c, has_changes);
     });
@@ -1100,6 +1132,7 @@ int hb_finish(hb_ctx *c)
             std::fprintf(stderr, "[hb results] hb_finish: entered at %.3f ms, done at %.3f ms (host clock); %u snapshots, list %llu\n", t0, now_ms(), c->rs.stages,
                          shipped ? (unsigned long long)*c->rs.h_count : 0ull);
         c->stats.pipelined_passes = c->pipelined_passes;
+        c->stats.tail_kernel_passes = c->tail_kernel_passes;
         c->stats.result_stages = c->rs.stages;
         c->stats.result_list = shipped ? *c->rs.h_count : 0;
         c->rs.valid = false;
@@ -1130,6 +1163,12 @@ int hb_run(hb_ctx *c, hb_stats *stats)
         const bool trace = std::getenv("HB_TRACE_RESULTS") != nullptr;
         // harmonic.rs:237-240: loop { if !has_changes { break } ... }
         while (has) {
+            if (tail_kernel_ready(c)) { // passes from work lists, several per launch, until the loop ends or the changed set outgrows the lists
+                uint32_t ran = 0;
+                if ((rc = tail_kernel_run(c, 64, &ran))) return rc;
+                has = c->has_changes ? 1 : 0;
+                if (ran) continue;
+            }
             if (tail_pipeline_ready(c)) {
                 if ((rc = tail_pipeline(c, &has))) return rc; // runs passes until the loop ends or the changed set grows again
                 continue;

@@ -696,6 +696,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void f
 
 } // namespace hbk
 #include "hb_sweep.hip.h"
+#include "hb_tail.hip.h"
 namespace hbk {
 
 // ---- unfused epilogue (edge-partition mode, after the all-reduce) ----------------------

@@ -227,6 +227,13 @@ EXPECT_MODES = {"frontier_always": {0, 1}, "frontier_always_slot_by_slot": {0, 1
 VARIANTS["long_tail_default"] = dict()
 VARIANTS["long_tail_chunk8"] = dict(chunk=8)
 VARIANTS["long_tail_staged_results"] = dict(tune=(0, 0x8000))
+# round 5: the far tail as one workgroup (hb_tail.hip.h; hb_step lets it run ONE pass per launch, so every pass is compared): default =
+# after a sweep pass that changed <= 4096 nodes; bit 22 = after any pass (right behind the dense passes: stale virtual bits, large
+# dirty sets, lists that overflow and make it decline); bit 21 = never
+VARIANTS["long_tail_tail_kernel_after_any_pass"] = dict(tune=(0, 0x400000))
+VARIANTS["long_tail_tail_kernel_after_any_pass_chunk4"] = dict(chunk=4, tune=(0, 0x400000))
+VARIANTS["long_tail_tail_kernel_off"] = dict(tune=(0, 0x200000))
+VARIANTS["tail_kernel_after_any_pass_sparse_always"] = dict(chunk=8, tune=(0, 0x400000, 101, 0, 0, 0, 1))
 
 
 @pytest.mark.parametrize("variant", sorted(VARIANTS))
@@ -296,8 +303,9 @@ def test_run_pipelines_the_convergence_tail_and_books_it_like_single_steps(gpu_c
     vals, keep, k = o.finish()
     keys = ("pass", "changed", "active_edges", "touched", "mode")
     seen = {}
-    for name, kw in (("pipelined", dict()), ("stepwise", dict(tune=(0, 0x100000))), ("pipelined_chunk8", dict(chunk=8)),
-                     ("pipelined_staged_every_pass", dict(tune=(0, 0x8000)))):
+    # (bit 21 = without the single-workgroup tail kernel, which would otherwise take these passes: it has its own test below)
+    for name, kw in (("pipelined", dict(tune=(0, 0x200000))), ("stepwise", dict(tune=(0, 0x300000))), ("pipelined_chunk8", dict(chunk=8, tune=(0, 0x200000))),
+                     ("pipelined_staged_every_pass", dict(tune=(0, 0x208000)))):
         with gpu_ctx_factory(**kw) as ctx:
             ctx.load_dense(g.ids, g.row_ptr, g.src)
             for again in range(2):  # (a second run on the same context: the pipeline's buffers and events are reused)
@@ -309,13 +317,49 @@ def test_run_pipelines_the_convergence_tail_and_books_it_like_single_steps(gpu_c
                 assert len(seen[name]) == T and all(ps["ms_gpu"] > 0 for ps in ctx.pass_stats()), name
     assert seen["pipelined"] == seen["stepwise"] == seen["pipelined_staged_every_pass"]
     # ... and the same bookkeeping as stepping through the C ABI one pass at a time
-    with gpu_ctx_factory() as ctx:
+    with gpu_ctx_factory(tune=(0, 0x200000)) as ctx:
         ctx.load_dense(g.ids, g.row_ptr, g.src)
         ctx.begin()
         while ctx.step():
             pass
         ctx.finish()
         assert [tuple(ps[f] for f in keys) for ps in ctx.pass_stats()] == seen["pipelined"]
+
+
+def test_tail_kernel_runs_whole_passes_from_work_lists(gpu_ctx_factory):
+    """The far tail as ONE workgroup [r5] (hb_tail.hip.h): once a sweep pass has changed <= 4096 nodes with short reader lists, a single
+    launch runs whole passes from work lists - seeds -> touched rows by level -> node rows -> carry-over / `+= 0.0` - keeps every
+    bitmap exact by list, and goes on by itself until a pass changes nothing, up to 64 passes per launch (hb_run) or one (hb_step:
+    the per-pass variants of test_per_pass_state_matches_oracle check registers / Kahan words / sizes after each of them).  Here:
+    the same run through hb_run with the kernel on, off, and entered right after the dense passes (bit 22: stale virtual bits, a
+    large Kahan-dirty set), on single- and multi-level chunk trees: same pass count, same per-pass changed counts / touched rows /
+    A_t, same final list, state checksum = the oracle's; and the multi-kernel path takes over and hands back in mid-run (a pass
+    budget of one launch is 64 passes; a second run on the same context re-collects its lists)."""
+    g = synth.RmatGraph(13, 60_000, tail=(300, 800, 10))
+    o = hbo.Dense(g.id_low64(), g.row_ptr, g.src)
+    T = o.run()
+    vals, keep, k = o.finish()
+    keys = ("pass", "changed", "active_edges", "touched")
+    seen = {}
+    for name, kw in (("on", dict()), ("off", dict(tune=(0, 0x200000))), ("after_any_pass", dict(tune=(0, 0x400000))), ("on_chunk8", dict(chunk=8)),
+                     ("after_any_pass_chunk4_staged", dict(chunk=4, tune=(0, 0x408000)))):
+        with gpu_ctx_factory(**kw) as ctx:
+            ctx.load_dense(g.ids, g.row_ptr, g.src)
+            for again in range(2):
+                st = ctx.run()
+                _check_final(ctx, g.ids, T, vals, keep, st)
+                assert ctx.state_hash() == o.state_hash(), name
+                ps = ctx.pass_stats()
+                seen[name] = [tuple(p[f] for f in keys) for p in ps]
+                in_kernel = sum(p["mode"] == 4 for p in ps)
+                assert in_kernel == st["tail_kernel_passes"] and (in_kernel >= 10) == (name != "off"), (name, in_kernel)
+                if "after_any_pass" in name:
+                    assert in_kernel > seen_on, (in_kernel, seen_on)  # entered earlier than the default policy does
+                elif name == "on":
+                    seen_on = in_kernel
+    assert seen["on"] == seen["off"]  # (touched rows included: the sweep kernels and the list kernel count the same rows)
+    strip = lambda rows: [r[:3] for r in rows]  # (a bitmap pass counts touched rows its own way: compare changed counts and A_t there)
+    assert strip(seen["on"]) == strip(seen["after_any_pass"]) == strip(seen["on_chunk8"]) == strip(seen["after_any_pass_chunk4_staged"])
 
 
 def test_tail_pipeline_when_a_late_change_would_ask_for_a_dense_pass(gpu_ctx_factory):
@@ -334,7 +378,8 @@ def test_tail_pipeline_when_a_late_change_would_ask_for_a_dense_pass(gpu_ctx_fac
     T = o.run()
     vals, keep, k = o.finish()
     seen = {}
-    for name, kw in (("pipelined", dict()), ("stepwise", dict(tune=(0, 0x100000))), ("pipelined_chunk8", dict(chunk=8))):
+    for name, kw in (("pipelined", dict(tune=(0, 0x200000))), ("stepwise", dict(tune=(0, 0x300000))), ("pipelined_chunk8", dict(chunk=8, tune=(0, 0x200000))),
+                     ("tail_kernel", dict()), ("tail_kernel_chunk8", dict(chunk=8))):
         with gpu_ctx_factory(**kw) as ctx:
             ctx.load_dense(ids, row_ptr, src)
             st = ctx.run()
@@ -342,13 +387,15 @@ def test_tail_pipeline_when_a_late_change_would_ask_for_a_dense_pass(gpu_ctx_fac
             assert ctx.state_hash() == o.state_hash(), name
             ps = ctx.pass_stats()
             seen[name] = [(p["pass"], p["changed"], p["active_edges"]) for p in ps]
-            first_sweep = min(p["pass"] for p in ps if p["mode"] == 2)
+            first_sweep = min(p["pass"] for p in ps if p["mode"] in (2, 4))
             late = [p["mode"] for p in ps if p["pass"] > first_sweep]
             if name == "stepwise":
-                assert st["pipelined_passes"] == 0 and any(m != 2 for m in late), late  # the hub moved: a dense pass in the middle of the tail
-            else:
+                assert st["pipelined_passes"] == 0 and any(m not in (2, 4) for m in late), late  # the hub moved: a dense pass in the middle of the tail
+            elif name.startswith("pipelined"):
                 assert st["pipelined_passes"] >= 5 and all(m == 2 for m in late), (st["pipelined_passes"], late)
-    assert seen["pipelined"] == seen["stepwise"] == seen["pipelined_chunk8"]
+            else:  # the single-workgroup kernel runs these passes (the hub's 3000 readers fit its lists) - or hands one to the other path
+                assert st["tail_kernel_passes"] >= 5 and all(m in (2, 4) for m in late), (st["tail_kernel_passes"], late)
+    assert seen["pipelined"] == seen["stepwise"] == seen["pipelined_chunk8"] == seen["tail_kernel"] == seen["tail_kernel_chunk8"]
 
 
 def test_salted_edge_records_match_faithful_oracle(gpu_ctx_factory):
@@ -612,7 +659,8 @@ def test_sweep_seeds_with_very_long_reader_lists(gpu_ctx_factory):
         tuples += [(leaf0 + k, leaf0 + K + (k % 7), 0) for k in range(0, K, 3)]   # a few leaves are read further on
         e = EdgeListGraph.from_tuples(tuples)
         fids, fvals, fst = hbo.faithful_run(e.host_edges())
-        for kw in (dict(tune=(0, 0, 101, 0, 0, 0, 1)), dict(tune=(0, 0x800, 101, 0, 0, 0, 1)), dict()):
+        # (bit 21: without the single-workgroup tail kernel, which would take these passes from the sweep kernels this test is about)
+        for kw in (dict(tune=(0, 0x200000, 101, 0, 0, 0, 1)), dict(tune=(0, 0x200800, 101, 0, 0, 0, 1)), dict()):
             hc = HarmonicCentrality.calculate(e, **kw)
             ids, vals = hc.arrays()
             assert hc.stats["passes"] == fst["passes"] and hc.stats["n"] == fst["n"], (K, kw)

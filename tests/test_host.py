@@ -50,7 +50,7 @@ def test_headers_are_plain_c99_and_struct_sizes_agree(tmp_path):
 def test_struct_layouts_match_header():
     assert ctypes.sizeof(_lib.HbOptions) == 4 * 7 + 128 + 32
     assert _lib.EDGE.itemsize == 40 and _lib.U128.itemsize == 16
-    assert ctypes.sizeof(_lib.HbStats) == 28 * 8  # ABI 5: + result_stages, result_list, pipelined_passes
+    assert ctypes.sizeof(_lib.HbStats) == 29 * 8  # ABI 5: + result_stages, result_list, pipelined_passes, tail_kernel_passes
     assert ctypes.sizeof(_lib.HbPassStats) == 4 * 8 + 6 * 4
 
 
