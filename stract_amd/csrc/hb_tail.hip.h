@@ -59,10 +59,13 @@ struct TailParams {
     uint32_t max_passes; // of this launch (hb_step: 1)
 };
 
-// ---- entry: the five lists from the bitmaps (grid-wide, once per entry into the tail kernel) --------------------------------
-// generation 0: changed[0] = nodes changed in the previous pass (seeds), changed[1] = two passes ago (their bits sit in the
-// bitmap this pass writes), vchanged[1] = the virtual rows' bits left in the bitmap this pass reads, vchanged[0] = those in the
-// other one, dirty[0] = the Kahan-dirty nodes.  Counts keep running past the capacity: the host enters only if all of them fit.
+// ---- entry: the lists from the bitmaps (grid-wide, once per entry into the tail kernel) -------------------------------------
+// generation 0: changed[0] = nodes changed in the previous pass (seeds), vchanged[0] = the virtual rows' bits in the bitmap the
+// NEXT pass reads, dirty[0] = the Kahan-dirty nodes.  The stale bits of two passes ago - node part of the bitmap this pass
+// writes, virtual part of the one it reads - are CLEARED here instead of being listed (at BASELINE sizes they are the changed set
+// of a pass that still changed a million nodes: no list holds them; every kernel of the other path rewrites those parts before it
+// reads them, so a cleared bitmap is as good to it as a stale one).  Counts keep running past the capacity: the loop kernel starts
+// a pass only if everything fits.
 __device__ __forceinline__ void tail_append_bits(uint32_t word, uint64_t first_row, uint32_t *list, uint32_t *count)
 {
     const int lane = threadIdx.x & 63;
@@ -95,10 +98,10 @@ __global__ __launch_bounds__(256) void tail_collect_kernel(const TailParams P)
         const bool in = w < all_words, node = w < node_words;
         const uint32_t a = in ? P.bits[cur][w] : 0u, b = in ? P.bits[cur ^ 1][w] : 0u, d = (in && node) ? P.kdirty[w] : 0u;
         tail_append_bits(node ? a : 0u, w << 5, P.changed[0], &P.count[kTcChanged + 0]);
-        tail_append_bits(node ? b : 0u, w << 5, P.changed[1], &P.count[kTcChanged + 1]);
-        tail_append_bits(node ? 0u : a, w << 5, P.vchanged[1], &P.count[kTcVirt + 1]);
         tail_append_bits(node ? 0u : b, w << 5, P.vchanged[0], &P.count[kTcVirt + 0]);
         tail_append_bits(d, w << 5, P.dirty[0], &P.count[kTcDirty + 0]);
+        if (in && node && b) P.bits[cur ^ 1][w] = 0;  // changed two passes ago: this pass writes its own set there
+        if (in && !node && a) P.bits[cur][w] = 0;     // virtual rows changed two passes ago: this pass sets its own
     }
 }
 
