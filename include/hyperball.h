@@ -171,7 +171,8 @@ typedef struct hb_stats {
                                    counters (convergence tail, one rank: a pass that changed <= 4096 nodes in sweep mode is
                                    followed by passes guarded on the device; the pass behind the loop's last one does nothing) */
     uint64_t tail_kernel_passes; /* [ABI 5] passes of the last run that ONE single-workgroup launch ran from work lists (the far
-                                   convergence tail: <= 4096 changed nodes with short reader lists; several passes per launch) */
+                                   convergence tail: <= 4096 changed nodes with short reader lists; several passes per launch).
+                                   Off by default (tune[1] bit 21 = on): measured no faster than the launches it replaces      */
 } hb_stats;
 
 typedef struct hb_pass_stats {

@@ -227,12 +227,12 @@ EXPECT_MODES = {"frontier_always": {0, 1}, "frontier_always_slot_by_slot": {0, 1
 VARIANTS["long_tail_default"] = dict()
 VARIANTS["long_tail_chunk8"] = dict(chunk=8)
 VARIANTS["long_tail_staged_results"] = dict(tune=(0, 0x8000))
-# round 5: the far tail as one workgroup (hb_tail.hip.h; hb_step lets it run ONE pass per launch, so every pass is compared): default =
-# after a sweep pass that changed <= 4096 nodes; bit 22 = after any pass (right behind the dense passes: stale virtual bits, large
-# dirty sets, lists that overflow and make it decline); bit 21 = never
+# round 5: the far tail as one workgroup (hb_tail.hip.h; off by default; hb_step lets it run ONE pass per launch, so every pass is
+# compared): bit 21 = on, after a sweep pass that changed <= 4096 nodes with short reader lists; bit 22 = on, after any pass (right
+# behind the dense passes: stale virtual bits, large dirty sets, lists that overflow and make it decline)
 VARIANTS["long_tail_tail_kernel_after_any_pass"] = dict(tune=(0, 0x400000))
 VARIANTS["long_tail_tail_kernel_after_any_pass_chunk4"] = dict(chunk=4, tune=(0, 0x400000))
-VARIANTS["long_tail_tail_kernel_off"] = dict(tune=(0, 0x200000))
+VARIANTS["long_tail_tail_kernel_on"] = dict(tune=(0, 0x200000))
 VARIANTS["tail_kernel_after_any_pass_sparse_always"] = dict(chunk=8, tune=(0, 0x400000, 101, 0, 0, 0, 1))
 
 
@@ -303,9 +303,8 @@ def test_run_pipelines_the_convergence_tail_and_books_it_like_single_steps(gpu_c
     vals, keep, k = o.finish()
     keys = ("pass", "changed", "active_edges", "touched", "mode")
     seen = {}
-    # (bit 21 = without the single-workgroup tail kernel, which would otherwise take these passes: it has its own test below)
-    for name, kw in (("pipelined", dict(tune=(0, 0x200000))), ("stepwise", dict(tune=(0, 0x300000))), ("pipelined_chunk8", dict(chunk=8, tune=(0, 0x200000))),
-                     ("pipelined_staged_every_pass", dict(tune=(0, 0x208000)))):
+    for name, kw in (("pipelined", dict()), ("stepwise", dict(tune=(0, 0x100000))), ("pipelined_chunk8", dict(chunk=8)),
+                     ("pipelined_staged_every_pass", dict(tune=(0, 0x8000)))):
         with gpu_ctx_factory(**kw) as ctx:
             ctx.load_dense(g.ids, g.row_ptr, g.src)
             for again in range(2):  # (a second run on the same context: the pipeline's buffers and events are reused)
@@ -317,7 +316,7 @@ def test_run_pipelines_the_convergence_tail_and_books_it_like_single_steps(gpu_c
                 assert len(seen[name]) == T and all(ps["ms_gpu"] > 0 for ps in ctx.pass_stats()), name
     assert seen["pipelined"] == seen["stepwise"] == seen["pipelined_staged_every_pass"]
     # ... and the same bookkeeping as stepping through the C ABI one pass at a time
-    with gpu_ctx_factory(tune=(0, 0x200000)) as ctx:
+    with gpu_ctx_factory() as ctx:
         ctx.load_dense(g.ids, g.row_ptr, g.src)
         ctx.begin()
         while ctx.step():
@@ -341,7 +340,9 @@ def test_tail_kernel_runs_whole_passes_from_work_lists(gpu_ctx_factory):
     vals, keep, k = o.finish()
     keys = ("pass", "changed", "active_edges", "touched")
     seen = {}
-    for name, kw in (("on", dict()), ("off", dict(tune=(0, 0x200000))), ("after_any_pass", dict(tune=(0, 0x400000))), ("on_chunk8", dict(chunk=8)),
+    # (the kernel is OFF by default - measured no faster than the launches it replaces; tune[1] bit 21 = on, bit 22 = on,
+    # after any pass)
+    for name, kw in (("on", dict(tune=(0, 0x200000))), ("off", dict()), ("after_any_pass", dict(tune=(0, 0x400000))), ("on_chunk8", dict(chunk=8, tune=(0, 0x200000))),
                      ("after_any_pass_chunk4_staged", dict(chunk=4, tune=(0, 0x408000)))):
         with gpu_ctx_factory(**kw) as ctx:
             ctx.load_dense(g.ids, g.row_ptr, g.src)
@@ -378,8 +379,8 @@ def test_tail_pipeline_when_a_late_change_would_ask_for_a_dense_pass(gpu_ctx_fac
     T = o.run()
     vals, keep, k = o.finish()
     seen = {}
-    for name, kw in (("pipelined", dict(tune=(0, 0x200000))), ("stepwise", dict(tune=(0, 0x300000))), ("pipelined_chunk8", dict(chunk=8, tune=(0, 0x200000))),
-                     ("tail_kernel", dict()), ("tail_kernel_chunk8", dict(chunk=8))):
+    for name, kw in (("pipelined", dict()), ("stepwise", dict(tune=(0, 0x100000))), ("pipelined_chunk8", dict(chunk=8)),
+                     ("tail_kernel", dict(tune=(0, 0x200000))), ("tail_kernel_chunk8", dict(chunk=8, tune=(0, 0x200000)))):
         with gpu_ctx_factory(**kw) as ctx:
             ctx.load_dense(ids, row_ptr, src)
             st = ctx.run()
@@ -659,8 +660,7 @@ def test_sweep_seeds_with_very_long_reader_lists(gpu_ctx_factory):
         tuples += [(leaf0 + k, leaf0 + K + (k % 7), 0) for k in range(0, K, 3)]   # a few leaves are read further on
         e = EdgeListGraph.from_tuples(tuples)
         fids, fvals, fst = hbo.faithful_run(e.host_edges())
-        # (bit 21: without the single-workgroup tail kernel, which would take these passes from the sweep kernels this test is about)
-        for kw in (dict(tune=(0, 0x200000, 101, 0, 0, 0, 1)), dict(tune=(0, 0x200800, 101, 0, 0, 0, 1)), dict()):
+        for kw in (dict(tune=(0, 0, 101, 0, 0, 0, 1)), dict(tune=(0, 0x800, 101, 0, 0, 0, 1)), dict()):
             hc = HarmonicCentrality.calculate(e, **kw)
             ids, vals = hc.arrays()
             assert hc.stats["passes"] == fst["passes"] and hc.stats["n"] == fst["n"], (K, kw)
