@@ -363,6 +363,26 @@ def test_tail_kernel_runs_whole_passes_from_work_lists(gpu_ctx_factory):
     assert strip(seen["on"]) == strip(seen["after_any_pass"]) == strip(seen["on_chunk8"]) == strip(seen["after_any_pass_chunk4_staged"])
 
 
+def test_max_passes_is_reported_by_every_driver_of_the_tail(gpu_ctx_factory):
+    """hb_options.max_passes: a run that needs more passes fails with HB_ERR_LIMIT - one pass at a time, with the tail pipeline (which
+    queues a pass ahead and must not queue one beyond the limit) and with the single-workgroup kernel (whose launch budget is cut to
+    what is left); with exactly enough passes it succeeds."""
+    g = synth.RmatGraph(13, 60_000, tail=(300, 800, 10))
+    o = hbo.Dense(g.id_low64(), g.row_ptr, g.src)
+    T = o.run()
+    vals, keep, k = o.finish()
+    for tune in ((), (0, 0x100000), (0, 0x200000), (0, 0x400000)):
+        for limit in (T - 1, T - 2, T - 7):
+            with gpu_ctx_factory(max_passes=limit, tune=tune) as ctx:
+                ctx.load_dense(g.ids, g.row_ptr, g.src)
+                with pytest.raises(_lib.HyperballError) as e:
+                    ctx.run()
+                assert e.value.code == _lib.HB_ERR_LIMIT, (tune, limit, str(e.value))
+        with gpu_ctx_factory(max_passes=T, tune=tune) as ctx:
+            ctx.load_dense(g.ids, g.row_ptr, g.src)
+            _check_final(ctx, g.ids, T, vals, keep, ctx.run())
+
+
 def test_tail_pipeline_when_a_late_change_would_ask_for_a_dense_pass(gpu_ctx_factory):
     """Found by tools/diff_fuzz.py on the MI355X (round 5): deep in the convergence tail ONE node with a large share of all out-links
     changes (a chain trickling into a hub whose counter is already large, so that it moves only now and then) - A_{t+1} jumps above
