@@ -237,7 +237,7 @@ struct Carve { // consecutive 256-byte aligned pieces of the work buffer
     template <class T>
     T *take(size_t count)
     {
-        T *r = (T *)(p + used);
+        T *r = (T *)((uintptr_t)p + used); // (integer arithmetic: the sizing pass carves from a null base)
         used += (count * sizeof(T) + 255) & ~(size_t)255;
         return r;
     }
