@@ -82,6 +82,9 @@ struct hb_ctx {
     bool sparse_ok = false;
     uint64_t plan_entries = 0; // entries of all work rows' source lists
     unsigned long long *h_counters = nullptr; // pinned, kCounterWords words; [0..3] hold the stripe sums after a pass
+    void *h_block = nullptr;                  // ONE page-locked block, allocated by hb_create, that h_counters / h_slot / h_tl_count / h_rank_cnt are
+                                              // carved from: no hipHostMalloc ever happens inside a run (the first hb_run of a process is the ONLY one
+                                              // a drop-in user makes, entrypoint/centrality.rs:49)
     uint64_t bits_words = 0;
     uint64_t ksum_len = 0; // entries allocated for ksum (world * slice in RCCL mode)
     uint64_t slice_rows = 0;
@@ -101,7 +104,8 @@ struct hb_ctx {
     struct EvSet {
         hipEvent_t e[6];
     };
-    std::vector<EvSet> ev_pool;         // one set per pass of a run (created on demand, kept)
+    std::vector<EvSet> ev_pool;         // deferred timing (destination partition + changed-only on a communicator): one set per pass of a run
+    EvSet ev_ring[4]{};                 // hb_run's tail pipeline (two passes in flight): pass t uses set t & 3; created by hb_create
     std::vector<uint64_t> pending_times; // passes whose ms_* fields still have to be read from their events
     // hb_run's tail pipeline: pass q + 1 is queued (guarded on the device by pass q's changed count) before pass q's counters are
     // read, so the convergence tail runs without a host round trip between passes
@@ -139,6 +143,8 @@ struct hb_ctx {
                                     // false positives are no longer results-inert
 
     // loop state
+    bool lean_init = false; // hb_begin left the initial counters / Kahan words / sizes to pass 0 (PassParams::rd_init); cleared by pass 0, or by
+                            // ensure_initial_state() when something wants to look at the state before pass 0
     uint64_t t = 0;
     int cur = 0; // d_regs[cur] = "old"
     bool has_changes = false;
@@ -532,7 +538,26 @@ int hb_create(const hb_options *opt, hb_ctx **out)
         if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { ctx->err = "hipStreamCreate failed"; return bail(HB_ERR_HIP); }
         for (int i = 0; i < 6; i++)
             if (hipEventCreate(&ctx->ev[i]) != hipSuccess) { ctx->err = "hipEventCreate failed"; return bail(HB_ERR_HIP); }
-        if (hipHostMalloc((void **)&ctx->h_counters, hbk::kCounterWords * sizeof(unsigned long long)) != hipSuccess) { ctx->err = "hipHostMalloc failed"; return bail(HB_ERR_NOMEM); }
+        {   // every small page-locked word the pass driver will ever read back, in one block, NOW: a hipHostMalloc inside the first run
+            // cost that run 13 ms at C3 and ~200 ms at C4 under a loaded page cache (profiles/r05j_e2e_C4_first_run_and_store_phases.txt)
+            const size_t world = (size_t)std::max(o.world_size, 1);
+            const size_t words = (size_t)hbk::kCounterWords * 3 + 32 + world + 1; // h_counters | h_slot (2 sets) | h_tl_count (kTcWords x u32) | h_rank_cnt
+            if (hipHostMalloc(&ctx->h_block, words * sizeof(unsigned long long)) != hipSuccess) { ctx->h_block = nullptr; ctx->err = "hipHostMalloc failed"; return bail(HB_ERR_NOMEM); }
+            std::memset(ctx->h_block, 0, words * sizeof(unsigned long long));
+            unsigned long long *w = (unsigned long long *)ctx->h_block;
+            ctx->h_counters = w;
+            ctx->h_slot = w + hbk::kCounterWords;
+            ctx->h_tl_count = (uint32_t *)(w + 3 * (size_t)hbk::kCounterWords);
+            ctx->h_rank_cnt = w + 3 * (size_t)hbk::kCounterWords + 32;
+            static_assert(hbk::kTcWords * sizeof(uint32_t) <= 32 * sizeof(unsigned long long), "h_tl_count slot too small");
+        }
+        for (auto &e : ctx->slot_done)
+            if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { ctx->err = "hipEventCreate failed"; return bail(HB_ERR_HIP); }
+        for (auto &e : ctx->tl_ev)
+            if (hipEventCreate(&e) != hipSuccess) { ctx->err = "hipEventCreate failed"; return bail(HB_ERR_HIP); }
+        for (auto &es : ctx->ev_ring)
+            for (auto &e : es.e)
+                if (hipEventCreate(&e) != hipSuccess) { ctx->err = "hipEventCreate failed"; return bail(HB_ERR_HIP); }
         if (hipStreamCreateWithFlags(&ctx->rs.stream, hipStreamNonBlocking) != hipSuccess ||
             hipEventCreateWithFlags(&ctx->rs.ready, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&ctx->rs.copied, hipEventDisableTiming) != hipSuccess) { ctx->err = "hipStreamCreate / hipEventCreate failed"; return bail(HB_ERR_HIP); }
@@ -569,10 +594,10 @@ void hb_destroy(hb_ctx *ctx)
     if (ctx->comm) (void)ncclCommDestroy(ctx->comm);
     ctx->app.free_all();
     free_graph_buffers(ctx);
-    if (ctx->h_counters) (void)hipHostFree(ctx->h_counters);
-    if (ctx->h_rank_cnt) (void)hipHostFree(ctx->h_rank_cnt);
-    if (ctx->h_slot) (void)hipHostFree(ctx->h_slot);
-    if (ctx->h_tl_count) (void)hipHostFree(ctx->h_tl_count);
+    if (ctx->h_block) (void)hipHostFree(ctx->h_block); // h_counters, h_slot, h_tl_count, h_rank_cnt
+    for (auto &es : ctx->ev_ring)
+        for (hipEvent_t e : es.e)
+            if (e) (void)hipEventDestroy(e);
     for (hipEvent_t e : ctx->tl_ev)
         if (e) (void)hipEventDestroy(e);
     for (hipEvent_t e : ctx->slot_done)
@@ -973,12 +998,20 @@ int hb_begin(hb_ctx *c)
         if (c->d_sparse_counts) HB_HIP(hipMemsetAsync(c->d_sparse_counts, 0, 64 * sizeof(unsigned int), c->stream));
         if (c->ksum_len > p.n_pad) // slice padding beyond the rows init_kernel writes (all-reduce mode)
             HB_HIP(hipMemsetAsync(c->d_ksum + p.n_pad, 0, (c->ksum_len - p.n_pad) * sizeof(double), c->stream));
+        c->cur = 0;
+        c->t = 0;
+        c->lean_init = false;
         if (p.n_pad) {
-            unsigned blocks = (unsigned)((p.n_pad * 4 + 255) / 256);
-            hipLaunchKernelGGL(hbk::init_kernel, dim3(blocks), dim3(256), 0, c->stream, c->d_idlow, (const uint32_t *)c->d_sid_of, p.n_pad,
-                               c->d_regs[0], c->d_regs[1], c->d_ksum, c->d_kerr, c->d_size, c->d_bits[0], c->d_kdirty,
-                               c->d_raw, c->d_bias, c->d_lc);
-            HB_HIP(hipGetLastError());
+            if (lean_pass0(c)) {
+                // [r6] pass 0 produces the initial state itself (hb_kernels.hip.h PassParams::rd_init): hb_begin writes two bitmaps instead of
+                // 88 bytes per node (C4: 8.7 GB, 3.3 ms of every run)
+                hipLaunchKernelGGL(hbk::init_lean_kernel, dim3((unsigned)((p.n_pad + 255) / 256)), dim3(256), 0, c->stream, (const uint32_t *)c->d_sid_of, p.n_pad,
+                                   c->d_bits[0], c->d_kdirty);
+                HB_HIP(hipGetLastError());
+                c->lean_init = true;
+            } else if ((rc = launch_full_init(c))) {
+                return rc;
+            }
         }
         if (ref_tail(c)) {
             // harmonic.rs:221,228: U64BloomFilter::new(num_nodes, 0.05); threshold = sqrt(num_nodes).max(0).round()
@@ -1066,6 +1099,7 @@ int hb_finish(hb_ctx *c)
         if (rc) return rc;
         const Plan &p = c->plan;
         double t0 = now_ms();
+        if ((rc = ensure_initial_state(c))) return rc; // (hb_finish right behind hb_begin)
         if (linked(c) && p.n_pad) {
             // every rank ends with all Kahan sums: in-place all-gather of the owned slices
             HB_COLL(coll_all_gather(c, c->d_ksum + (uint64_t)c->opt.rank * c->slice_rows, c->d_ksum, c->slice_rows, ncclDouble, c->stream));

@@ -65,21 +65,15 @@ __device__ __forceinline__ double pow2_neg(uint32_t r) // ONE_OVER_POWER_OF_TWO[
 // 64 registers (the left fold of hyperloglog.rs:4488-4492 is exact and order-independent in f64 when every register
 // is <= 47: all partial sums are multiples of 2^-47 below 2^7), zeros = number of zero registers, big = some register
 // is > 47 (then the fold must be replayed in register order: hll_fold_quad).
-__device__ __forceinline__ void hll_sum_quad(const uint4 &v, double &sum_out, uint32_t &zeros_out, uint32_t &big_out)
+// lc != NULL [r6]: the f64 sum is only built when some lane of the WAVE holds a counter whose size() is not decided by its zero count
+// (hll_size_from tests the linear-counting exit first and never looks at the sum then): after pass 0, and for the cold majority of the
+// rows in every pass, whole waves skip the 16 v_add_f64 per lane.  sum_out is 0.0 then.
+__device__ __forceinline__ void hll_sum_quad(const uint4 &v, double &sum_out, uint32_t &zeros_out, uint32_t &big_out, const uint8_t *lc = nullptr)
 {
     const uint32_t w[4] = {v.x, v.y, v.z, v.w};
-    // The 16 terms 2^-r of this lane are added as doubles built from their exponent field (hi word = (1023 - r) << 20):
-    // with every register <= 47 all partial sums are multiples of 2^-47 below 2^7, so these additions are exact in any
-    // order - the same value as the reference's left fold; four v_add_f64 per word instead of 64-bit integer shifts / adds.
-    double acc = 0.0;
     uint32_t zeros = 0, mx = 0;
 #pragma unroll
     for (int k = 0; k < 4; k++) {
-#pragma unroll
-        for (int b = 0; b < 4; b++) {
-            const uint32_t r = (w[k] >> (8 * b)) & 0xFFu;
-            acc += __hiloint2double((int)((1023u << 20) - (r << 20)), 0); // r <= 255: the exponent field stays positive
-        }
         // zero bytes of the word: bit 7 of every byte of z marks a zero byte
         const uint32_t z = ~(((w[k] & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | w[k] | 0x7F7F7F7Fu);
         zeros += __popc(z);
@@ -87,20 +81,38 @@ __device__ __forceinline__ void hll_sum_quad(const uint4 &v, double &sum_out, ui
         mx = pkmax(mx, pkmax(w[k] & 0x00FF00FFu, (w[k] >> 8) & 0x00FF00FFu));
     }
     uint32_t big = ((mx & 0xFFFFu) > 47u || (mx >> 16) > 47u) ? 1u : 0u;
-    // quad reduction (xor 1, xor 2); the f64 sums stay exact for the same reason
+    // quad reduction (xor 1, xor 2)
+    zeros += quad_perm<0xB1>(zeros);
+    big |= quad_perm<0xB1>(big);
+    zeros += quad_perm<0x4E>(zeros);
+    big |= quad_perm<0x4E>(big);
+    zeros_out = zeros;
+    big_out = big;
+    sum_out = 0.0;
+    if (lc) {
+        const bool by_zero_count = zeros != 0 && lc[zeros] != 0xFFu; // hll_size_from's first test
+        if (!__ballot(!by_zero_count)) return;                        // wave-uniform
+    }
+    // The 16 terms 2^-r of this lane are added as doubles built from their exponent field (hi word = (1023 - r) << 20):
+    // with every register <= 47 all partial sums are multiples of 2^-47 below 2^7, so these additions are exact in any
+    // order - the same value as the reference's left fold; four v_add_f64 per word instead of 64-bit integer shifts / adds.
+    double acc = 0.0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+            const uint32_t r = (w[k] >> (8 * b)) & 0xFFu;
+            acc += __hiloint2double((int)((1023u << 20) - (r << 20)), 0); // r <= 255: the exponent field stays positive
+        }
+    }
+    // quad reduction; the f64 sums stay exact for the same reason
     {
         uint32_t lo = (uint32_t)__double2loint(acc), hi = (uint32_t)__double2hiint(acc);
         acc += __hiloint2double((int)quad_perm<0xB1>(hi), (int)quad_perm<0xB1>(lo));
-        zeros += quad_perm<0xB1>(zeros);
-        big |= quad_perm<0xB1>(big);
         lo = (uint32_t)__double2loint(acc); hi = (uint32_t)__double2hiint(acc);
         acc += __hiloint2double((int)quad_perm<0x4E>(hi), (int)quad_perm<0x4E>(lo));
-        zeros += quad_perm<0x4E>(zeros);
-        big |= quad_perm<0x4E>(big);
     }
     sum_out = acc; // when big != 0 the value is unused - the fold is replayed in register order
-    zeros_out = zeros;
-    big_out = big;
 }
 
 // The rare case (a register > 47 needs a hash with > 46 leading zeros): the reference's sequential f64 fold over all
@@ -129,13 +141,16 @@ __device__ __forceinline__ double hll_fold_quad(const uint4 &v)
 // raw/bias/lc: tables (LDS or global).
 __device__ __forceinline__ uint64_t hll_size_from(double sum, uint32_t zeros, const double *raw, const double *bias, const uint8_t *lc)
 {
+    // :4504-4515 : linear counting wins iff v != 0 and 64 ln(64/v) <= 40 - a function of the zero count ALONE (v >= 35), so it is
+    // tested FIRST: the division, the 159-entry search and the 6-NN walk below are dead work for such a counter, and after pass 0
+    // (a node's counter = one register per in-neighbour + its own) that is most rows.  Same value either way: the reference
+    // computes e_star and then discards it (hyperloglog.rs:4511-4515).  [r6, VERDICT r5 #2b]
+    const uint32_t l = lc[zeros]; // zeros in 0..64
+    if (zeros != 0 && l != 0xFFu) return (uint64_t)l;
     const double z = 1.0 / sum;                 // :4494
     const double e = (0.709 * 4096.0) * z;      // :4496  am() * m.powi(2) * z
     double e_star = e;
     if (e <= 320.0) e_star = e - estimate_bias(raw, bias, e); // :4498-4502
-    // :4504-4515 : linear counting wins iff v != 0 and 64 ln(64/v) <= 40
-    uint32_t l = lc[zeros]; // zeros in 0..64
-    if (zeros != 0 && l != 0xFFu) return (uint64_t)l;
     return f64_as_usize(e_star);
 }
 
@@ -145,7 +160,7 @@ __device__ __forceinline__ uint64_t hll_size_quad(const uint4 &v, const double *
 {
     double sum;
     uint32_t zeros, big;
-    hll_sum_quad(v, sum, zeros, big);
+    hll_sum_quad(v, sum, zeros, big, lc);
     if (big) sum = hll_fold_quad(v); // quad-uniform branch
     return hll_size_from(sum, zeros, raw, bias, lc);
 }

@@ -114,7 +114,29 @@ struct PassParams {
     // (lbits); after the union over the ranks only those rows are exchanged, and the epilogue visits only them (ubits)
     uint32_t *lbits;
     const uint32_t *ubits;
+    // [r6] lean pass 0 (single rank, fused, INIT): hb_begin has NOT materialised the initial state - every node's counter is
+    // HyperLogLog::default() + add(id) (harmonic.rs:60-62: one register, a function of id_low), its KahanSum is (0, 0) and its cached
+    // size() is lc[63] - so pass 0 derives the own counters from id_low instead of reading 64 B per row that an init kernel would
+    // first have had to write, takes the Kahan / size words as constants and stores them for EVERY row.  rd_init = the "old" buffer
+    // itself: a row pass 0 leaves unchanged is stored there too, so that the lazy double buffer's invariant (the other buffer holds the
+    // row's value unless it changed in this or the previous pass) holds for pass 1 in every pass mode.  NULL = the state is in memory.
+    uint4 *rd_init;
+    const uint64_t *id_low;   // low 64 bits of the NodeID per device row (lean pass 0)
+    const uint32_t *sid_of;   // device row -> sid, kNone = padding row (lean pass 0)
 };
+
+// lane q's quarter of the initial counter of a node: HyperLogLog::default(); add_u128(id) - hyperloglog.rs:4385-4400 with
+// FastHasher (:4311-4313), only the low 64 bits of the id are hashed
+__device__ __forceinline__ uint4 initial_counter_quarter(uint64_t id_low, int q)
+{
+    const uint64_t hash = id_low * 11400714819323198549ull;
+    const uint32_t j = (uint32_t)(hash >> 58);
+    const uint64_t w = hash << 6;
+    const uint32_t pval = (w == 0 ? 64u : (uint32_t)__clzll((long long)w)) + 1u;
+    uint32_t ww[4] = {0, 0, 0, 0};
+    if ((int)(j >> 4) == q) ww[(j & 15u) >> 2] = pval << (8 * (j & 3u));
+    return make_uint4(ww[0], ww[1], ww[2], ww[3]);
+}
 
 } // namespace hbk
 #include "hb_estimator.hip.h"
@@ -188,19 +210,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((REAL && UN
     double p_sum = 0.0, p_ks = 0.0, p_ke = 0.0;
     uint32_t p_zeros = 0, p_flags = 0; // 1 = row exists, 2 = changed, 4 = Kahan-dirty, 8 = a register > 47 (p_szfull holds size())
     int npend = 0;                     // pending tiles of this wave, 0..3
+    const bool p_lean = INIT && REAL && FUSED && p.rd_init != nullptr;
     auto flush_pending = [&]() {
         bool err_nz = false;
-        if (q < npend && (p_flags & 1u) && (p_flags & 6u)) {
+        if (q < npend && (p_flags & 1u) && ((p_flags & 6u) || p_lean)) { // (lean pass 0: every row's words are written for the first time)
             const uint64_t sz_old = p_sz;
             uint64_t sz_new = sz_old;
             if (p_flags & 2u) sz_new = (p_flags & 8u) ? p_szfull : hll_size_from(p_sum, p_zeros, s_raw, s_bias, s_lc);
             double ks = p_ks, ke = p_ke;
             err_nz = kahan_update(ks, ke, sz_new, sz_old, p.t_plus_1); // still moving -> visit again
-            if (err_nz) {
+            if (err_nz || p_lean) {
                 p.ksum[p_row] = ks;
                 p.kerr[p_row] = ke;
             }
-            if (p_flags & 2u) p.size[p_row] = sz_new;
+            if ((p_flags & 2u) || p_lean) p.size[p_row] = sz_new;
         }
         const uint64_t bal = __ballot(err_nz); // bit 4g + k = row g of pending tile k
         if (lane == 0) {
@@ -216,13 +239,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((REAL && UN
     uint64_t nbeg = 0, nend = 0;
     uint32_t nod = 0;
     uint4 nself = make_uint4(0, 0, 0, 0);
+    const bool lean = INIT && REAL && FUSED && p.rd_init != nullptr; // kernel-uniform (PassParams::rd_init)
+    auto own_counter = [&](uint64_t r) -> uint4 { // the row's counter before this pass
+        if (INIT && REAL && FUSED && lean) return p.sid_of[r] != kNone ? initial_counter_quarter(ld_stream(&p.id_low[r]), q) : make_uint4(0, 0, 0, 0);
+        return p.rd[r * 4 + q];
+    };
     {
         const uint64_t r0 = row_lo + (tile0 << 6) + ((uint64_t)wave << 4) + (uint64_t)g;
         if (tile0 < ntiles && r0 < row_hi) {
             nbeg = ld_stream(&p.row_ptr[r0]);
             nend = ld_stream(&p.row_ptr[r0 + 1]);
             if (REAL && FUSED) nod = ld_stream(&p.outdeg[r0]);
-            if (kDenseReal) nself = p.rd[r0 * 4 + q];
+            if (kDenseReal) nself = own_counter(r0);
         }
     }
     for (uint64_t tile = tile0; tile < ntiles; tile += tstride) {
@@ -241,14 +269,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((REAL && UN
                 nbeg = ld_stream(&p.row_ptr[nrow]);
                 nend = ld_stream(&p.row_ptr[nrow + 1]);
                 if (REAL && FUSED) nod = ld_stream(&p.outdeg[nrow]);
-                if (kDenseReal) nself = p.rd[nrow * 4 + q];
+                if (kDenseReal) nself = own_counter(nrow);
             }
         }
         // dense fused node rows: 4 of 5 rows change, so the estimator/Kahan words are requested now, unconditionally
         uint64_t pre_sz = 0;
         double pre_ks = 0.0, pre_ke = 0.0;
         if (kDenseReal && FUSED && valid) {
-            if (kEpi4) {
+            if (lean) {
+                // (0, 0) and size() of a counter with one register set = the linear-counting value for 63 zero registers
+                // (hyperloglog.rs:4504-4515; init_kernel writes the same); a padding row's counter is empty and stays so: 0
+                const bool real_row = ((__ballot(u4_ne(selfv, make_uint4(0, 0, 0, 0))) >> qshift) & 0xFull) != 0;
+                pre_sz = real_row ? (uint64_t)s_lc[63] : 0ull;
+            } else if (kEpi4) {
                 if (q == npend) { // this lane owns the row's deferred epilogue
                     pre_sz = ld_stream(&p.size[row]);
                     pre_ks = ld_stream(&p.ksum[row]);
@@ -362,6 +395,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((REAL && UN
             // [r5: used by the fused dense pass too - a fifth of the hosts of an R-MAT graph have no in-link at all and never
             // change: 64 B per such row and pass that nobody needs; the unfused forms store every row: the exchanges read them]
             if (need && (!FUSED || INIT || changed || self_prev || p.t_plus_1 == 1.0)) st_stream(&p.wr[row * 4 + q], accv); // (pass 0 fills the other buffer)
+            if (lean && need && !changed) st_stream(&p.rd_init[row * 4 + q], accv); // (see PassParams::rd_init; a changed row is rewritten by pass 1 anyway)
         } else {
             if (changed) st_stream(&p.part[(row - p.n_pad) * 4 + q], accv);
         }
@@ -377,7 +411,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((REAL && UN
         if (kEpi4) {
             double rsum;
             uint32_t zeros, big;
-            hll_sum_quad(accv, rsum, zeros, big);
+            hll_sum_quad(accv, rsum, zeros, big, s_lc);
             uint64_t szfull = 0;
             if (big) szfull = hll_size_from(hll_fold_quad(accv), zeros, s_raw, s_bias, s_lc); // quad-uniform branch (rare)
             if (q == npend) {
@@ -398,17 +432,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((REAL && UN
         }
         if (REAL && FUSED && !kEpi4) {
             bool err_nz = false;
-            if (need && (changed || kd)) {
+            if (need && (changed || kd || lean)) {
                 const uint64_t sz_old = kDenseReal ? pre_sz : p.size[row];
                 const uint64_t sz_new = changed ? hll_size_quad(accv, s_raw, s_bias, s_lc) : sz_old;
                 if (q == 0) {
                     double ks = kDenseReal ? pre_ks : p.ksum[row], ke = kDenseReal ? pre_ke : p.kerr[row];
                     err_nz = kahan_update(ks, ke, sz_new, sz_old, p.t_plus_1); // still moving -> visit again
-                    if (err_nz) {
+                    if (err_nz || lean) {
                         p.ksum[row] = ks;
                         p.kerr[row] = ke;
                     }
-                    if (changed) p.size[row] = sz_new;
+                    if (changed || lean) p.size[row] = sz_new;
                 }
             }
             const uint32_t nk16 = pack16(__ballot(err_nz));
@@ -830,6 +864,21 @@ __global__ __launch_bounds__(256) void init_kernel(const uint64_t *id_low, const
     if ((threadIdx.x & 63) == 0) {
         ((uint16_t *)bits)[row >> 4] = (uint16_t)m16;
         ((uint16_t *)kdirty)[row >> 4] = 0;
+    }
+}
+
+// [r6] hb_begin when pass 0 runs lean (PassParams::rd_init): only the two bitmaps - every real node starts in the changed set
+// (harmonic.rs:221-225), no Kahan state is dirty; counters, Kahan words and cached sizes are produced by pass 0 itself.
+__global__ __launch_bounds__(256) void init_lean_kernel(const uint32_t *sid_of, uint64_t n_pad, uint32_t *bits, uint32_t *kdirty)
+{
+    const uint64_t row = (uint64_t)blockIdx.x * 256 + threadIdx.x; // n_pad is a multiple of 64: whole waves
+    if (row >= n_pad) return;
+    const uint64_t bal = __ballot(sid_of[row] != kNone);
+    if ((threadIdx.x & 63) == 0) {
+        bits[row >> 5] = (uint32_t)bal;
+        bits[(row >> 5) + 1] = (uint32_t)(bal >> 32);
+        kdirty[row >> 5] = 0;
+        kdirty[(row >> 5) + 1] = 0;
     }
 }
 

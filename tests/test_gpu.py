@@ -236,6 +236,16 @@ VARIANTS["long_tail_tail_kernel_on"] = dict(tune=(0, 0x200000))
 VARIANTS["tail_kernel_after_any_pass_sparse_always"] = dict(chunk=8, tune=(0, 0x400000, 101, 0, 0, 0, 1))
 
 
+# round 6: hb_begin leaves the initial state (counters, Kahan words, sizes) to a LEAN pass 0 (hb_kernels.hip.h PassParams::rd_init) when
+# that pass is the fused INIT launch of one rank; looking at the state right after hb_begin materialises it and pass 0 runs as before.
+# "<variant>_lean": the same knobs WITHOUT that look, so the lean pass 0 itself runs and everything is compared after it (registers of
+# all rows incl. the ones pass 0 left unchanged, every Kahan word and size, and - through pass 1 in its mode - the other buffer).
+for _base in ("default", "chunk4_multilevel", "sparse_always_multilevel", "frontier_always", "old_per_tile_epilogue", "no_reorder_unroll4",
+              "long_tail_default", "staged_results_every_pass", "no_xcd_map"):
+    VARIANTS[_base + "_lean"] = VARIANTS[_base]
+VARIANTS["full_init_switch"] = dict(tune=(0, 0x800000))  # hb_begin always writes the whole initial state (the pre-round-6 form)
+
+
 @pytest.mark.parametrize("variant", sorted(VARIANTS))
 def test_per_pass_state_matches_oracle(gpu_ctx_factory, variant):
     # long_tail_*: R-MAT core + levelled-DAG tail (tens of passes: dense -> push masks -> worklists)
@@ -245,8 +255,9 @@ def test_per_pass_state_matches_oracle(gpu_ctx_factory, variant):
     with gpu_ctx_factory(**kw) as ctx:
         ctx.load_dense(g.ids, g.row_ptr, g.src)
         ctx.begin()
-        assert np.array_equal(ctx.registers(), o.registers())
-        assert np.array_equal(ctx.sizes(), o.sizes())
+        if not variant.endswith("_lean"):
+            assert np.array_equal(ctx.registers(), o.registers())
+            assert np.array_equal(ctx.sizes(), o.sizes())
         has = True
         t = 0
         modes = set()
