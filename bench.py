@@ -616,6 +616,7 @@ def main():
                        "gathered_edges_per_run": gathered,
                        "gathered_gteps": round(gathered / (loop_ms / steps * 1e-3) / 1e9, 4) if loop_ms else None,
                        "collective": wire_info(world, main_part, a.changed_only, stats, n, ms, steps) if world > 1 else None,
+                       "scaling_model": scaling_model(avg, n, m_eff, passes, ms["dt"] * 1e3 / steps) if world == 1 and avg else None,
                        "results": int(len(vals)), "s_generate": round(t_gen, 2), "s_load": load["s_load"],
                        "ms_plan": round(stats["ms_plan"], 1), "ms_h2d": round(stats["ms_h2d"], 1),
                        "device_bytes": int(stats["device_bytes"]), "virtual_rows": int(stats["virtual_rows"]),
@@ -713,6 +714,47 @@ def main():
 
 
 XGMI_LINK_GBS_PER_DIR = 76.8  # MI355X: 7 xGMI links per GPU, ~153.6 GB/s each counting both directions (one direct link per peer)
+
+
+def scaling_model(avg, n, m_eff, passes, ms_per_step):
+    """What DESIGN.md §6's cost model predicts for N = 2, 4, 8 from THIS run's per-pass numbers, per decomposition - written into the
+    N = 1 line so that BENCH and SCALE records can be read side by side (VERDICT r5 #3c).  A model, not a measurement: local compute of a
+    pass = its 1-GPU time / N (optimistic: the node rows of the edge partition do not shrink with N), every GPU sends on its N - 1
+    direct xGMI links at once at 76.8 GB/s per link and direction, no protocol overhead, no launch latency.  Bytes received per GPU and
+    pass: edge partition 2 (N-1)/N n 64 (all-reduce = reduce-scatter + all-gather); its changed-only form the same over the rows that
+    changed + the ranks' n/8-byte bitmaps; destination partition (N-1)/N (n 64 + n/8); its changed-only form (N-1)/N (changed 64 + n/8),
+    and with the 6-bit register packing of the packed exchange 48 instead of 64 bytes per changed row."""
+    n_pad = (n + 63) // 64 * 64
+    fixed_ms = max(ms_per_step - sum(d["ms_gpu"] for d in avg), 0.0)  # hb_begin, hb_finish, host gaps: not divided
+    out = {"assumptions": "local compute per pass = 1-GPU pass time / N; N-1 links x %.1f GB/s per direction; bytes at link rate, no overlap / full overlap of "
+                          "collective and compute; fixed %.2f ms per run outside the passes" % (XGMI_LINK_GBS_PER_DIR, fixed_ms), "per_n": {}}
+    for N in (2, 4, 8):
+        egress = (N - 1) * XGMI_LINK_GBS_PER_DIR  # GB/s
+        f = (N - 1) / N
+        legs = {}
+        for name in ("edge_allreduce", "edge_changed_only", "dest_allgather", "dest_changed_only", "dest_changed_only_6bit"):
+            t_sum = t_max = 0.0
+            for d in avg:
+                ch = min(int(d["changed"]), n)
+                if name == "edge_allreduce":
+                    b = 2 * f * n_pad * 64
+                elif name == "edge_changed_only":
+                    b = 2 * f * ch * 64 + (N - 1) * n_pad / 8
+                elif name == "dest_allgather":
+                    b = f * (n_pad * 64 + n_pad / 8)
+                elif name == "dest_changed_only":
+                    b = f * (ch * 64 + n_pad / 8)
+                else:
+                    b = f * (ch * 48 + n_pad / 8)
+                coll = b / egress / 1e6
+                local = d["ms_gpu"] / N
+                t_sum += local + coll
+                t_max += max(local, coll)
+            legs[name] = {"ms_per_run_no_overlap": round(t_sum + fixed_ms, 2), "ms_per_run_full_overlap": round(t_max + fixed_ms, 2),
+                          "gteps_no_overlap": round(m_eff * passes / ((t_sum + fixed_ms) * 1e-3) / 1e9, 1),
+                          "gteps_full_overlap": round(m_eff * passes / ((t_max + fixed_ms) * 1e-3) / 1e9, 1)}
+        out["per_n"][str(N)] = legs
+    return out
 
 
 def wire_info(world, part, changed_only, stats, n, ms, steps):

@@ -58,6 +58,7 @@ struct hb_ctx {
     uint64_t *d_row_ptr = nullptr;
     uint32_t *d_src = nullptr;
     uint16_t *d_src_jp = nullptr; // parallel to d_src: the sources' initial register (pass 0 streams it, hb_kernels.hip.h)
+    uint16_t *d_self_jp = nullptr; // per node row: its OWN initial register in the same format (the lean pass 0 reads it instead of the counters)
     uint4 *d_regs[2] = {nullptr, nullptr};
     uint4 *d_part = nullptr;
     uint32_t *d_bits[2] = {nullptr, nullptr};
@@ -233,6 +234,7 @@ void free_graph_buffers(hb_ctx *c)
     c->d_row_ptr = nullptr;
     c->d_src = nullptr;
     c->d_src_jp = nullptr;
+    c->d_self_jp = nullptr;
     c->d_regs[0] = c->d_regs[1] = nullptr;
     c->d_part = nullptr;
     c->d_bits[0] = c->d_bits[1] = nullptr;
@@ -420,6 +422,21 @@ int build_sparse_support(hb_ctx *c)
 #include "hb_api_load.inc"
 
 #include "hb_api_pass.inc"
+
+// host worker threads of one call: joined on every way out of the scope (a std::thread that is still joinable when it is
+// destroyed - an exception while the pool is being filled - calls std::terminate, past every catch handler of guarded())
+struct ThreadPool {
+    std::vector<std::thread> th;
+    template <class F, class... A>
+    void spawn(F &&f, A &&...a) { th.emplace_back(std::forward<F>(f), std::forward<A>(a)...); }
+    void join()
+    {
+        for (auto &t : th)
+            if (t.joinable()) t.join();
+        th.clear();
+    }
+    ~ThreadPool() { join(); }
+};
 
 // The C ABI never unwinds (include/hyperball.h): every entry point that can allocate runs under this guard.
 template <class F>
@@ -1138,10 +1155,10 @@ int hb_finish(hb_ctx *c)
                 };
                 const uint64_t nthr = moved >= (1u << 16) ? std::min<uint64_t>(8, std::max(1u, std::thread::hardware_concurrency())) : 1;
                 if (nthr > 1) { // every sid occurs once: the shares are independent
-                    std::vector<std::thread> pool;
-                    for (uint64_t k = 1; k < nthr; k++) pool.emplace_back(apply, moved * k / nthr, moved * (k + 1) / nthr);
+                    ThreadPool pool;
+                    for (uint64_t k = 1; k < nthr; k++) pool.spawn(apply, moved * k / nthr, moved * (k + 1) / nthr);
                     apply(0, moved / nthr);
-                    for (auto &th : pool) th.join();
+                    pool.join();
                 } else {
                     apply(0, moved);
                 }
@@ -1225,11 +1242,21 @@ int hb_get_stats(const hb_ctx *c, hb_stats *out)
     return HB_OK;
 }
 
-int hb_get_pass_stats(const hb_ctx *c, uint64_t t, hb_pass_stats *out)
+int hb_get_pass_stats(const hb_ctx *cc, uint64_t t, hb_pass_stats *out)
 {
-    if (!c || !out || t >= c->pstats.size()) return HB_ERR_INVALID;
-    if (!c->pending_times.empty() && resolve_pass_times(const_cast<hb_ctx *>(c))) return HB_ERR_HIP; // (timing left in flight: read it now)
-    *out = c->pstats[t];
+    if (!cc || !out || t >= cc->pstats.size()) return HB_ERR_INVALID;
+    if (!cc->pending_times.empty()) {
+        // timing events left in flight by a pass whose host round trip sits in its middle (destination partition + changed-only on a
+        // communicator): read now, on the context's device and under the guard like every other call that talks to the runtime
+        // (hb_finish resolves them too, so this only happens between hb_step calls)
+        hb_ctx *c = const_cast<hb_ctx *>(cc);
+        const int rc = guarded(c, [&]() -> int {
+            const int rc_dev = set_device(c);
+            return rc_dev ? rc_dev : resolve_pass_times(c);
+        });
+        if (rc) return rc;
+    }
+    *out = cc->pstats[t];
     return HB_OK;
 }
 
@@ -1273,10 +1300,10 @@ int hb_result_copy(hb_ctx *c, hb_u128 *ids, double *vals, uint64_t cap)
             }
         };
         auto on_all = [&](auto &&f) {
-            std::vector<std::thread> pool;
-            for (uint64_t k = 1; k < nthr; k++) pool.emplace_back(f, k);
+            ThreadPool pool;
+            for (uint64_t k = 1; k < nthr; k++) pool.spawn(f, k);
             f(0);
-            for (auto &th : pool) th.join();
+            pool.join();
         };
         on_all(count_share);
         for (uint64_t k = 0; k < nthr; k++) first[k + 1] += first[k];

@@ -121,20 +121,26 @@ struct PassParams {
     // itself: a row pass 0 leaves unchanged is stored there too, so that the lazy double buffer's invariant (the other buffer holds the
     // row's value unless it changed in this or the previous pass) holds for pass 1 in every pass mode.  NULL = the state is in memory.
     uint4 *rd_init;
-    const uint64_t *id_low;   // low 64 bits of the NodeID per device row (lean pass 0)
-    const uint32_t *sid_of;   // device row -> sid, kNone = padding row (lean pass 0)
+    const uint16_t *self_jp;  // per device row: register index | value << 8 of the node's OWN initial counter (0 = padding row), written at
+                              // load time with the same arithmetic as src_jp (lean pass 0)
 };
 
-// lane q's quarter of the initial counter of a node: HyperLogLog::default(); add_u128(id) - hyperloglog.rs:4385-4400 with
-// FastHasher (:4311-4313), only the low 64 bits of the id are hashed
-__device__ __forceinline__ uint4 initial_counter_quarter(uint64_t id_low, int q)
+// the one register HyperLogLog::default(); add_u128(id) sets (hyperloglog.rs:4385-4400 with FastHasher :4311-4313; only the low 64 bits of
+// the id are hashed), as index | value << 8 - the entry format of src_jp / self_jp
+__device__ __forceinline__ uint16_t initial_register_jp(uint64_t id_low)
 {
     const uint64_t hash = id_low * 11400714819323198549ull;
     const uint32_t j = (uint32_t)(hash >> 58);
     const uint64_t w = hash << 6;
     const uint32_t pval = (w == 0 ? 64u : (uint32_t)__clzll((long long)w)) + 1u;
+    return (uint16_t)(j | (pval << 8));
+}
+// lane q's quarter (registers 16 q .. 16 q + 15) of the counter that entry describes
+__device__ __forceinline__ uint4 counter_quarter_of_jp(uint32_t jp, int q)
+{
+    const uint32_t j = jp & 63u, pval = jp >> 8;
     uint32_t ww[4] = {0, 0, 0, 0};
-    if ((int)(j >> 4) == q) ww[(j & 15u) >> 2] = pval << (8 * (j & 3u));
+    if (pval && (int)(j >> 4) == q) ww[(j & 15u) >> 2] = pval << (8 * (j & 3u));
     return make_uint4(ww[0], ww[1], ww[2], ww[3]);
 }
 
@@ -241,7 +247,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((REAL && UN
     uint4 nself = make_uint4(0, 0, 0, 0);
     const bool lean = INIT && REAL && FUSED && p.rd_init != nullptr; // kernel-uniform (PassParams::rd_init)
     auto own_counter = [&](uint64_t r) -> uint4 { // the row's counter before this pass
-        if (INIT && REAL && FUSED && lean) return p.sid_of[r] != kNone ? initial_counter_quarter(ld_stream(&p.id_low[r]), q) : make_uint4(0, 0, 0, 0);
+        if (INIT && REAL && FUSED && lean) return counter_quarter_of_jp((uint32_t)ld_stream(&p.self_jp[r]), q);
         return p.rd[r * 4 + q];
     };
     {
@@ -809,15 +815,15 @@ __global__ __launch_bounds__(256) void src_jp_kernel(const uint32_t *src, uint64
     for (uint64_t e = (uint64_t)blockIdx.x * 256 + threadIdx.x; e < len; e += (uint64_t)gridDim.x * 256) {
         const uint32_t s = src[e];
         uint16_t v = 0;
-        if (s < n_pad && sid_of[s] != kNone) {
-            const uint64_t hash = id_low[s] * 11400714819323198549ull;
-            const uint32_t j = (uint32_t)(hash >> 58);
-            const uint64_t w = hash << 6;
-            const uint32_t pval = (w == 0 ? 64u : (uint32_t)__clzll((long long)w)) + 1u;
-            v = (uint16_t)(j | (pval << 8));
-        }
+        if (s < n_pad && sid_of[s] != kNone) v = initial_register_jp(id_low[s]);
         jp[e] = v;
     }
+}
+// self_jp[row]: the same entry for every node row's OWN initial counter (padding rows: 0); read by the lean pass 0 (PassParams::rd_init)
+__global__ __launch_bounds__(256) void self_jp_kernel(const uint64_t *id_low, const uint32_t *sid_of, uint64_t n_pad, uint16_t *jp)
+{
+    for (uint64_t r = (uint64_t)blockIdx.x * 256 + threadIdx.x; r < n_pad; r += (uint64_t)gridDim.x * 256)
+        jp[r] = sid_of[r] != kNone ? initial_register_jp(id_low[r]) : (uint16_t)0;
 }
 
 // ---- initialisation: counter = HLL::default(); add_u128(id) (harmonic.rs:60-66) ----------

@@ -77,16 +77,33 @@ public:
     hipError_t free(void *p)
     {
         if (!p) return hipSuccess;
+        // what hipFree does implicitly - nothing in flight ON THE EXTENT'S DEVICE may still use it - happens OUTSIDE the lock (ADVICE r5:
+        // a free on device 0 that waits for a long kernel must not block every alloc / free / trim of the other devices): look the
+        // extent's device up under the lock, synchronise unlocked, then take the lock again to mark and coalesce.  The extent stays
+        // live in between (only its owner frees it), so the second lookup finds it.
+        int owner_dev = -1;
+        {
+            std::lock_guard<std::mutex> g(mu_);
+            for (const Base &b : bases_)
+                if ((char *)p >= b.ptr && (char *)p < b.ptr + b.bytes) {
+                    owner_dev = b.dev;
+                    break;
+                }
+        }
+        if (owner_dev < 0) { // not ours (allocated before the pool existed, or by someone else)
+            (void)hipDeviceSynchronize();
+            return (hipFree)(p);
+        }
+        {
+            int cur = owner_dev;
+            (void)hipGetDevice(&cur);
+            if (cur != owner_dev) (void)hipSetDevice(owner_dev);
+            (void)hipDeviceSynchronize();
+            if (cur != owner_dev) (void)hipSetDevice(cur);
+        }
         std::lock_guard<std::mutex> g(mu_);
         for (Base &b : bases_) {
             if ((char *)p < b.ptr || (char *)p >= b.ptr + b.bytes) continue;
-            {   // what hipFree does implicitly: nothing in flight ON THE EXTENT'S DEVICE may still use it
-                int cur = b.dev;
-                (void)hipGetDevice(&cur);
-                if (cur != b.dev) (void)hipSetDevice(b.dev);
-                (void)hipDeviceSynchronize();
-                if (cur != b.dev) (void)hipSetDevice(cur);
-            }
             const size_t off = (size_t)((char *)p - b.ptr);
             auto it = b.ext.find(off);
             if (it == b.ext.end() || it->second.free) return hipErrorInvalidValue; // not the start of a live extent
@@ -105,8 +122,7 @@ public:
             }
             return hipSuccess;
         }
-        (void)hipDeviceSynchronize();
-        return (hipFree)(p); // not ours (allocated before the pool existed, or by someone else)
+        return hipErrorInvalidValue; // (the block vanished between the two lookups: a live extent keeps its block, so this is a double free)
     }
     void trim()
     {

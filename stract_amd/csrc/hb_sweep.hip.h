@@ -58,6 +58,7 @@ __device__ __forceinline__ void touch_set(uint32_t *touch, uint32_t r, uint64_t 
 // cheap path of sweep_rows_kernel<true>, which reads those two bitmaps next to the touch bitmap.
 __global__ __launch_bounds__(256) void sweep_collect_kernel(const SweepParams sp)
 {
+    if (!guard_open(sp.guard)) return; // (a queued pass behind the loop's last one: EVERY kernel of it returns at once)
     if (blockIdx.x == 0 && threadIdx.x < 2) sp.counts_next[threadIdx.x] = 0; // last used two passes ago
     const uint64_t words = sp.p.n_pad >> 5;
     const int lane = threadIdx.x & 63;
@@ -93,6 +94,7 @@ __global__ __launch_bounds__(256) void sweep_collect_kernel(const SweepParams sp
 // with more than kHeavyReaders readers (hubs stay in the changed set longest) go to the grid-wide kernel.
 __global__ __launch_bounds__(256) void sweep_expand_kernel(const SweepParams sp)
 {
+    if (!guard_open(sp.guard)) return;
     const int lane = threadIdx.x & 63;
     const uint32_t nseeds = sp.counts[0];
     const uint32_t wave = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
@@ -189,6 +191,7 @@ __global__ __launch_bounds__(256) void sweep_seed_small_kernel(const SweepParams
 
 __global__ __launch_bounds__(256) void sweep_expand_heavy_kernel(const SweepParams sp)
 {
+    if (!guard_open(sp.guard)) return;
     const uint32_t nheavy = sp.counts[1];
     const uint64_t wbase = ((uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 64, nthreads = (uint64_t)gridDim.x * 256;
     const int lane = threadIdx.x & 63;

@@ -11,6 +11,9 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (gfx950) GPU")
+    # every changed-only exchange of the destination partition checks its run offsets two ways under test (hb_api_pass.inc exchange_pack:
+    # the ranks' changed counters against the prefix sums over the changed bitmap); inherited by the worker processes the tests launch
+    os.environ.setdefault("HB_CHECK_EXCHANGE", "1")
     # native pieces are built in-tree; build them when a test run starts without them
     need = [os.path.join(ROOT, "stract_amd", "lib", "libhyperball.so"),
             os.path.join(ROOT, "stract_amd", "lib", "libhb_synth.so"),

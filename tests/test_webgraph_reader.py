@@ -50,6 +50,13 @@ def test_crc32_is_ieee():
     for n in (0, 1, 7, 8, 9, 1000, 65537):
         b = rng.integers(0, 256, n, dtype=np.uint8)
         assert _lib.load().hbw_debug_crc32(b.ctypes.data if n else None, n) == (zlib.crc32(b.tobytes()) & 0xFFFFFFFF)
+    # [r6] the carry-less-multiplication form (hb_webgraph.cpp crc32_clmul: 64-byte folds, 16-byte folds, Barrett reduction, the table
+    # form for the last < 16 bytes) at every length around its block sizes and at odd alignments; zlib is the independent statement
+    buf = rng.integers(0, 256, 5000, dtype=np.uint8)
+    for n in list(range(0, 300)) + [1023, 1024, 1025, 4095, 4096, 4097]:
+        for off in (0, 1, 3, 7, 13):
+            b = buf[off:off + n]
+            assert _lib.load().hbw_debug_crc32(b.ctypes.data if n else None, n) == (zlib.crc32(b.tobytes()) & 0xFFFFFFFF), (n, off)
 
 
 def test_meta_json_reference_shape(tmp_path):
