@@ -1131,7 +1131,11 @@ int hb_finish(hb_ctx *c)
             // the bulk is already on the host (results_stage): what moved since follows as a (sid, value) list
             auto &rs = c->rs;
             HB_HIP(hipMemsetAsync(rs.d_count, 0, sizeof(unsigned long long), c->stream));
-            HB_HIP(hipStreamWaitEvent(c->stream, rs.copied, 0)); // out[] is rewritten: its download must be over
+            // [r6] the list kernel does NOT wait for the last snapshot's download any more (C4: that copy - 794 MB, 14 ms - outlasts the four
+            // sweep passes behind it by ~3 ms, and the kernel's 1.1 ms then came on top).  It rewrites out[sid] only for the entries it also
+            // puts on the list, and the host applies the list AFTER the download has landed (hipEventSynchronize below): whichever of the
+            // two values of such an entry the copy carried, the list's is the one that stays.  If the list overflows, out[] is shipped
+            // whole behind the download instead.
             const unsigned blocks = (unsigned)std::min<uint64_t>((p.n_pad + 2047) / 2048, (uint64_t)c->num_cu * 8);
             hipLaunchKernelGGL(hbk::results_sync_kernel, dim3(blocks), dim3(256), 0, c->stream, (const double *)c->d_ksum, rs.d_sent,
                                (const uint32_t *)c->d_sid_of, p.n_pad, norm, 0, c->d_out, rs.d_sid, rs.d_val, (unsigned long long)rs.cap, rs.d_count, cnt);
@@ -1146,7 +1150,7 @@ int hb_finish(hb_ctx *c)
                     HB_HIP(hipMemcpyAsync(rs.h_val, rs.d_val, moved * sizeof(double), hipMemcpyDeviceToHost, c->stream));
                     HB_HIP(hipStreamSynchronize(c->stream));
                 }
-                // (the snapshot's download is over: the main stream waited for `copied` above)
+                HB_HIP(hipEventSynchronize(rs.copied)); // the snapshot's download is over before the list is applied on top of it
                 double *out = c->h_out;
                 const uint32_t *ls = rs.h_sid;
                 const double *lv = rs.h_val;
@@ -1163,6 +1167,7 @@ int hb_finish(hb_ctx *c)
                     apply(0, moved);
                 }
             } else { // more moved than the list holds: out[] on the device is complete anyway, ship it whole
+                HB_HIP(hipStreamWaitEvent(c->stream, rs.copied, 0)); // (behind the snapshot's download: both write h_out)
                 HB_HIP(hipMemcpyAsync(c->h_out, c->d_out, p.n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
                 HB_HIP(hipStreamSynchronize(c->stream));
             }
