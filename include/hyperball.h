@@ -30,7 +30,8 @@
 extern "C" {
 #endif
 
-#define HB_ABI_VERSION 5
+#define HB_ABI_VERSION 6 /* 6 [r6]: hb_options.tune[1] above its low byte and tune[7] are refused by the product library (experiments build
+                            only); layouts unchanged since 5 */
 
 /* ---- error codes -------------------------------------------------------------- */
 #define HB_OK 0
@@ -112,21 +113,17 @@ typedef struct hb_options {
     int32_t  rank;          /* edge-partition mode: this process' rank ...                 */
     int32_t  world_size;    /* ... of world_size (<= 1: single GPU, no collective)         */
     uint8_t  rccl_id[128];  /* ncclUniqueId from hb_rccl_unique_id() of rank 0             */
-    uint32_t tune[8];       /* tuning knobs, 0 = default:
+    uint32_t tune[8];       /* tuning knobs, 0 = default (every setting gives the same results; these only move time):
                              *  [0] workgroups per CU of the pass launches: low byte = node rows (dense 64, bitmap 32),
-                             *      second byte = hub chunks (dense 2, bitmap 4)
-                             *  [1] low byte: gather unroll 1|2|4 (hub chunks 4, node rows 2); measurement switches: bit 8 = dense fused node
-                             *      rows with the per-tile estimator/Kahan epilogue instead of the once-per-row one; bit 11 = sweep passes
-                             *      always with the three-launch seed collection / expansion, also in the convergence tail; bit 12 = edge
-                             *      partition without the merge / all-reduce / epilogue pipeline over row ranges; bit 13 = bitmap passes
-                             *      gather slot by slot instead of packing each row's surviving sources first
-                             *  [2] frontier mode when A_t < tune[2] % of the edges (50; > 100 = always)
+                             *      second byte = hub chunks (dense 2, bitmap 5)
+                             *  [1] low byte: gather unroll 1|2|4 (hub chunks 4, node rows 2).  The bits above it are switches of the
+                             *      experiments build only (stract_amd/csrc/hb_experiments.h); hb_create refuses them
+                             *  [2] bitmap passes when A_t < tune[2] % of the edges (50; > 100 = always)
                              *  [3] log2 of the hotness slice width in counters (16 = 4 MiB; 1 = no slices)
                              *  [4] min sources of a chunk at a slice cut (8)
                              *  [5] largest row that is not split into chunks (chunk)
-                             *  [6] sweep mode (touched rows only) when A_t * tune[6] < edges (10; 1 = whenever frontier)
-                             *  [7] experiment: hottest counters staged in LDS by the level-1 dense launch (0 = off, <= 2048;
-                             *      measured slower); hb_host_plan: owner slices                */
+                             *  [6] sweep passes (touched rows only) when A_t * tune[6] < edges (10; 1 = whenever a bitmap pass would run)
+                             *  [7] reserved, must be 0 (experiments build: see hb_experiments.h)                 */
 } hb_options;
 
 typedef struct hb_ctx hb_ctx;
@@ -170,9 +167,8 @@ typedef struct hb_stats {
     uint64_t pipelined_passes;  /* [ABI 5] passes of the last hb_run that were queued BEFORE the host had read the previous pass'
                                    counters (convergence tail, one rank: a pass that changed <= 4096 nodes in sweep mode is
                                    followed by passes guarded on the device; the pass behind the loop's last one does nothing) */
-    uint64_t tail_kernel_passes; /* [ABI 5] passes of the last run that ONE single-workgroup launch ran from work lists (the far
-                                   convergence tail: <= 4096 changed nodes with short reader lists; several passes per launch).
-                                   Off by default (tune[1] bit 21 = on): measured no faster than the launches it replaces      */
+    uint64_t tail_kernel_passes; /* [ABI 5] always 0 in the product library (experiments build: passes one single-workgroup launch ran
+                                   from work lists; measured no faster than the launches it replaces, so not shipped)          */
 } hb_stats;
 
 typedef struct hb_pass_stats {
@@ -185,8 +181,7 @@ typedef struct hb_pass_stats {
     uint32_t mode;          /* 0 = dense (no frontier test), 1 = frontier bitmap, 2 = sweep (touch bitmap of the rows
                                that read a changed node; only those rows run), 3 = reference tail
                                (HB_FLAG_REFERENCE_TAIL: update_changed_counters over the page-level records)  
-                               4 = [ABI 5] the far tail as one workgroup: the pass ran from work lists inside a launch that may
-                               hold several passes (hb_tail.hip.h); ms_gpu = the launch's time / its passes                       */
+                               (4 = experiments build only: the pass ran inside the single-workgroup tail kernel)                 */
     float    ms_gpu;        /* GPU time of the pass (all its launches + collective)         */
     float    ms_main;       /* GPU time of the dominant launch (real rows)                  */
     float    ms_collective;

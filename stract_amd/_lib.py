@@ -17,7 +17,10 @@ os.environ.setdefault("OMP_WAIT_POLICY", "passive")
 import numpy as np  # noqa: E402
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get("HB_LIB_PATH") or os.path.join(_HERE, "lib", "libhyperball.so")  # HB_LIB_PATH: experiment builds
+LIB_PATH = os.environ.get("HB_LIB_PATH") or os.path.join(_HERE, "lib", "libhyperball.so")  # HB_LIB_PATH: debug / interpreter builds
+# The EXPERIMENTS build (stract_amd/csrc/hb_experiments.h: A/B switches of rejected kernel forms, test hooks; `make exp`): the product
+# library refuses those switches, so a Context that asks for one is served by this build.  Tests and measurement tools only.
+LIB_EXP_PATH = os.environ.get("HB_LIB_PATH") or os.path.join(_HERE, "lib", "libhyperball_exp.so")
 
 HB_OK = 0
 HB_ERR_INVALID, HB_ERR_NO_DEVICE, HB_ERR_HIP, HB_ERR_NOMEM, HB_ERR_RCCL, HB_ERR_LIMIT, HB_ERR_IO = -1, -2, -3, -4, -5, -6, -7
@@ -203,6 +206,13 @@ _SIGNATURES += [
 SYMBOLS = [s[0] for s in _SIGNATURES]
 
 _lib = None
+_lib_exp = None
+
+
+def needs_experiments_build(tune):
+    """hb_options.tune values that only the experiments build understands (hb_experiments.h): tune[1] above its low byte, tune[7]."""
+    tune = tuple(tune)
+    return (len(tune) > 1 and (int(tune[1]) & ~0xFF) != 0) or (len(tune) > 7 and int(tune[7]) != 0)
 
 
 class HyperballError(RuntimeError):
@@ -211,27 +221,34 @@ class HyperballError(RuntimeError):
         self.code = code
 
 
-def load():
-    """Load libhyperball.so (once).  Raises if it has not been built."""
-    global _lib
-    if _lib is not None:
-        return _lib
-    if not os.path.exists(LIB_PATH):
+def _open(path):
+    if not os.path.exists(path):
         raise HyperballError(HB_ERR_INVALID,
                              "%s not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
-                             "or `make -C stract_amd/csrc` (there is no CPU fallback)" % LIB_PATH)
-    lib = ctypes.CDLL(LIB_PATH)
+                             "or `make -C stract_amd/csrc` (there is no CPU fallback)" % path)
+    lib = ctypes.CDLL(path)
     if hasattr(lib, "hb_simt_interpreter") and os.environ.get("HB_ALLOW_SIMT_INTERPRETER") != "1":
         # tests/simt builds the library's sources against a host interpreter of the device code: test infrastructure for
         # kernel LOGIC, never a way to compute.  Only tests/test_simt.py sets the variable (for its own child process).
         raise HyperballError(HB_ERR_NO_DEVICE, "%s is the SIMT-interpreter test build, not the gfx950 library: refused "
-                             "(there is no CPU fallback)" % LIB_PATH)
+                             "(there is no CPU fallback)" % path)
     for name, res, args in _SIGNATURES:
         fn = getattr(lib, name)  # AttributeError if the ABI lost a symbol
         fn.restype = res
         fn.argtypes = args
-    _lib = lib
     return lib
+
+
+def load(experiments=False):
+    """Load libhyperball.so (once).  Raises if it has not been built.  experiments=True: the experiments build (see LIB_EXP_PATH)."""
+    global _lib, _lib_exp
+    if experiments and LIB_EXP_PATH != LIB_PATH:
+        if _lib_exp is None:
+            _lib_exp = _open(LIB_EXP_PATH)
+        return _lib_exp
+    if _lib is None:
+        _lib = _open(LIB_PATH)
+    return _lib
 
 
 def device_count():
@@ -314,7 +331,7 @@ class Context:
     """Thin owner of an hb_ctx*; methods map 1:1 onto the C entry points."""
 
     def __init__(self, device=-1, flags=0, chunk=0, max_passes=0, rank=0, world_size=1, rccl_id=None, tune=()):
-        self.lib = load()
+        self.lib = load(experiments=needs_experiments_build(tune))
         opt = HbOptions()
         opt.struct_size = ctypes.sizeof(HbOptions)
         opt.device = device

@@ -18,8 +18,11 @@
 #include <vector>
 
 #include "hb_internal.h"
+#include "hb_experiments.h" // HB_XBITS: the switches of the experiments build (none in the product library)
 #include "hb_kernels.hip.h"
+#ifdef HB_EXPERIMENTS
 #include "hb_experiments.hip.h"
+#endif
 #include "hll64_tables.inc"
 
 using namespace hb;
@@ -392,6 +395,7 @@ int build_sparse_support(hb_ctx *c)
     if ((rc = dev_alloc(c, &c->d_seeds, p.n_pad))) return rc;
     if ((rc = dev_alloc(c, &c->d_heavy, p.n_pad))) return rc;
     if ((rc = dev_alloc(c, &c->d_sparse_counts, 64))) return rc;
+#ifdef HB_EXPERIMENTS
     for (int k = 0; k < 2; k++) { // the tail kernel's lists (hb_tail.hip.h): 2.7 MB in all
         if ((rc = dev_alloc(c, &c->d_tl_changed[k], hbk::kTailCap))) return rc;
         if ((rc = dev_alloc(c, &c->d_tl_vchanged[k], hbk::kTailCap))) return rc;
@@ -399,6 +403,7 @@ int build_sparse_support(hb_ctx *c)
     }
     if ((rc = dev_alloc(c, &c->d_tl_work, (size_t)(hbk::kTailLevels + 1) * hbk::kTailCap))) return rc;
     if ((rc = dev_alloc(c, &c->d_tl_count, hbk::kTcWords))) return rc;
+#endif
     if ((rc = dev_alloc(c, &d_count, rows_total))) return rc; // stays allocated (small next to out_rows)
     HB_HIP(hipMemsetAsync(c->d_touch, 0, (c->bits_words + 64) * sizeof(uint32_t), c->stream));
     HB_HIP(hipMemsetAsync(d_count, 0, rows_total * sizeof(uint32_t), c->stream));
@@ -422,21 +427,6 @@ int build_sparse_support(hb_ctx *c)
 #include "hb_api_load.inc"
 
 #include "hb_api_pass.inc"
-
-// host worker threads of one call: joined on every way out of the scope (a std::thread that is still joinable when it is
-// destroyed - an exception while the pool is being filled - calls std::terminate, past every catch handler of guarded())
-struct ThreadPool {
-    std::vector<std::thread> th;
-    template <class F, class... A>
-    void spawn(F &&f, A &&...a) { th.emplace_back(std::forward<F>(f), std::forward<A>(a)...); }
-    void join()
-    {
-        for (auto &t : th)
-            if (t.joinable()) t.join();
-        th.clear();
-    }
-    ~ThreadPool() { join(); }
-};
 
 // The C ABI never unwinds (include/hyperball.h): every entry point that can allocate runs under this guard.
 template <class F>
@@ -535,6 +525,11 @@ int hb_create(const hb_options *opt, hb_ctx **out)
         if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
             return fail(c, HB_ERR_NO_DEVICE, std::string("device is ") + prop.gcnArchName + ", kernels are built for gfx950 only");
         if (o.world_size > 1 && (o.rank < 0 || o.rank >= o.world_size)) return fail(c, HB_ERR_INVALID, "rank out of range");
+#ifndef HB_EXPERIMENTS
+        if ((o.tune[1] & ~0xFFu) || o.tune[7])
+            return fail(c, HB_ERR_INVALID, "hb_options.tune[1] bits above the low byte and tune[7] are switches of the experiments build (libhyperball_exp.so, "
+                                           "-DHB_EXPERIMENTS: stract_amd/csrc/hb_experiments.h); the product library has none of them");
+#endif
         if ((o.flags & HB_FLAG_REFERENCE_TAIL) && (o.world_size > 1 || (o.flags & (HB_FLAG_RCCL_SELF | HB_FLAG_DEST_PARTITION))))
             return fail(c, HB_ERR_INVALID, "HB_FLAG_REFERENCE_TAIL is a single-rank mode (no partition / RCCL flags)");
         hb_ctx *ctx = new (std::nothrow) hb_ctx();
@@ -566,7 +561,9 @@ int hb_create(const hb_options *opt, hb_ctx **out)
             ctx->h_slot = w + hbk::kCounterWords;
             ctx->h_tl_count = (uint32_t *)(w + 3 * (size_t)hbk::kCounterWords);
             ctx->h_rank_cnt = w + 3 * (size_t)hbk::kCounterWords + 32;
+#ifdef HB_EXPERIMENTS
             static_assert(hbk::kTcWords * sizeof(uint32_t) <= 32 * sizeof(unsigned long long), "h_tl_count slot too small");
+#endif
         }
         for (auto &e : ctx->slot_done)
             if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { ctx->err = "hipEventCreate failed"; return bail(HB_ERR_HIP); }
@@ -1151,21 +1148,7 @@ int hb_finish(hb_ctx *c)
                     HB_HIP(hipStreamSynchronize(c->stream));
                 }
                 HB_HIP(hipEventSynchronize(rs.copied)); // the snapshot's download is over before the list is applied on top of it
-                double *out = c->h_out;
-                const uint32_t *ls = rs.h_sid;
-                const double *lv = rs.h_val;
-                auto apply = [out, ls, lv](uint64_t lo, uint64_t hi) {
-                    for (uint64_t k = lo; k < hi; k++) out[ls[k]] = lv[k];
-                };
-                const uint64_t nthr = moved >= (1u << 16) ? std::min<uint64_t>(8, std::max(1u, std::thread::hardware_concurrency())) : 1;
-                if (nthr > 1) { // every sid occurs once: the shares are independent
-                    ThreadPool pool;
-                    for (uint64_t k = 1; k < nthr; k++) pool.spawn(apply, moved * k / nthr, moved * (k + 1) / nthr);
-                    apply(0, moved / nthr);
-                    pool.join();
-                } else {
-                    apply(0, moved);
-                }
+                host_scatter_f64(c->h_out, rs.h_sid, rs.h_val, moved); // every sid occurs once: the shares are independent (hb_host.cpp, OpenMP team)
             } else { // more moved than the list holds: out[] on the device is complete anyway, ship it whole
                 HB_HIP(hipStreamWaitEvent(c->stream, rs.copied, 0)); // (behind the snapshot's download: both write h_out)
                 HB_HIP(hipMemcpyAsync(c->h_out, c->d_out, p.n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
@@ -1283,36 +1266,7 @@ int hb_result_copy(hb_ctx *c, hb_u128 *ids, double *vals, uint64_t cap)
         if (!c->finished) return fail(c, HB_ERR_INVALID, "no results: hb_run / hb_finish not called");
         // compaction of the per-node array (absent = negative) into the caller's buffers, on the host cores the process may use
         // (C4: 99 M nodes -> 79 M results = 1.9 GB written; one thread took 1.3 s of the 15 s chain store -> load -> run -> store)
-        const uint64_t n = c->plan.n;
-        const double *src = c->h_out;
-        const hb_u128 *idsrc = c->g.ids.data();
-        const uint64_t nthr = n >= (1u << 18) ? std::min<uint64_t>(16, std::max(1u, std::thread::hardware_concurrency())) : 1;
-        std::vector<uint64_t> first(nthr + 1, 0);
-        auto share = [&](uint64_t k) { return n * k / nthr; };
-        auto count_share = [&](uint64_t k) {
-            uint64_t kept = 0;
-            for (uint64_t sid = share(k); sid < share(k + 1); sid++) kept += src[sid] >= 0.0;
-            first[k + 1] = kept;
-        };
-        auto copy_share = [&](uint64_t k) {
-            uint64_t at = first[k];
-            for (uint64_t sid = share(k); sid < share(k + 1) && at < cap; sid++) {
-                const double v = src[sid];
-                if (v < 0.0) continue;
-                if (ids) ids[at] = idsrc[sid];
-                if (vals) vals[at] = v;
-                at++;
-            }
-        };
-        auto on_all = [&](auto &&f) {
-            ThreadPool pool;
-            for (uint64_t k = 1; k < nthr; k++) pool.spawn(f, k);
-            f(0);
-            pool.join();
-        };
-        on_all(count_share);
-        for (uint64_t k = 0; k < nthr; k++) first[k + 1] += first[k];
-        on_all(copy_share);
+        host_compact_results(c->h_out, c->g.ids.data(), c->plan.n, ids, vals, cap);
         return HB_OK;
     });
 }

@@ -21,6 +21,8 @@
 
 #ifdef _OPENMP
 #include <omp.h>
+
+#include "hb_threads.h"
 #include <parallel/algorithm>
 #define HB_SORT(b, e) __gnu_parallel::sort((b), (e))
 #define HB_SORT_CMP(b, e, c) __gnu_parallel::sort((b), (e), (c))
@@ -765,6 +767,47 @@ bool build_lc_table(uint8_t lc[68])
         }
     }
     return robust;
+}
+
+// ---- host-parallel loops of the result path (hb_internal.h) ------------------------------------------------------------------------
+void host_scatter_f64(double *out, const uint32_t *idx, const double *val, uint64_t n)
+{
+    if (n < (1u << 16)) {
+        for (uint64_t k = 0; k < n; k++) out[idx[k]] = val[k];
+        return;
+    }
+#pragma omp parallel for num_threads(std::min(host_threads(), 8)) schedule(static)
+    for (int64_t k = 0; k < (int64_t)n; k++) out[idx[k]] = val[k];
+}
+
+void host_compact_results(const double *src, const hb_u128 *idsrc, uint64_t n, hb_u128 *ids, double *vals, uint64_t cap)
+{
+    const int want = n >= (1u << 18) ? std::min(host_threads(), 16) : 1;
+    std::vector<uint64_t> first((size_t)want + 1, 0);
+    int team = 1;
+#pragma omp parallel num_threads(want)
+    {
+        // (the team may be smaller than asked for: the shares are cut by the team that exists)
+        const int nt = omp_get_num_threads(), t = omp_get_thread_num();
+#pragma omp single
+        team = nt;
+        const uint64_t lo = n * (uint64_t)t / (uint64_t)nt, hi = n * (uint64_t)(t + 1) / (uint64_t)nt;
+        uint64_t kept = 0;
+        for (uint64_t sid = lo; sid < hi; sid++) kept += src[sid] >= 0.0;
+        first[(size_t)t + 1] = kept;
+#pragma omp barrier
+#pragma omp single
+        for (int k = 0; k < nt; k++) first[(size_t)k + 1] += first[(size_t)k];
+        uint64_t at = first[(size_t)t];
+        for (uint64_t sid = lo; sid < hi && at < cap; sid++) {
+            const double v = src[sid];
+            if (v < 0.0) continue;
+            if (ids) ids[at] = idsrc[sid];
+            if (vals) vals[at] = v;
+            at++;
+        }
+    }
+    (void)team;
 }
 
 } // namespace hb

@@ -262,6 +262,14 @@ std::string gpu_build_plan(void *stream, uint64_t n, const uint64_t *d_row_ptr, 
                            bool reorder, const PlanTune &tune, Plan *plan, DevicePlan *out);
 
 double now_ms();
+// [r6] the two host-parallel loops of the result path, on the OpenMP team the process already has (hb_host.cpp): no thread is CREATED
+// inside hb_finish / hb_result_copy any more.  Creating one needs the process' address-space lock (its stack is mmap'ed), and
+// hb_load_webgraph's background unmapping of a 100 GB store holds that lock for seconds: the first hb_finish behind a real webgraph load
+// took 419 ms at C4 against 4.7 ms steady, hb_result_copy 2.1 s (profiles/r06c_bench_default.err).
+//   out[idx[k]] = val[k] for k < n; every idx occurs at most once
+void host_scatter_f64(double *out, const uint32_t *idx, const double *val, uint64_t n);
+//   the (id, value) pairs with src[sid] >= 0.0 in ascending sid order, at most cap of them; ids / vals may be NULL
+void host_compact_results(const double *src, const hb_u128 *idsrc, uint64_t n, hb_u128 *ids, double *vals, uint64_t cap);
 
 // ---- store emission (hb_store.cpp; the key order may come from the device: hb_ingest.hip gpu_store_keys) ---------------------
 // one entry of the sort: the 17 key bytes as two big-endian words + the last byte, so that integer order = byte order of

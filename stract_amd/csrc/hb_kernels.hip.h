@@ -44,20 +44,6 @@ __device__ unsigned int g_dbg_line = 0;
 #define HB_DBG_ASSERT(cond) ((void)0)
 #endif
 
-// Streams that are read or written exactly once per pass (row pointers, source indices, per-row Kahan / size words, the
-// freshly written counters) go through these two helpers.  A non-temporal variant of them (cache-bypass hints, leaving
-// the L2 to the gathered counters) was measured in rounds 2 and 3 and lost (dense pass 2.96 -> 3.04 ms at C3; DESIGN.md
-// "tried and rejected"); the switch is gone, the helpers stay as the one place such a hint would go.
-template <class T>
-__device__ __forceinline__ T ld_stream(const T *p)
-{
-    return *p;
-}
-template <class T>
-__device__ __forceinline__ void st_stream(T *p, const T &v)
-{
-    *p = v;
-}
 // Per-pass counters are striped: kStripes copies of 4 words, a block adds to stripe blockIdx % kStripes
 // (one same-address atomic stream sustains only ~90 updates/us; 8192 waves finishing together made a
 // 0.1 ms tail).  The host sums the stripes.
@@ -247,15 +233,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((REAL && UN
     uint4 nself = make_uint4(0, 0, 0, 0);
     const bool lean = INIT && REAL && FUSED && p.rd_init != nullptr; // kernel-uniform (PassParams::rd_init)
     auto own_counter = [&](uint64_t r) -> uint4 { // the row's counter before this pass
-        if (INIT && REAL && FUSED && lean) return counter_quarter_of_jp((uint32_t)ld_stream(&p.self_jp[r]), q);
+        if (INIT && REAL && FUSED && lean) return counter_quarter_of_jp((uint32_t)p.self_jp[r], q);
         return p.rd[r * 4 + q];
     };
     {
         const uint64_t r0 = row_lo + (tile0 << 6) + ((uint64_t)wave << 4) + (uint64_t)g;
         if (tile0 < ntiles && r0 < row_hi) {
-            nbeg = ld_stream(&p.row_ptr[r0]);
-            nend = ld_stream(&p.row_ptr[r0 + 1]);
-            if (REAL && FUSED) nod = ld_stream(&p.outdeg[r0]);
+            nbeg = p.row_ptr[r0];
+            nend = p.row_ptr[r0 + 1];
+            if (REAL && FUSED) nod = p.outdeg[r0];
             if (kDenseReal) nself = own_counter(r0);
         }
     }
@@ -272,9 +258,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((REAL && UN
             nod = 0;
             nself = make_uint4(0, 0, 0, 0);
             if (tile + tstride < ntiles && nrow < row_hi) {
-                nbeg = ld_stream(&p.row_ptr[nrow]);
-                nend = ld_stream(&p.row_ptr[nrow + 1]);
-                if (REAL && FUSED) nod = ld_stream(&p.outdeg[nrow]);
+                nbeg = p.row_ptr[nrow];
+                nend = p.row_ptr[nrow + 1];
+                if (REAL && FUSED) nod = p.outdeg[nrow];
                 if (kDenseReal) nself = own_counter(nrow);
             }
         }
@@ -289,15 +275,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((REAL && UN
                 pre_sz = real_row ? (uint64_t)s_lc[63] : 0ull;
             } else if (kEpi4) {
                 if (q == npend) { // this lane owns the row's deferred epilogue
-                    pre_sz = ld_stream(&p.size[row]);
-                    pre_ks = ld_stream(&p.ksum[row]);
-                    pre_ke = ld_stream(&p.kerr[row]);
+                    pre_sz = p.size[row];
+                    pre_ks = p.ksum[row];
+                    pre_ke = p.kerr[row];
                 }
             } else {
-                pre_sz = ld_stream(&p.size[row]);
+                pre_sz = p.size[row];
                 if (q == 0) {
-                    pre_ks = ld_stream(&p.ksum[row]);
-                    pre_ke = ld_stream(&p.kerr[row]);
+                    pre_ks = p.ksum[row];
+                    pre_ke = p.kerr[row];
                 }
             }
         }
@@ -321,7 +307,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((REAL && UN
 #pragma unroll
                     for (int u = 0; u < UNROLL; u++) {
                         const uint64_t ee = e + 4 * u + q;
-                        idx[u] = (ee < end) ? (uint32_t)ld_stream(&p.src_jp[ee]) : 0u; // value 0 = nothing to merge
+                        idx[u] = (ee < end) ? (uint32_t)p.src_jp[ee] : 0u; // value 0 = nothing to merge
                     }
 #pragma unroll
                     for (int u = 0; u < UNROLL; u++) {
@@ -334,7 +320,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((REAL && UN
 #pragma unroll
                 for (int u = 0; u < UNROLL; u++) {
                     uint64_t ee = e + 4 * u + q;
-                    idx[u] = (ee < end) ? ld_stream(&p.src[ee]) : kNone;
+                    idx[u] = (ee < end) ? p.src[ee] : kNone;
                 }
 #pragma unroll
                 for (int u = 0; u < UNROLL; u++) {
@@ -400,10 +386,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((REAL && UN
             // lazy double buffer: wr[row] already holds the right value unless the row changed in this or in the previous pass
             // [r5: used by the fused dense pass too - a fifth of the hosts of an R-MAT graph have no in-link at all and never
             // change: 64 B per such row and pass that nobody needs; the unfused forms store every row: the exchanges read them]
-            if (need && (!FUSED || INIT || changed || self_prev || p.t_plus_1 == 1.0)) st_stream(&p.wr[row * 4 + q], accv); // (pass 0 fills the other buffer)
-            if (lean && need && !changed) st_stream(&p.rd_init[row * 4 + q], accv); // (see PassParams::rd_init; a changed row is rewritten by pass 1 anyway)
+            if (need && (!FUSED || INIT || changed || self_prev || p.t_plus_1 == 1.0)) p.wr[row * 4 + q] = accv; // (pass 0 fills the other buffer)
+            if (lean && need && !changed) p.rd_init[row * 4 + q] = accv; // (see PassParams::rd_init; a changed row is rewritten by pass 1 anyway)
         } else {
-            if (changed) st_stream(&p.part[(row - p.n_pad) * 4 + q], accv);
+            if (changed) p.part[(row - p.n_pad) * 4 + q] = accv;
         }
         const uint32_t ch16 = pack16(bal);
         if (FUSED) { // changed bits of the node rows -> next frontier (nobody tests a virtual row's bit in a dense pass)
@@ -520,8 +506,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void f
         nprev16 = nkd16 = 0;
         const uint64_t r16 = row_lo + (tile << 6) + ((uint64_t)wave << 4), r = r16 + (uint64_t)g;
         if (tile < ntiles && r < row_hi) {
-            nbeg = ld_stream(&p.row_ptr[r]);
-            nend = ld_stream(&p.row_ptr[r + 1]);
+            nbeg = p.row_ptr[r];
+            nend = p.row_ptr[r + 1];
         }
         if (REAL && tile < ntiles && r16 < row_hi) {
             nprev16 = (uint32_t)((const uint16_t *)p.bits_rd)[r16 >> 4];
@@ -559,7 +545,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void f
 #pragma unroll
                     for (int j = 4 * b; j < 4 * b + 4; j++) {
                         const uint64_t ee = e0 + 4 * j + q;
-                        idx[j] = (ee < end) ? ld_stream(&p.src[ee]) : kNone;
+                        idx[j] = (ee < end) ? p.src[ee] : kNone;
                     }
                 } else {
 #pragma unroll
@@ -688,9 +674,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void f
         const bool changed = ((bal >> qshift) & 0xFull) != 0;
         if (REAL) {
             // lazy double buffer: wr[row] already holds the right value unless the row changed in this or in the previous pass
-            if (need && (changed || self_prev)) st_stream(&p.wr[row * 4 + q], accv);
+            if (need && (changed || self_prev)) p.wr[row * 4 + q] = accv;
         } else {
-            if (changed) st_stream(&p.part[(row - p.n_pad) * 4 + q], accv);
+            if (changed) p.part[(row - p.n_pad) * 4 + q] = accv;
         }
         const uint32_t ch16 = pack16(bal);
         if (FUSED || !REAL) {
@@ -736,7 +722,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void f
 
 } // namespace hbk
 #include "hb_sweep.hip.h"
-#include "hb_tail.hip.h"
+#ifdef HB_EXPERIMENTS
+#include "hb_tail.hip.h" // the far tail as one workgroup: experiments build only (measured no faster)
+#endif
 namespace hbk {
 
 // ---- unfused epilogue (edge-partition mode, after the all-reduce) ----------------------

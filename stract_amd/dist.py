@@ -122,7 +122,7 @@ class HostStagedCollectives:
         self.td, self.torch, self.group = td, torch, group
         self.world = td.get_world_size(group)
         self.rank = td.get_rank(group)
-        self.lib = _lib.load()
+        self.lib = ctx.lib  # (the build that owns the context: product, or the experiments build when the context asked for one of its switches)
         self.calls = {"all_reduce": 0, "all_gather": 0, "broadcast": 0, "bytes": 0}
         self.error = None
         np_of = {_lib.HB_COLL_U8: np.uint8, _lib.HB_COLL_U32: np.uint32, _lib.HB_COLL_U64: np.uint64, _lib.HB_COLL_F64: np.float64}

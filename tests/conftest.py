@@ -16,6 +16,7 @@ def pytest_configure(config):
     os.environ.setdefault("HB_CHECK_EXCHANGE", "1")
     # native pieces are built in-tree; build them when a test run starts without them
     need = [os.path.join(ROOT, "stract_amd", "lib", "libhyperball.so"),
+            os.path.join(ROOT, "stract_amd", "lib", "libhyperball_exp.so"),
             os.path.join(ROOT, "stract_amd", "lib", "libhb_synth.so"),
             os.path.join(ROOT, "oracle", "libhb_oracle.so")]
     if not all(os.path.exists(p) for p in need):

@@ -26,7 +26,7 @@ def test_header_symbols_all_exported():
     assert not missing, missing
     # and the Python binding covers exactly the declared set
     assert declared == set(_lib.SYMBOLS)
-    assert _lib.load().hb_abi_version() == 5
+    assert _lib.load().hb_abi_version() == 6
 
 
 def test_headers_are_plain_c99_and_struct_sizes_agree(tmp_path):
