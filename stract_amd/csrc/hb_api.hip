@@ -404,8 +404,22 @@ int build_sparse_support(hb_ctx *c)
     if ((rc = dev_alloc(c, &c->d_tl_work, (size_t)(hbk::kTailLevels + 1) * hbk::kTailCap))) return rc;
     if ((rc = dev_alloc(c, &c->d_tl_count, hbk::kTcWords))) return rc;
 #endif
-    if ((rc = dev_alloc(c, &d_count, rows_total))) return rc; // stays allocated (small next to out_rows)
     HB_HIP(hipMemsetAsync(c->d_touch, 0, (c->bits_words + 64) * sizeof(uint32_t), c->stream));
+    {   // [r6] by sorting (hb_plan.hip gpu_transpose_rows: streaming traffic only); the scatter form below only when the device cannot
+        // lend the sort 16 bytes per entry, or on request (experiments build, tune[1] bit 25: A/B runs and the parity variant that
+        // keeps the fallback exact)
+        const bool scatter = (HB_XBITS(c->opt.tune[1]) & 0x2000000u) != 0;
+        if (!scatter) {
+            const std::string e = gpu_transpose_rows((void *)c->stream, c->d_row_ptr, c->d_src, rows_total, entries, c->d_out_ptr, c->d_out_rows);
+            if (e.empty()) {
+                c->sparse_ok = true;
+                return HB_OK;
+            }
+            if (e.find("out of memory") == std::string::npos) return fail(c, HB_ERR_HIP, e);
+            (void)hipGetLastError();
+        }
+    }
+    if ((rc = dev_alloc(c, &d_count, rows_total))) return rc; // stays allocated (small next to out_rows)
     HB_HIP(hipMemsetAsync(d_count, 0, rows_total * sizeof(uint32_t), c->stream));
     const unsigned blocks = (unsigned)std::min<uint64_t>((rows_total * 4 + 255) / 256, (uint64_t)c->num_cu * 16);
     hipLaunchKernelGGL(hbk::transpose_count_kernel, dim3(blocks), dim3(256), 0, c->stream, (const uint64_t *)c->d_row_ptr,

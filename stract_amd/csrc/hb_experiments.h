@@ -19,6 +19,8 @@
 //     bit 21  0x200000  the far tail as one workgroup (hb_tail.hip.h) after a small sweep pass; measured no faster (round 5)
 //     bit 22  0x400000  ... after any pass (tests)
 //     bit 23  0x800000  hb_begin always writes the whole initial state (round 6 A/B: the lean pass 0 off)
+//     bit 24  0x1000000 destination partition, changed-only: 64-byte counters on the wire instead of the 6-bit packing (round 6 A/B)
+//     bit 25  0x2000000 the transposed work-row graph by atomic scatter (the form before round 6; today only the out-of-memory fallback)
 //   hb_options.tune[7]  hottest counters staged in LDS by the level-1 dense launch (0 = off, <= 2048; measured slower, round 2)
 #pragma once
 #include <stdint.h>

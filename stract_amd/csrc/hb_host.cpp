@@ -19,10 +19,10 @@
 #include <sched.h>
 #include <numeric>
 
-#ifdef _OPENMP
-#include <omp.h>
+#include <omp.h> // (the query functions are linked in every build; a compiler that ignores the pragmas runs the loops serially)
 
 #include "hb_threads.h"
+#ifdef _OPENMP
 #include <parallel/algorithm>
 #define HB_SORT(b, e) __gnu_parallel::sort((b), (e))
 #define HB_SORT_CMP(b, e, c) __gnu_parallel::sort((b), (e), (c))
@@ -167,7 +167,7 @@ std::string ingest_edges(const hb_u128 *node_ids, uint64_t n_in, const hb_edge *
     if (m && !edges) return "edges == NULL with m > 0";
     ThreadScope threads(m + n_in);
     // ---- node set
-    std::vector<hb_u128> &ids = out->ids;
+    auto &ids = out->ids;
     try {
         if (node_ids && n_in) {
             ids.assign(node_ids, node_ids + n_in);

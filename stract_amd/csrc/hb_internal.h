@@ -53,7 +53,7 @@ static inline bool u128_eq(const hb_u128 &a, const hb_u128 &b) { return a.hi == 
 // The reduced graph in ascending-NodeID ("sid") indexing: what the reference's
 // host_nodes()/host_edges() semantics leave.
 struct DenseGraph {
-    std::vector<hb_u128> ids;      // n, strictly ascending
+    uvec<hb_u128> ids;             // n, strictly ascending (uvec: sized, then filled by a copy from the device or from the caller - no zero fill of 1.6 GB at C4)
     std::vector<uint64_t> row_ptr; // n + 1, in-edges of sid v
     std::vector<uint32_t> src;     // m_eff, sids
     uint64_t m_input = 0, m_unique = 0;
@@ -256,6 +256,10 @@ struct DevicePlan {
 std::string device_offsets(void *stream, uint32_t *d_counts, uint64_t count, uint64_t *d_offsets, uint64_t expect);
 // d_offsets[0 .. count]: exclusive prefix sums of d_counts (count + 1 outputs)
 std::string device_prefix(void *stream, const uint32_t *d_counts, uint64_t count, uint64_t *d_offsets);
+// the transposed work-row graph (out_ptr: rows_total + 1 offsets, out_rows: `entries` reader rows) by one stable radix sort of
+// (source, row) keys; "" or an error text - "out of memory ..." = the caller may fall back to the scatter kernels
+std::string gpu_transpose_rows(void *stream, const uint64_t *d_row_ptr, const uint32_t *d_src, uint64_t rows_total, uint64_t entries, uint64_t *d_out_ptr,
+                               uint32_t *d_out_rows);
 // destination partition: drop the in-edges of the rows other ranks own from a device CSR (the device form of keep_owned_rows)
 std::string gpu_keep_owned_rows(void *stream, DeviceCsr *csr, uint64_t n, uint64_t world, uint64_t rank);
 std::string gpu_build_plan(void *stream, uint64_t n, const uint64_t *d_row_ptr, const uint32_t *d_src, const uint32_t *d_outdeg_sid,

@@ -797,14 +797,13 @@ __global__ __launch_bounds__(256) void epilogue_kernel(const PassParams p)
 
 // src_jp[e] for every entry of the work rows' source lists: the ONE register HyperLogLog::add(id) sets in the
 // source's initial counter (same arithmetic as init_kernel below), as index | value << 8; virtual sources: 0.
-__global__ __launch_bounds__(256) void src_jp_kernel(const uint32_t *src, uint64_t len, const uint64_t *id_low, const uint32_t *sid_of,
-                                                     uint64_t n_pad, uint16_t *jp)
+// [r6] gathered from self_jp (2 bytes per node: 200 MB at C4, Infinity-Cache resident) instead of recomputed from id_low / sid_of
+// (12 bytes per node behind two random 64-byte fetches per entry: 180 GB of HBM traffic for C4's 2.7 G entries, profiles/r05c_C4_pmc.json)
+__global__ __launch_bounds__(256) void src_jp_kernel(const uint32_t *src, uint64_t len, const uint16_t *self_jp, uint64_t n_pad, uint16_t *jp)
 {
     for (uint64_t e = (uint64_t)blockIdx.x * 256 + threadIdx.x; e < len; e += (uint64_t)gridDim.x * 256) {
         const uint32_t s = src[e];
-        uint16_t v = 0;
-        if (s < n_pad && sid_of[s] != kNone) v = initial_register_jp(id_low[s]);
-        jp[e] = v;
+        jp[e] = s < n_pad ? self_jp[s] : (uint16_t)0;
     }
 }
 // self_jp[row]: the same entry for every node row's OWN initial counter (padding rows: 0); read by the lean pass 0 (PassParams::rd_init)

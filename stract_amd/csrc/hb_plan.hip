@@ -575,6 +575,84 @@ std::string device_prefix(void *stream_v, const uint32_t *d_counts, uint64_t cou
     return "";
 }
 
+// ---- the transposed work-row graph by SORTING [r6] ----------------------------------------------------------------------------------
+// out_rows / out_ptr (who reads each node or virtual row: the sweep passes' expansion) used to be built by scattering: one atomic
+// cursor bump and one 4-byte store at a random place per entry - 126 bytes of HBM traffic per entry at C4 (266 GB for 2.1 G entries,
+// L2 hit rate 8.7 %: profiles/r05c_C4_pmc.json), plus a counting pass of atomics before it.  Here: one 64-bit key (source << 32 | row)
+// per entry, written row by row (so equal sources keep ascending row order), ONE stable radix sort on the source bits with two
+// ping-pong buffers, the low halves are the reader lists and the run ends - max-scanned - the offsets.  Streaming traffic only:
+// 8 B written + 4 passes x 16 B + 12 B read back per entry.  Needs 16 bytes per entry of work memory; when the device cannot give
+// that (C5 on a full device) the caller falls back to the scatter form (same lists up to the order inside a list, which no kernel
+// depends on).
+static __global__ __launch_bounds__(256) void transpose_keys_kernel(const uint64_t *row_ptr, const uint32_t *src, uint64_t rows, uint64_t *keys)
+{
+    const uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    const uint64_t nq = (uint64_t)gridDim.x * 64; // quads in the grid
+    const int q = threadIdx.x & 3;
+    for (uint64_t row = t >> 2; row < rows; row += nq) {
+        const uint64_t b = row_ptr[row], e = row_ptr[row + 1];
+        for (uint64_t k = b + q; k < e; k += 4) keys[k] = ((uint64_t)src[k] << 32) | row;
+    }
+}
+static __global__ __launch_bounds__(256) void transpose_emit_kernel(const uint64_t *keys, uint64_t entries, uint32_t *out_rows, uint64_t *ends /* out_ptr + 1 */)
+{
+    for (uint64_t e = (uint64_t)blockIdx.x * 256 + threadIdx.x; e < entries; e += (uint64_t)gridDim.x * 256) {
+        const uint64_t k = keys[e];
+        out_rows[e] = (uint32_t)k;
+        const uint64_t s = k >> 32;
+        if (e + 1 == entries || (keys[e + 1] >> 32) != s) ends[s] = e + 1; // the last reader of s: its list ends here
+    }
+}
+std::string gpu_transpose_rows(void *stream_v, const uint64_t *d_row_ptr, const uint32_t *d_src, uint64_t rows_total, uint64_t entries, uint64_t *d_out_ptr,
+                               uint32_t *d_out_rows)
+{
+    hipStream_t stream = (hipStream_t)stream_v;
+    PL_HIP(hipMemsetAsync(d_out_ptr, 0, (rows_total + 1) * sizeof(uint64_t), stream));
+    if (!entries || !rows_total) {
+        PL_HIP(hipStreamSynchronize(stream));
+        return "";
+    }
+    struct Work {
+        uint64_t *a = nullptr, *b = nullptr;
+        void *tmp = nullptr;
+        ~Work()
+        {
+            if (a) (void)hipFree(a);
+            if (b) (void)hipFree(b);
+            if (tmp) (void)hipFree(tmp);
+        }
+    } w;
+    if (hipMalloc((void **)&w.a, entries * sizeof(uint64_t)) != hipSuccess || hipMalloc((void **)&w.b, entries * sizeof(uint64_t)) != hipSuccess) {
+        (void)hipGetLastError();
+        return "out of memory for the sort-based transposition";
+    }
+    hipLaunchKernelGGL(transpose_keys_kernel, dim3((unsigned)std::min<uint64_t>((rows_total * 4 + 255) / 256, 1u << 16)), dim3(256), 0, stream, d_row_ptr, d_src, rows_total, w.a);
+    PL_HIP(hipGetLastError());
+    const unsigned end_bit = 32 + (unsigned)bits_for(std::max<uint64_t>(rows_total, 2));
+    rocprim::double_buffer<uint64_t> keys(w.a, w.b);
+    size_t bytes = 0;
+    PL_HIP(rocprim::radix_sort_keys(nullptr, bytes, keys, (size_t)entries, 32u, end_bit, stream));
+    if (hipMalloc(&w.tmp, std::max<size_t>(bytes, 256)) != hipSuccess) {
+        (void)hipGetLastError();
+        return "out of memory for the sort-based transposition";
+    }
+    PL_HIP(rocprim::radix_sort_keys(w.tmp, bytes, keys, (size_t)entries, 32u, end_bit, stream));
+    hipLaunchKernelGGL(transpose_emit_kernel, dim3(grid_strided(entries)), dim3(256), 0, stream, (const uint64_t *)keys.current(), entries, d_out_rows, d_out_ptr + 1);
+    PL_HIP(hipGetLastError());
+    // out_ptr[s + 1] = end of the last non-empty list at or below s: an inclusive maximum scan of the ends (a source nobody reads keeps 0)
+    (void)hipFree(w.tmp);
+    w.tmp = nullptr;
+    bytes = 0;
+    PL_HIP(rocprim::inclusive_scan(nullptr, bytes, d_out_ptr + 1, d_out_ptr + 1, (size_t)rows_total, rocprim::maximum<uint64_t>(), stream));
+    if (hipMalloc(&w.tmp, std::max<size_t>(bytes, 256)) != hipSuccess) {
+        (void)hipGetLastError();
+        return "out of memory for the sort-based transposition";
+    }
+    PL_HIP(rocprim::inclusive_scan(w.tmp, bytes, d_out_ptr + 1, d_out_ptr + 1, (size_t)rows_total, rocprim::maximum<uint64_t>(), stream));
+    PL_HIP(hipStreamSynchronize(stream));
+    return "";
+}
+
 // ---- destination partition: keep the in-edges of the owned rows only (the device form of hb_host.cpp keep_owned_rows) -----
 static __global__ __launch_bounds__(256) void owned_counts_kernel(const uint64_t *row_ptr, uint64_t n, uint64_t world, uint64_t rank, uint32_t *cnt)
 {

@@ -87,19 +87,58 @@ __attribute__((target("sse4.2"))) uint32_t crc32c_update(uint32_t crc, const uin
     return ~(uint32_t)c;
 }
 
+// crc of A ++ B from crc(A), crc(B) and |B| - the zlib construction (crc(A) advanced over |B| zero bytes by repeated squaring of the
+// "one zero bit" operator over GF(2)) for the reflected Castagnoli polynomial; lets the fst writer take the CRC of a sub-trie that
+// another thread computed and account for it in the running file CRC without touching the bytes again
+uint32_t gf2_times32(const uint32_t *mat, uint32_t vec)
+{
+    uint32_t sum = 0;
+    for (; vec; vec >>= 1, mat++)
+        if (vec & 1) sum ^= *mat;
+    return sum;
+}
+void gf2_square32(uint32_t *sq, const uint32_t *mat)
+{
+    for (int k = 0; k < 32; k++) sq[k] = gf2_times32(mat, mat[k]);
+}
+uint32_t crc32c_combine(uint32_t crc1, uint32_t crc2, uint64_t len2)
+{
+    if (!len2) return crc1;
+    uint32_t even[32], odd[32];
+    odd[0] = 0x82F63B78u; // operator for one zero bit
+    for (int k = 1; k < 32; k++) odd[k] = 1u << (k - 1);
+    gf2_square32(even, odd); // two zero bits
+    gf2_square32(odd, even); // four
+    do {                     // first squaring below: one zero byte
+        gf2_square32(even, odd);
+        if (len2 & 1) crc1 = gf2_times32(even, crc1);
+        len2 >>= 1;
+        if (!len2) break;
+        gf2_square32(odd, even);
+        if (len2 & 1) crc1 = gf2_times32(odd, crc1);
+        len2 >>= 1;
+    } while (len2);
+    return crc1 ^ crc2;
+}
+
+bool pwrite_all(int fd, const uint8_t *p, size_t n, uint64_t off);
+
 // ---- byte sinks of the fst writer -----------------------------------------------------------------------------------
-// a file (stdio, buffered) with the running byte count and CRC
+// a file with the running byte count and CRC.  Small writes are buffered and go out with pwrite at their offset; a BLOCK whose CRC the
+// caller already has (a finished sub-trie, [r6]) is only booked - offset, pointer, length; running CRC by crc32c_combine - and written
+// by close() with all other blocks on all host cores: the sequential top of the parallel fst build no longer copies and checksums
+// 1.3 GB (C4) on one thread.  The blocks must stay alive until close().
 class FileSink {
 public:
     explicit FileSink(const std::string &path) : path_(path)
     {
-        f_ = std::fopen(path.c_str(), "wb");
-        if (!f_) failed_ = true;
+        fd_ = ::open(path.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0666);
+        if (fd_ < 0) failed_ = true;
         buf_.reserve(1 << 20);
     }
     ~FileSink()
     {
-        if (f_) std::fclose(f_);
+        if (fd_ >= 0) ::close(fd_);
     }
     bool ok() const { return !failed_; }
     const std::string &path() const { return path_; }
@@ -113,6 +152,15 @@ public:
         if (n > (1u << 20)) raw(p, n);
         else buf_.insert(buf_.end(), p, p + n);
     }
+    void write_block(const bytes &b, uint32_t crc_of_b)
+    {
+        if (b.empty()) return;
+        flush();
+        blocks_.push_back(Block{count_, b.data(), b.size()});
+        crc_ = crc32c_combine(crc_, crc_of_b, b.size());
+        count_ += b.size();
+        pos_ = count_;
+    }
     void u8(uint8_t v) { write(&v, 1); }
     void le(uint64_t v, int nbytes)
     {
@@ -123,19 +171,35 @@ public:
     bool close()
     {
         flush();
-        if (f_ && std::fclose(f_) != 0) failed_ = true;
-        f_ = nullptr;
+        if (fd_ >= 0 && !blocks_.empty()) {
+            std::atomic<bool> ok{true};
+            const int fd = fd_;
+            const std::vector<Block> &bl = blocks_;
+#pragma omp parallel for num_threads(hb::host_threads()) schedule(dynamic, 64)
+            for (size_t k = 0; k < bl.size(); k++)
+                if (!pwrite_all(fd, bl[k].p, bl[k].n, bl[k].off)) ok = false;
+            if (!ok) failed_ = true;
+            blocks_.clear();
+        }
+        if (fd_ >= 0 && ::close(fd_) != 0) failed_ = true;
+        fd_ = -1;
         return !failed_;
     }
 
 private:
+    struct Block {
+        uint64_t off;
+        const uint8_t *p;
+        size_t n;
+    };
     void raw(const uint8_t *p, size_t n)
     {
-        if (!f_) {
+        if (fd_ < 0) {
             failed_ = true;
             return;
         }
-        if (n && std::fwrite(p, 1, n, f_) != n) failed_ = true;
+        if (n && !pwrite_all(fd_, p, n, pos_)) failed_ = true;
+        pos_ += n;
     }
     void flush()
     {
@@ -143,9 +207,11 @@ private:
         buf_.clear();
     }
     std::string path_;
-    std::FILE *f_ = nullptr;
+    int fd_ = -1;
     bytes buf_;
-    uint64_t count_ = 0;
+    std::vector<Block> blocks_;
+    uint64_t count_ = 0; // bytes accepted so far = file offset of the next byte
+    uint64_t pos_ = 0;   // file offset of the first byte still in buf_
     uint32_t crc_ = 0;
     bool failed_ = false;
 };
@@ -159,6 +225,7 @@ public:
     bytes data;
     uint64_t count() const { return kSubBase + data.size(); }
     void write(const uint8_t *p, size_t n) { data.insert(data.end(), p, p + n); }
+    void write_block(const bytes &b, uint32_t) { write(b.data(), b.size()); }
     void u8(uint8_t v) { data.push_back(v); }
     void le(uint64_t v, int nbytes)
     {
@@ -223,7 +290,7 @@ public:
     // A compiled sub-trie (`sub`, built by FstWriter<MemSink> over the key suffixes behind `prefix`, values relative to
     // `value`, `keys` keys, root at virtual address `sub_root`) hangs below the path `prefix`: exactly what insert() of its
     // keys one by one would have produced.  prefix must be > every key inserted so far and no prefix of one.
-    bool insert_subtrie(const uint8_t *prefix, size_t plen, uint64_t value, const bytes &sub, uint64_t sub_root, uint64_t keys,
+    bool insert_subtrie(const uint8_t *prefix, size_t plen, uint64_t value, const bytes &sub, uint32_t sub_crc, uint64_t sub_root, uint64_t keys,
                         const uint8_t *last_key, size_t last_len)
     {
         if (!plen || !keys) return false;
@@ -246,7 +313,7 @@ public:
         }
         // the node behind the prefix is the sub-trie's root: its bytes go out now, the last unfinished node points at it
         const uint64_t base = w_.count();
-        w_.write(sub.data(), sub.size());
+        w_.write_block(sub, sub_crc); // (a file sink books it and writes it at close(): `sub` must stay alive until then)
         const uint64_t addr = base - kSubBase + sub_root;
         Unfinished &parent = stack_[depth_ - 1];
         parent.node.trans.push_back(Trans{parent.last_inp, parent.last_out, addr});
@@ -601,6 +668,7 @@ bool fst_parallel(const EntryVec &e, const std::string &path, std::string *why)
         bytes sub;
         uint64_t root = 0;
         bool ok = true;
+        uint32_t crc = 0; // CRC-32C of `sub`, computed by the thread that built it
     };
     std::vector<Group> groups;
     for (size_t i = 0; i < n;) {
@@ -611,7 +679,7 @@ bool fst_parallel(const EntryVec &e, const std::string &path, std::string *why)
         const uint64_t pre = e[i].k0 >> 40;
         size_t j = i + 1;
         while (j < n && e[j].key_len() >= 4 && (e[j].k0 >> 40) == pre) j++;
-        groups.push_back(Group{i, j, {}, 0, true});
+        groups.push_back(Group{i, j, {}, 0, true, 0});
         i = j;
     }
 #pragma omp parallel for num_threads(hb::host_threads()) schedule(dynamic, 1)
@@ -627,6 +695,8 @@ bool fst_parallel(const EntryVec &e, const std::string &path, std::string *why)
         }
         if (G.ok) G.root = sub.finish_sub();
         G.sub.swap(mem.data);
+        G.sub.shrink_to_fit();
+        G.crc = crc32c_update(0, G.sub.data(), G.sub.size());
     }
     FileSink out(path);
     if (!out.ok()) {
@@ -641,12 +711,11 @@ bool fst_parallel(const EntryVec &e, const std::string &path, std::string *why)
             Group &G = groups[g++];
             e[i].key_bytes(key);
             e[G.hi - 1].key_bytes(last);
-            if (!G.ok || !top.insert_subtrie(key, 3, i, G.sub, G.root, G.hi - G.lo, last, (size_t)e[G.hi - 1].key_len())) {
+            if (!G.ok || !top.insert_subtrie(key, 3, i, G.sub, G.crc, G.root, G.hi - G.lo, last, (size_t)e[G.hi - 1].key_len())) {
                 *why = "keys not strictly ascending";
                 return false;
             }
-            bytes().swap(G.sub);
-            i = G.hi;
+            i = G.hi; // (G.sub stays until out.close() has written it)
         } else {
             e[i].key_bytes(key);
             if (!top.insert(key, (size_t)e[i].key_len(), i)) {

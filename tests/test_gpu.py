@@ -244,6 +244,10 @@ for _base in ("default", "chunk4_multilevel", "sparse_always_multilevel", "front
               "long_tail_default", "staged_results_every_pass", "no_xcd_map"):
     VARIANTS[_base + "_lean"] = VARIANTS[_base]
 VARIANTS["full_init_switch"] = dict(tune=(0, 0x800000))  # hb_begin always writes the whole initial state (the pre-round-6 form)
+# round 6: the transposed work-row graph (the sweep passes' reader lists) is built by ONE stable radix sort (hb_plan.hip gpu_transpose_rows);
+# bit 25 = the atomic-scatter form it replaced, which remains the out-of-memory fallback: same passes, same bits either way
+VARIANTS["sweep_transpose_by_scatter"] = dict(chunk=8, tune=(0, 0x2000000, 101, 0, 0, 0, 1))
+VARIANTS["long_tail_transpose_by_scatter"] = dict(tune=(0, 0x2000000))
 
 
 @pytest.mark.parametrize("variant", sorted(VARIANTS))
@@ -956,6 +960,59 @@ def test_logical_ranks_on_one_device(gpu_ctx_factory, world, mode):
     finally:
         for c in ctxs:
             c.close()
+
+
+def test_packed_exchange_is_six_bits_per_register(gpu_ctx_factory):
+    """[r6] The destination partition's changed-only exchange ships a counter as 48 bytes: 6 bits per register (hb_aux.hip.h
+    pack6_quarter - exact, because a register of this path is 0, 1..58 or 65: hyperloglog.rs:4385-4396 shifts the hash left by six
+    before counting leading zeros).  Two logical ranks, a graph that contains the one register value above 58 (NodeIDs whose low 64
+    bits are 0 hash to 0: p = 65, code 63) spread by the merges: same registers after every pass and same final list as the oracle,
+    and exactly 3/4 of the counter bytes of the 64-byte form (experiments build, tune[1] bit 24) on the wire."""
+    g = synth.RmatGraph(11, 14_000)
+    lcg = graphs.lcg_graph(n=300, m=2400, seed=7)
+    zero_lo = [0, 1 << 64, 5 << 64]  # three ids with low 64 bits 0: their counters start with a register of 65
+    ids, row_ptr, src = graphs.dense_from_tuples([(zero_lo[f % 3] if f % 50 == 0 else f + (f << 70), zero_lo[t % 3] if t % 50 == 0 else t + (t << 70)) for f, t in lcg])
+    o, T, vals, keep, k = _oracle_dense(ids, row_ptr, src)
+    assert int(o.registers().max()) == 65 and not np.isin(o.registers(), np.arange(59, 65)).any()
+    world = 2
+    n_pad_slices = None
+    wires = {}
+    for name, tune in (("six_bit", ()), ("bytes", (0, 0x1000000))):
+        ctxs = []
+        try:
+            for r in range(world):
+                c = gpu_ctx_factory(rank=r, world_size=world, flags=_lib.HB_FLAG_NO_RCCL | _lib.HB_FLAG_DEST_PARTITION | _lib.HB_FLAG_CHANGED_ONLY, tune=tune)
+                rp, sr = dist.partition_dense_by_dest(row_ptr, src, r, world)
+                c.load_dense(ids, rp, sr)
+                c.begin()
+                ctxs.append(c)
+            has, t = True, 0
+            while has:
+                for c in ctxs:
+                    c.step_local()
+                _lib.Context.exchange(ctxs, 0)
+                has = [c.step_finish() for c in ctxs][0]
+                for c in ctxs:
+                    assert np.array_equal(c.registers(), ctxs[0].registers())
+                t += 1
+            assert t == T and np.array_equal(ctxs[0].registers(), o.registers())
+            _lib.Context.exchange(ctxs, 1)
+            for c in ctxs:
+                c.finish()
+                _check_final(c, ids, T, vals, keep, c.stats())
+            wires[name] = [int(c.stats()["wire_bytes"]) for c in ctxs]
+            n_pad_slices = [int(c.stats()["work_rows"]) for c in ctxs]
+        finally:
+            for c in ctxs:
+                c.close()
+    # per rank: wire = T x (bitmap bytes of the foreign slices) + bytes per row x (foreign changed rows over the run)
+    for r in range(world):
+        rows64 = wires["bytes"][r]
+        rows48 = wires["six_bit"][r]
+        assert rows48 < rows64
+        # the bitmap part is the same in both runs: (rows64 - B) * 3 == (rows48 - B) * 4  =>  B = 4 rows48 - 3 rows64
+        b = 4 * rows48 - 3 * rows64
+        assert b >= 0 and (rows64 - b) % 64 == 0 and (rows48 - b) % 48 == 0 and (rows64 - b) // 64 == (rows48 - b) // 48, (rows48, rows64, b)
 
 
 def test_dest_partition_ignores_foreign_records(gpu_ctx_factory):
