@@ -61,6 +61,7 @@ struct hb_ctx {
     uint64_t *d_row_ptr = nullptr;
     uint32_t *d_src = nullptr;
     uint16_t *d_src_jp = nullptr; // parallel to d_src: the sources' initial register (pass 0 streams it, hb_kernels.hip.h)
+    uint32_t *d_virt_rows = nullptr; // one bit per work row: its sources are virtual rows (pass 0, PassParams::virt_rows)
     uint16_t *d_self_jp = nullptr; // per node row: its OWN initial register in the same format (the lean pass 0 reads it instead of the counters)
     uint4 *d_regs[2] = {nullptr, nullptr};
     uint4 *d_part = nullptr;
@@ -238,6 +239,7 @@ void free_graph_buffers(hb_ctx *c)
     c->d_src = nullptr;
     c->d_src_jp = nullptr;
     c->d_self_jp = nullptr;
+    c->d_virt_rows = nullptr;
     c->d_regs[0] = c->d_regs[1] = nullptr;
     c->d_part = nullptr;
     c->d_bits[0] = c->d_bits[1] = nullptr;

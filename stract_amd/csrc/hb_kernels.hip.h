@@ -107,6 +107,11 @@ struct PassParams {
     // itself: a row pass 0 leaves unchanged is stored there too, so that the lazy double buffer's invariant (the other buffer holds the
     // row's value unless it changed in this or the previous pass) holds for pass 1 in every pass mode.  NULL = the state is in memory.
     uint4 *rd_init;
+    // [r6] pass 0 (INIT): one bit per WORK row, set = the row's sources are virtual rows.  The streaming form of pass 0 never looks at a
+    // source id, and finding out a row's kind by loading its first one (`src[beg]`, as every other launch does - they read the list anyway)
+    // pulled the whole index array through the memory system once more: 6.7 GB next to the 3.3 GB of src_jp the level-1 launch streams at
+    // C4.  Written once at load (virt_rows_kernel).  NULL = read src[beg].
+    const uint32_t *virt_rows;
     const uint16_t *self_jp;  // per device row: register index | value << 8 of the node's OWN initial counter (0 = padding row), written at
                               // load time with the same arithmetic as src_jp (lean pass 0)
 };
@@ -230,7 +235,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((REAL && UN
     };
     uint64_t nbeg = 0, nend = 0;
     uint32_t nod = 0;
+    uint32_t nvirt = 0; // (INIT) the row's sources are virtual rows (PassParams::virt_rows)
     uint4 nself = make_uint4(0, 0, 0, 0);
+    const bool by_bitmap = INIT && p.virt_rows != nullptr;             // kernel-uniform
     const bool lean = INIT && REAL && FUSED && p.rd_init != nullptr; // kernel-uniform (PassParams::rd_init)
     auto own_counter = [&](uint64_t r) -> uint4 { // the row's counter before this pass
         if (INIT && REAL && FUSED && lean) return counter_quarter_of_jp((uint32_t)p.self_jp[r], q);
@@ -243,6 +250,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((REAL && UN
             nend = p.row_ptr[r0 + 1];
             if (REAL && FUSED) nod = p.outdeg[r0];
             if (kDenseReal) nself = own_counter(r0);
+            if (INIT && by_bitmap) nvirt = (p.virt_rows[r0 >> 5] >> (r0 & 31u)) & 1u;
         }
     }
     for (uint64_t tile = tile0; tile < ntiles; tile += tstride) {
@@ -251,17 +259,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((REAL && UN
         const bool valid = row < row_hi;
         const uint64_t beg = nbeg, end = nend;
         const uint32_t od = nod; // out-degree of the row's node, used in the epilogue
+        const uint32_t virt = nvirt;
         uint4 selfv = nself;
         {   // requests for the next tile of this workgroup
             const uint64_t nrow = row + (tstride << 6);
             nbeg = nend = 0;
             nod = 0;
+            nvirt = 0;
             nself = make_uint4(0, 0, 0, 0);
             if (tile + tstride < ntiles && nrow < row_hi) {
                 nbeg = p.row_ptr[nrow];
                 nend = p.row_ptr[nrow + 1];
                 if (REAL && FUSED) nod = p.outdeg[nrow];
                 if (kDenseReal) nself = own_counter(nrow);
+                if (INIT && by_bitmap) nvirt = (p.virt_rows[nrow >> 5] >> (nrow & 31u)) & 1u;
             }
         }
         // dense fused node rows: 4 of 5 rows change, so the estimator/Kahan words are requested now, unconditionally
@@ -295,9 +306,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((REAL && UN
         if (kDenseReal && valid) acc_merge(acc, selfv);
         if (beg < end) {
             // all sources of one row are of one kind: real nodes (read rd) or virtual rows (read part)
-            const uint32_t first = p.src[beg];
-            const uint4 *base = (first >= p.n_pad) ? (const uint4 *)(p.part - p.n_pad * 4) : p.rd;
-            const bool real_src = first < p.n_pad;
+            uint32_t first;
+            bool real_src;
+            if (INIT && by_bitmap) { // pass 0: a row that streams its sources never touches the index array (PassParams::virt_rows)
+                real_src = !virt;
+                first = real_src ? 0u : p.src[beg];
+                HB_DBG_ASSERT(real_src == (p.src[beg] < p.n_pad));
+            } else {
+                first = p.src[beg];
+                real_src = first < p.n_pad;
+            }
+            const uint4 *base = real_src ? p.rd : (const uint4 *)(p.part - p.n_pad * 4);
             for (uint64_t e = beg; e < end; e += 4 * UNROLL) {
                 uint32_t idx[UNROLL];
                 if (INIT && real_src) {
@@ -804,6 +823,24 @@ __global__ __launch_bounds__(256) void src_jp_kernel(const uint32_t *src, uint64
     for (uint64_t e = (uint64_t)blockIdx.x * 256 + threadIdx.x; e < len; e += (uint64_t)gridDim.x * 256) {
         const uint32_t s = src[e];
         jp[e] = s < n_pad ? self_jp[s] : (uint16_t)0;
+    }
+}
+// virt_rows (PassParams): bit r = work row r reads virtual rows; one lane per row, a wave writes the 64 bits of its rows
+__global__ __launch_bounds__(256) void virt_rows_kernel(const uint64_t *row_ptr, const uint32_t *src, uint64_t rows_total, uint64_t n_pad, uint32_t *bits)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * 256;
+    for (uint64_t r0 = (uint64_t)blockIdx.x * 256; r0 < rows_total; r0 += stride) { // wave-uniform trip count
+        const uint64_t r = r0 + threadIdx.x;
+        bool v = false;
+        if (r < rows_total) {
+            const uint64_t b = row_ptr[r], e = row_ptr[r + 1];
+            v = b < e && src[b] >= n_pad;
+        }
+        const uint64_t m = __ballot(v);
+        if ((threadIdx.x & 63) == 0 && r < rows_total) {
+            bits[(r >> 5)] = (uint32_t)m;
+            bits[(r >> 5) + 1] = (uint32_t)(m >> 32);
+        }
     }
 }
 // self_jp[row]: the same entry for every node row's OWN initial counter (padding rows: 0); read by the lean pass 0 (PassParams::rd_init)
