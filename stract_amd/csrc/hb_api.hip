@@ -61,6 +61,7 @@ struct hb_ctx {
     uint64_t *d_row_ptr = nullptr;
     uint32_t *d_src = nullptr;
     uint16_t *d_src_jp = nullptr; // parallel to d_src: the sources' initial register (pass 0 streams it, hb_kernels.hip.h)
+    bool level0_all_real = false;    // no row of the first hub-chunk level reads virtual rows (checked at load): pass 0 may run init_level1_kernel there
     uint32_t *d_virt_rows = nullptr; // one bit per work row: its sources are virtual rows (pass 0, PassParams::virt_rows)
     uint16_t *d_self_jp = nullptr; // per node row: its OWN initial register in the same format (the lean pass 0 reads it instead of the counters)
     uint4 *d_regs[2] = {nullptr, nullptr};
@@ -240,6 +241,7 @@ void free_graph_buffers(hb_ctx *c)
     c->d_src_jp = nullptr;
     c->d_self_jp = nullptr;
     c->d_virt_rows = nullptr;
+    c->level0_all_real = false;
     c->d_regs[0] = c->d_regs[1] = nullptr;
     c->d_part = nullptr;
     c->d_bits[0] = c->d_bits[1] = nullptr;
@@ -724,6 +726,7 @@ int hb_load_edges(hb_ctx *c, const hb_u128 *node_ids, uint64_t n, const hb_edge 
         if ((rc = keep_owned(c, &csr))) {
             if (csr.d_row_ptr) (void)hipFree(csr.d_row_ptr);
             if (csr.d_src) (void)hipFree(csr.d_src);
+            if (csr.d_id_lo) (void)hipFree(csr.d_id_lo);
             return rc;
         }
         const uint64_t nn = c->g.ids.size();
@@ -733,6 +736,7 @@ int hb_load_edges(hb_ctx *c, const hb_u128 *node_ids, uint64_t n, const hb_edge 
         rc = plan_and_upload(c, csr.d_row_ptr ? &csr : nullptr, m_eff);
         if (csr.d_row_ptr) (void)hipFree(csr.d_row_ptr); // only if plan_and_upload bailed out before taking them
         if (csr.d_src) (void)hipFree(csr.d_src);
+            if (csr.d_id_lo) (void)hipFree(csr.d_id_lo);
         c->stats.ms_ingest = ing;
         c->stats.ingest_peak_bytes = peak;
         return rc;
@@ -794,6 +798,7 @@ int hb_finalize(hb_ctx *c, const hb_u128 *node_ids, uint64_t n)
         if ((rc = keep_owned(c, &csr))) {
             if (csr.d_row_ptr) (void)hipFree(csr.d_row_ptr);
             if (csr.d_src) (void)hipFree(csr.d_src);
+            if (csr.d_id_lo) (void)hipFree(csr.d_id_lo);
             return rc;
         }
         const uint64_t nn = c->g.ids.size();
@@ -802,6 +807,7 @@ int hb_finalize(hb_ctx *c, const hb_u128 *node_ids, uint64_t n)
         rc = plan_and_upload(c, csr.d_row_ptr ? &csr : nullptr, m_eff);
         if (csr.d_row_ptr) (void)hipFree(csr.d_row_ptr);
         if (csr.d_src) (void)hipFree(csr.d_src);
+            if (csr.d_id_lo) (void)hipFree(csr.d_id_lo);
         c->stats.ms_ingest = ing;
         c->stats.ingest_peak_bytes = peak;
         if (trace) std::fprintf(stderr, "[hb finalize] done after %.1f ms (plan %.1f ms, state %.1f ms)\n", now_ms() - t0, c->stats.ms_plan, c->stats.ms_h2d);
@@ -987,6 +993,7 @@ int hb_load_dense(hb_ctx *c, const hb_u128 *sorted_ids, uint64_t n, const uint64
             if (he != hipSuccess) {
                 (void)hipFree(csr.d_row_ptr);
                 if (csr.d_src) (void)hipFree(csr.d_src);
+            if (csr.d_id_lo) (void)hipFree(csr.d_id_lo);
                 return fail(c, he == hipErrorOutOfMemory ? HB_ERR_NOMEM : HB_ERR_HIP, std::string("uploading the graph: ") + hipGetErrorString(he));
             }
             csr.m = m_eff;
@@ -994,6 +1001,7 @@ int hb_load_dense(hb_ctx *c, const hb_u128 *sorted_ids, uint64_t n, const uint64
         if ((rc = keep_owned(c, &csr))) {
             if (csr.d_row_ptr) (void)hipFree(csr.d_row_ptr);
             if (csr.d_src) (void)hipFree(csr.d_src);
+            if (csr.d_id_lo) (void)hipFree(csr.d_id_lo);
             return rc;
         }
         const uint64_t m_local = csr.d_row_ptr ? csr.m : ((dest_mode(c) && n) ? c->g.row_ptr[n] : m_eff);
@@ -1001,6 +1009,7 @@ int hb_load_dense(hb_ctx *c, const hb_u128 *sorted_ids, uint64_t n, const uint64
         rc = plan_and_upload(c, csr.d_row_ptr ? &csr : nullptr, m_local);
         if (csr.d_row_ptr) (void)hipFree(csr.d_row_ptr);
         if (csr.d_src) (void)hipFree(csr.d_src);
+            if (csr.d_id_lo) (void)hipFree(csr.d_id_lo);
         c->stats.ms_ingest = ing;
         return rc;
     });

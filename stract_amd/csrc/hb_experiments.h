@@ -21,6 +21,9 @@
 //     bit 23  0x800000  hb_begin always writes the whole initial state (round 6 A/B: the lean pass 0 off)
 //     bit 24  0x1000000 destination partition, changed-only: 64-byte counters on the wire instead of the 6-bit packing (round 6 A/B)
 //     bit 25  0x2000000 the transposed work-row graph by atomic scatter (the form before round 6; today only the out-of-memory fallback)
+//     bit 26  0x4000000 sweep passes: a touched row's sources 8 per round (index / bit word / gather each a round trip) instead of all at once
+//     bit 27  0x8000000 pass 0: the first hub-chunk level through the generic INIT kernel instead of init_level1_kernel (A/B)
+//     bit 28  0x10000000 TIMING PROBE, WRONG RESULTS: the dense fused node rows neither read nor write size[] (16 B per row less state traffic)
 //   hb_options.tune[7]  hottest counters staged in LDS by the level-1 dense launch (0 = off, <= 2048; measured slower, round 2)
 #pragma once
 #include <stdint.h>

@@ -780,6 +780,12 @@ void host_scatter_f64(double *out, const uint32_t *idx, const double *val, uint6
     for (int64_t k = 0; k < (int64_t)n; k++) out[idx[k]] = val[k];
 }
 
+void host_gather_id_lo(const hb_u128 *ids, uint64_t n, uint64_t *lo)
+{
+#pragma omp parallel for num_threads(n >= (1u << 18) ? std::min(host_threads(), 16) : 1) schedule(static)
+    for (int64_t s = 0; s < (int64_t)n; s++) lo[s] = ids[s].lo;
+}
+
 void host_compact_results(const double *src, const hb_u128 *idsrc, uint64_t n, hb_u128 *ids, double *vals, uint64_t cap)
 {
     const int want = n >= (1u << 18) ? std::min(host_threads(), 16) : 1;

@@ -144,7 +144,7 @@ __global__ __launch_bounds__(256) void ids_to_keys_kernel(const hb_u128 *ids, ui
     HB_GRID_STRIDE(i, n) keys[i] = make_key(ids[i]);
 }
 
-__global__ __launch_bounds__(256) void keys_to_ids_kernel(const u128 *keys, uint64_t n, hb_u128 *ids)
+__global__ __launch_bounds__(256) void keys_to_ids_kernel(const u128 *keys, uint64_t n, hb_u128 *ids, uint64_t *lo_out)
 {
     HB_GRID_STRIDE(i, n)
     {
@@ -152,6 +152,7 @@ __global__ __launch_bounds__(256) void keys_to_ids_kernel(const u128 *keys, uint
         v.lo = (uint64_t)keys[i];
         v.hi = (uint64_t)(keys[i] >> 64);
         ids[i] = v;
+        if (lo_out) lo_out[i] = v.lo;
     }
 }
 
@@ -782,10 +783,12 @@ std::string gpu_ingest_reduce(void *stream_v, const hb_u128 *node_ids, uint64_t 
     } catch (const std::bad_alloc &) {
         return "out of host memory for the node set";
     }
+    uint64_t *d_id_lo = nullptr; // (keep) handed to the caller with the CSR
     if (n) {
         hb_u128 *d_out_ids = nullptr;
         IG_HIP(mem.alloc(&d_out_ids, n));
-        hipLaunchKernelGGL(keys_to_ids_kernel, dim3(grid_for(n)), dim3(256), 0, stream, (const u128 *)d_ids, n, d_out_ids);
+        if (keep) IG_HIP(mem.alloc(&d_id_lo, n));
+        hipLaunchKernelGGL(keys_to_ids_kernel, dim3(grid_for(n)), dim3(256), 0, stream, (const u128 *)d_ids, n, d_out_ids, d_id_lo);
         IG_HIP(hipGetLastError());
         IG_HIP(hipMemcpyAsync(out->ids.data(), d_out_ids, n * sizeof(hb_u128), hipMemcpyDeviceToHost, stream));
         IG_HIP(hipStreamSynchronize(stream));
@@ -913,6 +916,10 @@ std::string gpu_ingest_reduce(void *stream_v, const hb_u128 *node_ids, uint64_t 
         keep->d_row_ptr = d_row_ptr;
         keep->d_src = d_src;
         keep->m = m_eff;
+        if (d_id_lo) {
+            mem.disown(d_id_lo);
+            keep->d_id_lo = d_id_lo;
+        }
     }
     return "";
 }

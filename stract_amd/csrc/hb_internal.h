@@ -239,6 +239,8 @@ struct DeviceCsr {
     uint64_t *d_row_ptr = nullptr; // n + 1
     uint32_t *d_src = nullptr;     // m
     uint64_t m = 0;
+    uint64_t *d_id_lo = nullptr;   // n, optional: the low 64 bits of every NodeID in ascending-id order (the device ingest has them: the
+                                   // state stage hashes them on the device instead of collecting 8 of every 16 host bytes and uploading them)
 };
 // Device buffers of a finished plan (hipMalloc'ed; the caller owns them).
 struct DevicePlan {
@@ -272,6 +274,8 @@ double now_ms();
 // took 419 ms at C4 against 4.7 ms steady, hb_result_copy 2.1 s (profiles/r06c_bench_default.err).
 //   out[idx[k]] = val[k] for k < n; every idx occurs at most once
 void host_scatter_f64(double *out, const uint32_t *idx, const double *val, uint64_t n);
+// lo[s] = ids[s].lo (the half of a NodeID HyperLogLog::add_u128 hashes), on the OpenMP team
+void host_gather_id_lo(const hb_u128 *ids, uint64_t n, uint64_t *lo);
 //   the (id, value) pairs with src[sid] >= 0.0 in ascending sid order, at most cap of them; ids / vals may be NULL
 void host_compact_results(const double *src, const hb_u128 *idsrc, uint64_t n, hb_u128 *ids, double *vals, uint64_t cap);
 

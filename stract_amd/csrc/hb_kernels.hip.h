@@ -112,6 +112,8 @@ struct PassParams {
     // pulled the whole index array through the memory system once more: 6.7 GB next to the 3.3 GB of src_jp the level-1 launch streams at
     // C4.  Written once at load (virt_rows_kernel).  NULL = read src[beg].
     const uint32_t *virt_rows;
+    uint32_t xflags;          // experiments build only (0 in the product): bit 0 = the dense fused node rows neither read nor write size[] -
+                              // WRONG RESULTS, a timing probe: what a node-row state diet of 16 B per row could buy at most
     const uint16_t *self_jp;  // per device row: register index | value << 8 of the node's OWN initial counter (0 = padding row), written at
                               // load time with the same arithmetic as src_jp (lean pass 0)
 };
@@ -220,6 +222,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((REAL && UN
                 p.ksum[p_row] = ks;
                 p.kerr[p_row] = ke;
             }
+#ifdef HB_EXPERIMENTS
+            if (!(p.xflags & 1u))
+#endif
             if ((p_flags & 2u) || p_lean) p.size[p_row] = sz_new;
         }
         const uint64_t bal = __ballot(err_nz); // bit 4g + k = row g of pending tile k
@@ -286,6 +291,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((REAL && UN
                 pre_sz = real_row ? (uint64_t)s_lc[63] : 0ull;
             } else if (kEpi4) {
                 if (q == npend) { // this lane owns the row's deferred epilogue
+#ifdef HB_EXPERIMENTS
+                    if (!(p.xflags & 1u))
+#endif
                     pre_sz = p.size[row];
                     pre_ks = p.ksum[row];
                     pre_ke = p.kerr[row];
@@ -825,8 +833,88 @@ __global__ __launch_bounds__(256) void src_jp_kernel(const uint32_t *src, uint64
         jp[e] = s < n_pad ? self_jp[s] : (uint16_t)0;
     }
 }
+// ---- pass 0, first level of hub chunks [r6] ------------------------------------------------------------------------------------------
+// Every source of such a row is a real node whose counter still holds ONE register (harmonic.rs:60-62): the row streams its 2-byte
+// src_jp entries, max-accumulates them in its scratch counter in LDS and writes the partial - what pass_kernel<false, .., INIT> does for
+// these rows, as a kernel of its own: the generic kernel carries the gather path of the upper levels (16 uint4 in flight per lane: 92
+// VGPRs, 5 waves per SIMD) through a launch that never gathers, and this launch answers to occupancy (a deeper per-wave pipeline was
+// measured slower, profiles/r06g_*REJECTED*).  A quad takes all (<= 64) entries of its row at once, 16 per lane, quarters no row of the
+// wave reaches are skipped wave-uniformly.  Same maxima, same bits (the per-pass parity variants run it: it is the default).
+__global__ __launch_bounds__(256) void init_level1_kernel(const PassParams p)
+{
+    __shared__ uint4 s_cnt4[4 * 16 * 16]; // per wave 16 scratch counters of 64 x u32, register r of row g at word (r + 4 g) & 63 (pass_kernel's layout)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int g = lane >> 2, q = lane & 3;
+    uint32_t *cnt_row = (uint32_t *)s_cnt4 + (wave * 16 + g) * 64;
+#pragma unroll
+    for (int k = 0; k < 4; k++) s_cnt4[(wave * 16 + g) * 16 + ((4 * q + k + g) & 15)] = make_uint4(0, 0, 0, 0);
+    const uint64_t ntiles = (p.row_hi - p.row_lo + 63) >> 6;
+    constexpr int W = 16;
+    uint64_t nbeg = 0, nend = 0;
+    {
+        const uint64_t r0 = p.row_lo + ((uint64_t)blockIdx.x << 6) + ((uint64_t)wave << 4) + (uint64_t)g;
+        if (blockIdx.x < ntiles && r0 < p.row_hi) {
+            nbeg = p.row_ptr[r0];
+            nend = p.row_ptr[r0 + 1];
+        }
+    }
+    for (uint64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const uint64_t row = p.row_lo + (tile << 6) + ((uint64_t)wave << 4) + (uint64_t)g;
+        const bool valid = row < p.row_hi;
+        const uint64_t beg = nbeg, end = nend;
+        {
+            const uint64_t nrow = row + ((uint64_t)gridDim.x << 6);
+            nbeg = nend = 0;
+            if (tile + gridDim.x < ntiles && nrow < p.row_hi) {
+                nbeg = p.row_ptr[nrow];
+                nend = p.row_ptr[nrow + 1];
+            }
+        }
+        for (uint64_t e0 = beg; __ballot(e0 < end) != 0; e0 += 4 * W) { // (one iteration unless hb_options.chunk > 64)
+            const uint64_t span = e0 < end ? end - e0 : 0;
+            uint32_t jp[W];
+#pragma unroll
+            for (int b = 0; b < W / 4; b++) {
+                if (__ballot(span > (uint64_t)(16 * b))) { // wave-uniform: some row of the wave reaches this quarter
+#pragma unroll
+                    for (int j = 4 * b; j < 4 * b + 4; j++) {
+                        const uint64_t ee = e0 + 4 * j + q;
+                        jp[j] = (ee < end && e0 < end) ? (uint32_t)p.src_jp[ee] : 0u; // value 0 = nothing to merge
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 4 * b; j < 4 * b + 4; j++) jp[j] = 0u;
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < W; j++) {
+                const uint32_t v = jp[j];
+                if (v >> 8) __hip_atomic_fetch_max(&cnt_row[((v & 63u) + 4u * (uint32_t)g) & 63u], v >> 8, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+        }
+        // the rows' scratch counters -> register blocks (lane q: registers 16 q .. 16 q + 15), scratch cleared for the next tile
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        uint32_t wv[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            uint4 *cell = &s_cnt4[(wave * 16 + g) * 16 + ((4 * q + k + g) & 15)]; // registers 16 q + 4 k .. + 3
+            const uint4 c = *cell;
+            *cell = make_uint4(0, 0, 0, 0);
+            wv[k] = c.x | (c.y << 8) | (c.z << 16) | (c.w << 24);
+        }
+        if (valid) p.part[(row - p.n_pad) * 4 + q] = make_uint4(wv[0], wv[1], wv[2], wv[3]);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 // virt_rows (PassParams): bit r = work row r reads virtual rows; one lane per row, a wave writes the 64 bits of its rows
-__global__ __launch_bounds__(256) void virt_rows_kernel(const uint64_t *row_ptr, const uint32_t *src, uint64_t rows_total, uint64_t n_pad, uint32_t *bits)
+// *l0_virtual += the rows of [l0_lo, l0_hi) - the first level of hub chunks - that read virtual rows (none, by construction of both planners:
+// init_level1_kernel, which streams every source of such a row, is only used when the count is 0)
+__global__ __launch_bounds__(256) void virt_rows_kernel(const uint64_t *row_ptr, const uint32_t *src, uint64_t rows_total, uint64_t n_pad, uint32_t *bits,
+                                                        uint64_t l0_lo, uint64_t l0_hi, unsigned long long *l0_virtual)
 {
     const uint64_t stride = (uint64_t)gridDim.x * 256;
     for (uint64_t r0 = (uint64_t)blockIdx.x * 256; r0 < rows_total; r0 += stride) { // wave-uniform trip count
@@ -837,6 +925,8 @@ __global__ __launch_bounds__(256) void virt_rows_kernel(const uint64_t *row_ptr,
             v = b < e && src[b] >= n_pad;
         }
         const uint64_t m = __ballot(v);
+        const uint64_t m0 = __ballot(v && r >= l0_lo && r < l0_hi);
+        if (m0 && (threadIdx.x & 63) == 0) atomicAdd(l0_virtual, (unsigned long long)__popcll(m0));
         if ((threadIdx.x & 63) == 0 && r < rows_total) {
             bits[(r >> 5)] = (uint32_t)m;
             bits[(r >> 5) + 1] = (uint32_t)(m >> 32);

@@ -212,7 +212,7 @@ __global__ __launch_bounds__(256) void sweep_expand_heavy_kernel(const SweepPara
 // order keeps together), and contiguous 2048-row slabs gave a few waves all the work.  The wave OWNS the rows of
 // its words for the whole pass, so their changed / Kahan-dirty words are assembled in LDS and stored once - no
 // global atomics and no clearing of those bitmaps (every word of the range is rewritten).
-template <bool REAL>
+template <bool REAL, bool SLOW = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void sweep_rows_kernel(const SweepParams sp)
 {
     __shared__ double s_raw[REAL ? kTableLen : 1];
@@ -222,7 +222,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void s
     __shared__ uint32_t s_word[4][64];   // bitmap word index loaded by each lane
     __shared__ uint32_t s_chw[4][64];    // changed bits of this pass, per owned word
     __shared__ uint32_t s_kdw[4][64];    // Kahan-dirty bits, per owned word (REAL)
-    constexpr int kU = 2;                // index quads per gather round
+    // [r6] the sources of a touched row in THREE round trips, as the bitmap pass does it (frontier_kernel): all indices of the row at once
+    // (W per lane: 64 sources for a hub chunk, 16 for a node row), then all their changed-bit words, then only the gathers that are needed,
+    // packed per quad in an LDS strip so that the wave runs as many gather rounds as its fullest quad has survivors.  The loop this
+    // replaces took 8 sources per round - index, bit word and gather each a dependent round trip - so a wave whose longest chunk row has
+    // 64 sources walked 24 of them per batch of 16 rows while 1-2 sources per row had changed; at C4 the first sweep pass spent 3.5 ms in
+    // the level-1 launch that way.  SLOW (experiments build, tune[1] bit 26): the old loop, kept as the A/B form.
+    constexpr int W = REAL ? 4 : 16;
+    __shared__ uint32_t s_strip[SLOW ? 1 : 64 * (4 * W + 1)];
+    constexpr int kU = 2;                // (SLOW) index quads per gather round
     const PassParams &p = sp.p;
     if (!guard_open(sp.guard)) return; // (block-uniform: every wave reads the same words)
     if (REAL) {
@@ -331,7 +339,97 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void s
             Acc acc;
             acc_zero(acc);
             bool lane_act = false;
-            if (beg < end) {
+            if (!SLOW) {
+                for (uint64_t e0 = beg; e0 < end; e0 += 4 * W) { // one iteration unless the row has more than 4 W sources
+                    // ---- round trip 1: all indices of the batch (slot j of lane q = source e0 + 4 j + q)
+                    const uint64_t span = end - e0;
+                    uint32_t idx[W];
+                    uint64_t bal4[W / 4];
+#pragma unroll
+                    for (int b = 0; b < W / 4; b++) bal4[b] = __ballot(span > (uint64_t)(16 * b));
+#pragma unroll
+                    for (int b = 0; b < W / 4; b++) {
+                        if (bal4[b]) { // wave-uniform: some row of the wave reaches this quarter
+#pragma unroll
+                            for (int j = 4 * b; j < 4 * b + 4; j++) {
+                                const uint64_t ee = e0 + 4 * j + q;
+                                idx[j] = (ee < end) ? p.src[ee] : kNone;
+                            }
+                        } else {
+#pragma unroll
+                            for (int j = 4 * b; j < 4 * b + 4; j++) idx[j] = kNone;
+                        }
+                    }
+                    const uint32_t first = quad_bcast<0>(idx[0]);
+                    const uint4 *srcbase = (first >= p.n_pad) ? (const uint4 *)(p.part - p.n_pad * 4) : p.rd;
+                    // ---- round trip 2: the changed bits of all of them
+                    uint32_t wb[W];
+#pragma unroll
+                    for (int b = 0; b < W / 4; b++) {
+                        if (bal4[b]) {
+#pragma unroll
+                            for (int j = 4 * b; j < 4 * b + 4; j++) {
+                                HB_DBG_ASSERT(idx[j] == kNone || idx[j] < p.rows_total);
+                                wb[j] = (idx[j] != kNone) ? p.bits_rd[idx[j] >> 5] : 0u;
+                            }
+                        } else {
+#pragma unroll
+                            for (int j = 4 * b; j < 4 * b + 4; j++) wb[j] = 0u;
+                        }
+                    }
+                    uint32_t mine = 0;
+#pragma unroll
+                    for (int j = 0; j < W; j++) {
+                        if (!((wb[j] >> (idx[j] & 31u)) & 1u)) idx[j] = kNone;
+                        mine += (idx[j] != kNone);
+                    }
+                    lane_act |= mine != 0;
+                    // ---- round trip 3: the survivors, packed per quad (prefix over the quad's 4 lanes by DPP; odd strip stride)
+                    uint32_t incl = mine;
+                    {
+                        const uint32_t t1 = quad_perm<0x90>(incl); // lane q reads lane q-1
+                        if (q >= 1) incl += t1;
+                        const uint32_t t2 = quad_perm<0x44>(incl); // lane q reads lane q-2
+                        if (q >= 2) incl += t2;
+                    }
+                    const uint32_t nsurv = quad_bcast<3>(incl);
+                    uint32_t *strip = &s_strip[(wv * 16 + g) * (4 * W + 1)];
+                    uint32_t pos = incl - mine;
+#pragma unroll
+                    for (int j = 0; j < W; j++) {
+                        if (idx[j] != kNone) {
+                            HB_DBG_ASSERT(pos < (uint32_t)(4 * W));
+                            strip[pos++] = idx[j];
+                        }
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); // same wave writes and reads the strip: its LDS operations complete in order
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll 1
+                    for (uint32_t j = 0; j < (uint32_t)(4 * W); j += 8) {
+                        if (!__ballot(j < nsurv)) break; // no quad of the wave has an entry left
+                        uint4 r[2][4];
+#pragma unroll
+                        for (int u = 0; u < 2; u++) {
+                            const uint32_t e = j + 4 * u + q;
+                            const uint32_t my = (e < nsurv) ? strip[e] : kNone;
+                            const uint32_t s0 = quad_bcast<0>(my), s1 = quad_bcast<1>(my);
+                            const uint32_t s2 = quad_bcast<2>(my), s3 = quad_bcast<3>(my);
+                            r[u][0] = r[u][1] = r[u][2] = r[u][3] = make_uint4(0, 0, 0, 0); // max with 0 = identity
+                            if (s0 != kNone) r[u][0] = srcbase[(uint64_t)s0 * 4 + q];
+                            if (s1 != kNone) r[u][1] = srcbase[(uint64_t)s1 * 4 + q];
+                            if (s2 != kNone) r[u][2] = srcbase[(uint64_t)s2 * 4 + q];
+                            if (s3 != kNone) r[u][3] = srcbase[(uint64_t)s3 * 4 + q];
+                        }
+#pragma unroll
+                        for (int k = 0; k < 4; k++) acc_merge(acc, r[0][k]);
+                        if (__ballot(j + 4 < nsurv)) {
+#pragma unroll
+                            for (int k = 0; k < 4; k++) acc_merge(acc, r[1][k]);
+                        }
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); // the strip is rewritten by the next batch
+                }
+            } else if (beg < end) {
                 const uint32_t first = p.src[beg];
                 const uint4 *srcbase = (first >= p.n_pad) ? (const uint4 *)(p.part - p.n_pad * 4) : p.rd;
                 for (uint64_t e = beg; e < end; e += 4 * kU) { // 4 * kU sources per round: indices, bit tests, gathers

@@ -248,6 +248,14 @@ VARIANTS["full_init_switch"] = dict(tune=(0, 0x800000))  # hb_begin always write
 # bit 25 = the atomic-scatter form it replaced, which remains the out-of-memory fallback: same passes, same bits either way
 VARIANTS["sweep_transpose_by_scatter"] = dict(chunk=8, tune=(0, 0x2000000, 101, 0, 0, 0, 1))
 VARIANTS["long_tail_transpose_by_scatter"] = dict(tune=(0, 0x2000000))
+# round 6: a touched row of a sweep pass takes all its indices, then all their changed-bit words, then the needed gathers (hb_sweep.hip.h);
+# bit 26 = the round-by-round loop it replaced (A/B form)
+VARIANTS["pass0_level1_generic_kernel"] = dict(tune=(0, 0x8000000))  # bit 27: pass 0's first hub level through pass_kernel<.., INIT> (the form before init_level1_kernel)
+VARIANTS["pass0_level1_chunk128"] = dict(chunk=128)                   # init_level1_kernel with rows of more than 64 sources: two batches
+VARIANTS["sweep_rows_round_by_round"] = dict(chunk=8, tune=(0, 0x4000000, 101, 0, 0, 0, 1))
+VARIANTS["long_tail_rows_round_by_round"] = dict(tune=(0, 0x4000000))
+VARIANTS["sparse_always_chunk128"] = dict(chunk=128, tune=(0, 0, 101, 0, 0, 0, 1))  # sweep rows with more than 64 sources: two batches per hub chunk
+VARIANTS["sparse_always_direct32"] = dict(chunk=32, tune=(0, 0, 101, 5, 8, 8, 1))    # node rows with more than 16 direct sources: several batches
 
 
 @pytest.mark.parametrize("variant", sorted(VARIANTS))
