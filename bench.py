@@ -669,6 +669,13 @@ def main():
             dog.cancel()
         if rank == 0:
             out["detail"]["partitions"] = legs
+            # `value` stays the decomposition BASELINE configs[3] names (edge partition + all-reduce per pass); the fastest decomposition
+            # whose final results equal the main leg's bit for bit is named at the top level, where a truncating reader still sees it
+            ok = {k: v for k, v in legs.items() if isinstance(v, dict) and v.get("same_result_as_edge_partition") and "value" in v}
+            ok["edge_allreduce"] = {"value": out["value"], "ms_per_step": out["ms_per_step"]}
+            best = max(ok, key=lambda k: ok[k]["value"])
+            out["best_decomposition"] = {"name": best, "value": ok[best]["value"], "unit": "GTEPS", "ms_per_step": ok[best]["ms_per_step"],
+                                         "note": "same final (NodeID, f64) list as the edge-partition leg; `value` above is the north-star decomposition"}
         if dog.is_alive() and any("error" in v for v in legs.values() if isinstance(v, dict)):
             dog.join()  # a leg failed here: wait for the watchdog (it prints on rank 0 and ends the process)
 

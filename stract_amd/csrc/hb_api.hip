@@ -173,6 +173,12 @@ struct hb_ctx {
     double *d_out = nullptr;
     double *h_out = nullptr; // pinned, n entries
     uint64_t h_out_len = 0;
+    // [r6] the image's layout: out_len live entries.  Identity (out_len = n, index = sid, d_cid_of = d_sid_of) or, when the results travel in
+    // stages (rs.on: single rank), COMPACT: one entry per node with in-edges, ascending NodeID (hb_aux.hip.h "the compact result image");
+    // h_in_bits = those nodes as a bitmap over the sids (empty = identity)
+    uint64_t out_len = 0;
+    uint32_t *d_cid_of = nullptr; // n_pad: device row -> index into out[] (kNone = not in the image)
+    std::vector<uint64_t> h_in_bits;
     uint64_t res_count = 0;
     // results that travel while the passes still run (results_stage below; hb_aux.hip.h results_sync_kernel)
     struct ResultSync {
@@ -256,6 +262,9 @@ void free_graph_buffers(hb_ctx *c)
     c->d_raw = c->d_bias = nullptr;
     c->d_lc = nullptr;
     c->d_out = nullptr;
+    c->d_cid_of = nullptr;
+    c->out_len = 0;
+    std::vector<uint64_t>().swap(c->h_in_bits);
     c->d_pack = nullptr;
     c->d_wpop = nullptr;
     c->d_wprefix = nullptr;
@@ -1160,7 +1169,7 @@ int hb_finish(hb_ctx *c)
             // whole behind the download instead.
             const unsigned blocks = (unsigned)std::min<uint64_t>((p.n_pad + 2047) / 2048, (uint64_t)c->num_cu * 8);
             hipLaunchKernelGGL(hbk::results_sync_kernel, dim3(blocks), dim3(256), 0, c->stream, (const double *)c->d_ksum, rs.d_sent,
-                               (const uint32_t *)c->d_sid_of, p.n_pad, norm, 0, c->d_out, rs.d_sid, rs.d_val, (unsigned long long)rs.cap, rs.d_count, cnt);
+                               (const uint32_t *)c->d_cid_of, p.n_pad, norm, 0, c->d_out, rs.d_sid, rs.d_val, (unsigned long long)rs.cap, rs.d_count, cnt);
             HB_HIP(hipGetLastError());
             HB_HIP(hipMemcpyAsync(rs.h_count, rs.d_count, sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
             HB_HIP(hipMemcpyAsync(c->h_counters, cnt, hbk::kCounterWords * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
@@ -1176,17 +1185,25 @@ int hb_finish(hb_ctx *c)
                 host_scatter_f64(c->h_out, rs.h_sid, rs.h_val, moved); // every sid occurs once: the shares are independent (hb_host.cpp, OpenMP team)
             } else { // more moved than the list holds: out[] on the device is complete anyway, ship it whole
                 HB_HIP(hipStreamWaitEvent(c->stream, rs.copied, 0)); // (behind the snapshot's download: both write h_out)
-                HB_HIP(hipMemcpyAsync(c->h_out, c->d_out, p.n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+                HB_HIP(hipMemcpyAsync(c->h_out, c->d_out, c->out_len * sizeof(double), hipMemcpyDeviceToHost, c->stream));
                 HB_HIP(hipStreamSynchronize(c->stream));
             }
             shipped = true;
         }
         if (p.n && !shipped) {
-            unsigned blocks = (unsigned)std::min<uint64_t>((p.n + 255) / 256, (uint64_t)c->num_cu * 8);
-            hipLaunchKernelGGL(hbk::finish_kernel, dim3(blocks), dim3(256), 0, c->stream, (const double *)c->d_ksum,
-                               (const uint32_t *)c->d_dev_of, p.n, norm, c->d_out, cnt);
+            if (c->rs.on) {
+                // no snapshot was taken (the loop ended before the policy asked for one): the compact image whole, from the same kernel
+                // (all rows, no list; sent[] is rewritten - nobody reads it before the next run's first snapshot does the same)
+                const unsigned blocks = (unsigned)std::min<uint64_t>((p.n_pad + 2047) / 2048, (uint64_t)c->num_cu * 8);
+                hipLaunchKernelGGL(hbk::results_sync_kernel, dim3(blocks), dim3(256), 0, c->stream, (const double *)c->d_ksum, c->rs.d_sent,
+                                   (const uint32_t *)c->d_cid_of, p.n_pad, norm, 1, c->d_out, (uint32_t *)nullptr, (double *)nullptr, 0ull, c->rs.d_count, cnt);
+            } else {
+                unsigned blocks = (unsigned)std::min<uint64_t>((p.n + 255) / 256, (uint64_t)c->num_cu * 8);
+                hipLaunchKernelGGL(hbk::finish_kernel, dim3(blocks), dim3(256), 0, c->stream, (const double *)c->d_ksum,
+                                   (const uint32_t *)c->d_dev_of, p.n, norm, c->d_out, cnt);
+            }
             HB_HIP(hipGetLastError());
-            HB_HIP(hipMemcpyAsync(c->h_out, c->d_out, p.n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+            HB_HIP(hipMemcpyAsync(c->h_out, c->d_out, c->out_len * sizeof(double), hipMemcpyDeviceToHost, c->stream));
         }
         if (!shipped) {
             HB_HIP(hipMemcpyAsync(c->h_counters, cnt, hbk::kCounterWords * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
@@ -1291,7 +1308,7 @@ int hb_result_copy(hb_ctx *c, hb_u128 *ids, double *vals, uint64_t cap)
         if (!c->finished) return fail(c, HB_ERR_INVALID, "no results: hb_run / hb_finish not called");
         // compaction of the per-node array (absent = negative) into the caller's buffers, on the host cores the process may use
         // (C4: 99 M nodes -> 79 M results = 1.9 GB written; one thread took 1.3 s of the 15 s chain store -> load -> run -> store)
-        host_compact_results(c->h_out, c->g.ids.data(), c->plan.n, ids, vals, cap);
+        host_compact_results(c->h_out, c->g.ids.data(), c->plan.n, ids, vals, cap, c->h_in_bits.empty() ? nullptr : c->h_in_bits.data());
         return HB_OK;
     });
 }
@@ -1304,7 +1321,7 @@ int hb_result_ranks(hb_ctx *c, uint64_t *ranks, uint64_t cap)
         if (cap < c->res_count) return fail(c, HB_ERR_INVALID, "hb_result_ranks: cap < hb_result_count");
         int rc = set_device(c);
         if (rc) return rc;
-        std::string e = gpu_rank_results((void *)c->stream, c->d_out, c->plan.n, c->res_count, ranks);
+        std::string e = gpu_rank_results((void *)c->stream, c->d_out, c->out_len, c->res_count, ranks); // (the compact image keeps NodeID order: same ranks)
         if (!e.empty()) return fail(c, HB_ERR_HIP, e);
         return HB_OK;
     });
@@ -1321,18 +1338,27 @@ int hb_result_top(hb_ctx *c, uint64_t k, hb_u128 *ids, double *vals, uint64_t *w
         if (written) *written = top;
         if (!top || (!ids && !vals)) return HB_OK;
         std::vector<uint64_t> order(top);
-        std::string e = gpu_rank_results((void *)c->stream, c->d_out, c->plan.n, c->res_count, nullptr, order.data(), top);
+        std::string e = gpu_rank_results((void *)c->stream, c->d_out, c->out_len, c->res_count, nullptr, order.data(), top);
         if (!e.empty()) return fail(c, HB_ERR_HIP, e);
-        // result index (ascending NodeID among the kept ones) -> sid
-        std::vector<uint32_t> kept;
+        // result index (ascending NodeID among the kept ones) -> (sid, index into the image); compact image: the k-th set bit of h_in_bits
+        std::vector<uint32_t> kept, at;
         kept.reserve(c->res_count);
-        for (uint64_t sid = 0; sid < c->plan.n; sid++)
-            if (c->h_out[sid] >= 0.0) kept.push_back((uint32_t)sid);
+        const bool compact = !c->h_in_bits.empty();
+        if (compact) at.reserve(c->res_count);
+        uint64_t cid = 0;
+        for (uint64_t sid = 0; sid < c->plan.n; sid++) {
+            if (compact && !((c->h_in_bits[sid >> 6] >> (sid & 63u)) & 1ull)) continue;
+            const uint64_t pos = compact ? cid++ : sid;
+            if (c->h_out[pos] >= 0.0) {
+                kept.push_back((uint32_t)sid);
+                if (compact) at.push_back((uint32_t)pos);
+            }
+        }
         if (kept.size() != c->res_count) return fail(c, HB_ERR_INVALID, "hb_result_top: result buffer changed since hb_finish");
         for (uint64_t i = 0; i < top; i++) {
             const uint32_t sid = kept[order[i]];
             if (ids) ids[i] = c->g.ids[sid];
-            if (vals) vals[i] = c->h_out[sid];
+            if (vals) vals[i] = c->h_out[compact ? at[order[i]] : sid];
         }
         return HB_OK;
     });

@@ -332,6 +332,38 @@ __global__ __launch_bounds__(256) void finish_kernel(const double *ksum, const u
     block_add_counters(count, v, 0x1u); // striped: the host sums word 0 of every stripe
 }
 
+// ---- the compact result image [r6] ----------------------------------------------------------------------------------------------
+// A node without in-edges never changes its counter, so its centrality stays 0 and it is never a result (harmonic.rs:178-195 keeps
+// centrality > 0): on a single rank the host-bound image therefore holds one f64 per node WITH in-edges only, in ascending-NodeID order
+// ("cid" = rank of the node among those) - at C4 79.0 M of 99.2 M entries: 632 instead of 794 MB over the link for the snapshot whose
+// download hb_finish waits for, and as many fewer scattered stores in the snapshot kernel.  Built once per load: flags in NodeID order
+// -> exclusive scan -> cid per device row (kNone = no in-edges: the row is skipped by results_sync_kernel); the flags also go to the
+// host as a bitmap, from which hb_result_copy / hb_result_top find the NodeID of every compact entry.
+__global__ __launch_bounds__(256) void in_flags_kernel(const uint64_t *row_ptr, const uint32_t *sid_of, uint64_t n_pad, uint32_t *flags)
+{
+    for (uint64_t row = (uint64_t)blockIdx.x * 256 + threadIdx.x; row < n_pad; row += (uint64_t)gridDim.x * 256) {
+        const uint32_t sd = sid_of[row];
+        if (sd != kNone) flags[sd] = row_ptr[row + 1] > row_ptr[row] ? 1u : 0u;
+    }
+}
+__global__ __launch_bounds__(256) void cid_of_kernel(const uint64_t *row_ptr, const uint32_t *sid_of, const uint64_t *cpos, uint64_t n_pad, uint32_t *cid_of)
+{
+    for (uint64_t row = (uint64_t)blockIdx.x * 256 + threadIdx.x; row < n_pad; row += (uint64_t)gridDim.x * 256) {
+        const uint32_t sd = sid_of[row];
+        cid_of[row] = (sd != kNone && row_ptr[row + 1] > row_ptr[row]) ? (uint32_t)cpos[sd] : kNone;
+    }
+}
+// words[w] bit b = flags[64 w + b] (the wave's ballot IS the word); `words` covers ceil(n / 64) entries
+__global__ __launch_bounds__(256) void pack_flags_kernel(const uint32_t *flags, uint64_t n, unsigned long long *words)
+{
+    const uint64_t nw = (n + 63) >> 6;
+    for (uint64_t w = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6); w < nw; w += (uint64_t)gridDim.x * 4) { // wave-uniform trip count
+        const uint64_t i = (w << 6) + (threadIdx.x & 63);
+        const unsigned long long m = __ballot(i < n && flags[i] != 0u);
+        if ((threadIdx.x & 63) == 0) words[w] = m;
+    }
+}
+
 // ---- results that travel while the passes still run (hb_api.hip: results_stage / hb_finish) --------------------------------
 // The host needs one f64 per node at the end (HarmonicCentrality's map); a download of n x 8 bytes AFTER the last pass is
 // 7-8 % of a whole run at BASELINE sizes (C4: 794 MB = 14 ms over the link against 212 ms).  Most nodes' sums are final long

@@ -786,10 +786,10 @@ void host_gather_id_lo(const hb_u128 *ids, uint64_t n, uint64_t *lo)
     for (int64_t s = 0; s < (int64_t)n; s++) lo[s] = ids[s].lo;
 }
 
-void host_compact_results(const double *src, const hb_u128 *idsrc, uint64_t n, hb_u128 *ids, double *vals, uint64_t cap)
+void host_compact_results(const double *src, const hb_u128 *idsrc, uint64_t n, hb_u128 *ids, double *vals, uint64_t cap, const uint64_t *in_bits)
 {
     const int want = n >= (1u << 18) ? std::min(host_threads(), 16) : 1;
-    std::vector<uint64_t> first((size_t)want + 1, 0);
+    std::vector<uint64_t> first((size_t)want + 1, 0), cfirst((size_t)want + 1, 0);
     int team = 1;
 #pragma omp parallel num_threads(want)
     {
@@ -797,20 +797,50 @@ void host_compact_results(const double *src, const hb_u128 *idsrc, uint64_t n, h
         const int nt = omp_get_num_threads(), t = omp_get_thread_num();
 #pragma omp single
         team = nt;
-        const uint64_t lo = n * (uint64_t)t / (uint64_t)nt, hi = n * (uint64_t)(t + 1) / (uint64_t)nt;
+        // shares are cut at multiples of 64 sids, so that a share owns whole words of the bitmap
+        const uint64_t nw = (n + 63) / 64;
+        const uint64_t lo = std::min(n, nw * (uint64_t)t / (uint64_t)nt * 64), hi = std::min(n, nw * (uint64_t)(t + 1) / (uint64_t)nt * 64);
+        if (in_bits) { // where this share's entries begin in the compact image
+            uint64_t bits = 0;
+            for (uint64_t w = lo / 64; w < (hi + 63) / 64; w++) bits += (uint64_t)__builtin_popcountll(in_bits[w]);
+            cfirst[(size_t)t + 1] = bits;
+#pragma omp barrier
+#pragma omp single
+            for (int k = 0; k < nt; k++) cfirst[(size_t)k + 1] += cfirst[(size_t)k];
+        }
         uint64_t kept = 0;
-        for (uint64_t sid = lo; sid < hi; sid++) kept += src[sid] >= 0.0;
+        if (in_bits) {
+            for (uint64_t c = cfirst[(size_t)t]; c < cfirst[(size_t)t + 1]; c++) kept += src[c] >= 0.0;
+        } else {
+            for (uint64_t sid = lo; sid < hi; sid++) kept += src[sid] >= 0.0;
+        }
         first[(size_t)t + 1] = kept;
 #pragma omp barrier
 #pragma omp single
         for (int k = 0; k < nt; k++) first[(size_t)k + 1] += first[(size_t)k];
         uint64_t at = first[(size_t)t];
-        for (uint64_t sid = lo; sid < hi && at < cap; sid++) {
-            const double v = src[sid];
-            if (v < 0.0) continue;
-            if (ids) ids[at] = idsrc[sid];
-            if (vals) vals[at] = v;
-            at++;
+        if (in_bits) {
+            uint64_t c = cfirst[(size_t)t];
+            for (uint64_t w = lo / 64; w < (hi + 63) / 64 && at < cap; w++) {
+                uint64_t m = in_bits[w];
+                while (m && at < cap) {
+                    const uint64_t sid = (w << 6) + (uint64_t)__builtin_ctzll(m);
+                    m &= m - 1;
+                    const double v = src[c++];
+                    if (v < 0.0) continue;
+                    if (ids) ids[at] = idsrc[sid];
+                    if (vals) vals[at] = v;
+                    at++;
+                }
+            }
+        } else {
+            for (uint64_t sid = lo; sid < hi && at < cap; sid++) {
+                const double v = src[sid];
+                if (v < 0.0) continue;
+                if (ids) ids[at] = idsrc[sid];
+                if (vals) vals[at] = v;
+                at++;
+            }
         }
     }
     (void)team;

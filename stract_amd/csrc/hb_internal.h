@@ -277,7 +277,8 @@ void host_scatter_f64(double *out, const uint32_t *idx, const double *val, uint6
 // lo[s] = ids[s].lo (the half of a NodeID HyperLogLog::add_u128 hashes), on the OpenMP team
 void host_gather_id_lo(const hb_u128 *ids, uint64_t n, uint64_t *lo);
 //   the (id, value) pairs with src[sid] >= 0.0 in ascending sid order, at most cap of them; ids / vals may be NULL
-void host_compact_results(const double *src, const hb_u128 *idsrc, uint64_t n, hb_u128 *ids, double *vals, uint64_t cap);
+// in_bits != NULL [r6]: src is the COMPACT image - one entry per sid whose bit is set, in sid order (hb_aux.hip.h "the compact result image")
+void host_compact_results(const double *src, const hb_u128 *idsrc, uint64_t n, hb_u128 *ids, double *vals, uint64_t cap, const uint64_t *in_bits = nullptr);
 
 // ---- store emission (hb_store.cpp; the key order may come from the device: hb_ingest.hip gpu_store_keys) ---------------------
 // one entry of the sort: the 17 key bytes as two big-endian words + the last byte, so that integer order = byte order of

@@ -616,14 +616,28 @@ def test_store_from_the_context_equals_the_host_sorted_store(gpu_ctx_factory, tm
                 ctx.store_harmonic(str(a))  # the directory holds databases now: refused like the host entry point
 
 
-def test_result_ranks_match_store_harmonic_order(gpu_ctx_factory):
+@pytest.mark.parametrize("image", ["one_entry_per_node", "compact"])
+def test_result_ranks_match_store_harmonic_order(gpu_ctx_factory, image):
     # centrality/mod.rs:92-103: harmonic_rank = position by (Reverse(total_cmp(centrality)), NodeID)
+    # image = compact [r6]: results shipped in stages (forced here; the default from 2^20 nodes on) keep one image entry per node WITH
+    # in-edges only; list, ranks and top-k must come out of it exactly as out of the one-entry-per-node image
     g = synth.RmatGraph(13, 60_000)
+    kw = dict(tune=(0, 0x8000)) if image == "compact" else {}
+    _factory = gpu_ctx_factory
+    gpu_ctx_factory = lambda: _factory(**kw)  # noqa: E731
+    o = hbo.Dense(g.id_low64(), g.row_ptr, g.src)
+    while o.step(hbo.FRONTIER)[0]:
+        pass
+    ovals, okeep, ok = o.finish()
+    indeg = np.diff(g.row_ptr)
+    assert (indeg == 0).sum() > 100 and ok < g.n  # the graph has nodes the compact image leaves out
     with gpu_ctx_factory() as ctx:
         ctx.load_dense(g.ids, g.row_ptr, g.src)
         ctx.run()
         ids, vals = ctx.results()
         ranks = ctx.ranks()
+        assert (ctx.stats()["result_stages"] >= 1) == (image == "compact")
+    assert np.array_equal(ids, g.ids[okeep]) and np.array_equal(vals.view(np.uint64), ovals[okeep].view(np.uint64))
     assert len(ranks) == len(vals) and sorted(ranks.tolist()) == list(range(len(vals)))
     assert np.array_equal(ranks, hbo.rank_results(vals))
     assert len(np.unique(vals)) < len(vals)  # ties exist: the NodeID tie-break is exercised
@@ -643,6 +657,23 @@ def test_result_ranks_match_store_harmonic_order(gpu_ctx_factory):
         ctx.run()
         assert ctx.ranks().tolist() == [1, 2, 0]  # C > A > B (harmonic.rs:465-473)
         assert hc.len() == 3
+    # a run that ends before any snapshot was taken (2 nodes, one edge): the compact image then goes whole at hb_finish
+    with gpu_ctx_factory() as ctx:
+        e = np.zeros(1, dtype=_lib.EDGE)
+        e["from"]["lo"], e["to"]["lo"] = 5, 9
+        ctx.load_edges(e)
+        ctx.run()
+        i2, v2 = ctx.results()
+        assert [int(x) for x in i2["lo"]] == [9] and v2.tolist() == [1.0] and ctx.ranks().tolist() == [0]
+        t2 = ctx.top(5)
+        assert [int(x) for x in t2[0]["lo"]] == [9] and t2[1].tolist() == [1.0]
+    # ... and a graph without any edge: pass 0 changes nothing, no snapshot is ever taken, the image has no entry at all
+    with gpu_ctx_factory() as ctx:
+        ids3 = np.zeros(3, dtype=_lib.U128)
+        ids3["lo"] = [2, 4, 6]
+        ctx.load_dense(ids3, np.zeros(4, dtype=np.uint64), np.zeros(0, dtype=np.uint32))
+        ctx.run()
+        assert len(ctx.results()[1]) == 0 and len(ctx.ranks()) == 0 and len(ctx.top(3)[1]) == 0 and ctx.stats()["result_stages"] == 0
 
 
 def test_gpu_ingest_equals_host_ingest(gpu_ctx_factory):

@@ -67,9 +67,10 @@ def main():
         for did, name, counter, value in rows:
             if "rocclr" in name:
                 continue
-            e = pmc.setdefault(cls_of[did], {}).setdefault(counter, {"dispatches": 0, "sum": 0.0})
+            e = pmc.setdefault(cls_of[did], {}).setdefault(counter, {"dispatches": 0, "sum": 0.0, "max": 0.0})
             e["dispatches"] += 1
             e["sum"] += value
+            e["max"] = max(e["max"], value)  # the largest single dispatch (sweep kernels: the first sweep pass of a run, cf. MaxNs of the trace)
     for k, cs in pmc.items():
         for e in cs.values():
             e["per_dispatch"] = e["sum"] / e["dispatches"]
