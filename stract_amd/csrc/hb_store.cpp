@@ -27,6 +27,7 @@
 #include <new>
 #include <random>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include <fcntl.h>
@@ -184,12 +185,42 @@ public:
     {
         flush();
         if (fd_ >= 0 && !blocks_.empty()) {
+            // The booked blocks are adjacent in file order.  Writes to ONE file queue behind its inode lock whatever the number of writers,
+            // and a store of hashed NodeIDs books 131 072 blocks of a few KB: one pwrite each was 131 072 system calls taking turns.  Runs
+            // of >= 8 MB are gathered into a staging buffer by the team (the copies run in parallel) and go out as one write each.
             std::atomic<bool> ok{true};
             const int fd = fd_;
             const std::vector<Block> &bl = blocks_;
-#pragma omp parallel for num_threads(hb::host_threads()) schedule(dynamic, 64)
-            for (size_t k = 0; k < bl.size(); k++)
-                if (!pwrite_all(fd, bl[k].p, bl[k].n, bl[k].off)) ok = false;
+            std::vector<size_t> cut{0};
+            {
+                uint64_t run = 0;
+                for (size_t k = 0; k < bl.size(); k++) {
+                    const bool adjacent = k && bl[k - 1].off + bl[k - 1].n == bl[k].off;
+                    if (k && (!adjacent || run >= (8u << 20))) {
+                        cut.push_back(k);
+                        run = 0;
+                    }
+                    run += bl[k].n;
+                }
+                cut.push_back(bl.size());
+            }
+            const size_t nruns = cut.size() - 1;
+#pragma omp parallel num_threads(hb::host_threads())
+            {
+                bytes stage;
+#pragma omp for schedule(dynamic, 1)
+                for (size_t c = 0; c < nruns; c++) {
+                    const size_t a = cut[c], b = cut[c + 1];
+                    if (b == a + 1) {
+                        if (!pwrite_all(fd, bl[a].p, bl[a].n, bl[a].off)) ok = false;
+                        continue;
+                    }
+                    const uint64_t total = bl[b - 1].off + bl[b - 1].n - bl[a].off;
+                    stage.resize(total);
+                    for (size_t k = a; k < b; k++) std::memcpy(stage.data() + (bl[k].off - bl[a].off), bl[k].p, bl[k].n);
+                    if (!pwrite_all(fd, stage.data(), total, bl[a].off)) ok = false;
+                }
+            }
             if (!ok) failed_ = true;
             blocks_.clear();
             owned_.clear();
@@ -676,6 +707,12 @@ bool fst_sequential(const EntryVec &e, const std::string &path, std::string *why
 bool fst_parallel(const EntryVec &e, const std::string &path, std::string *why)
 {
     const size_t n = e.size();
+    const bool trace = std::getenv("HB_TRACE_STORE") != nullptr;
+    double t_lap = omp_get_wtime();
+    auto lap = [&](const char *what) {
+        if (trace) std::fprintf(stderr, "[hb store fst] %-24s %8.3f s\n", what, omp_get_wtime() - t_lap);
+        t_lap = omp_get_wtime();
+    };
     // group = maximal run of keys of length >= 4 with the same first three bytes; shorter keys go through insert()
     struct Group {
         size_t lo, hi;
@@ -685,17 +722,31 @@ bool fst_parallel(const EntryVec &e, const std::string &path, std::string *why)
         uint32_t crc = 0; // CRC-32C of `sub`, computed by the thread that built it
     };
     std::vector<Group> groups;
-    for (size_t i = 0; i < n;) {
-        if (e[i].key_len() < 4) {
-            i++;
-            continue;
+    {
+        // boundaries = indices where a group starts, and keys too short to be in one; a group runs from its start to the next boundary.
+        // Found by the team, every thread in its own share of the keys (79 M at C4: a third of a second on one thread).
+        const int want = n >= (1u << 18) ? hb::host_threads() : 1;
+        std::vector<std::vector<uint64_t>> found((size_t)want); // index << 1 | is_start
+#pragma omp parallel num_threads(want)
+        {
+            const size_t nt = (size_t)omp_get_num_threads(), t = (size_t)omp_get_thread_num();
+            const size_t lo = n * t / nt, hi = n * (t + 1) / nt;
+            std::vector<uint64_t> mine;
+            for (size_t i = lo; i < hi; i++) {
+                if (e[i].key_len() < 4) {
+                    mine.push_back((uint64_t)i << 1);
+                    continue;
+                }
+                if (i == 0 || e[i - 1].key_len() < 4 || (e[i - 1].k0 >> 40) != (e[i].k0 >> 40)) mine.push_back(((uint64_t)i << 1) | 1u);
+            }
+            if (t < found.size()) found[t].swap(mine);
         }
-        const uint64_t pre = e[i].k0 >> 40;
-        size_t j = i + 1;
-        while (j < n && e[j].key_len() >= 4 && (e[j].k0 >> 40) == pre) j++;
-        groups.push_back(Group{i, j, {}, 0, true, 0});
-        i = j;
+        std::vector<uint64_t> bnd;
+        for (auto &v : found) bnd.insert(bnd.end(), v.begin(), v.end());
+        for (size_t k = 0; k < bnd.size(); k++)
+            if (bnd[k] & 1u) groups.push_back(Group{(size_t)(bnd[k] >> 1), k + 1 < bnd.size() ? (size_t)(bnd[k + 1] >> 1) : n, {}, 0, true, 0});
     }
+    lap("group scan");
 #pragma omp parallel for num_threads(hb::host_threads()) schedule(dynamic, 1)
     for (size_t g = 0; g < groups.size(); g++) {
         Group &G = groups[g];
@@ -712,6 +763,7 @@ bool fst_parallel(const EntryVec &e, const std::string &path, std::string *why)
         G.sub.shrink_to_fit();
         G.crc = crc32c_update(0, G.sub.data(), G.sub.size());
     }
+    lap("sub-tries (parallel)");
     FileSink out(path);
     if (!out.ok()) {
         *why = "cannot create " + path;
@@ -740,10 +792,12 @@ bool fst_parallel(const EntryVec &e, const std::string &path, std::string *why)
         }
     }
     top.finish();
+    lap("top levels (sequential)");
     if (!out.close()) {
         *why = "write failed on " + path;
         return false;
     }
+    lap("close (parallel pwrite)");
     return true;
 }
 
@@ -1000,7 +1054,6 @@ int write_dbs(const std::vector<Target> &targets, const hb_u128 *ids, uint64_t c
     lap("bloom");
     const char *mode = std::getenv("HB_STORE_FST");
     const bool sequential = mode && std::strcmp(mode, "sequential") == 0;
-    std::string first_ids;
     // A call that fails leaves nothing behind: every file it wrote is removed again, and the meta.json files - what makes a
     // directory a database, and what makes this writer refuse it next time - are written only after the segment files of ALL targets
     // are complete (hb_store_harmonic: a failure in `harmonic_rank` must not leave a `harmonic` that blocks the retry).
@@ -1013,28 +1066,70 @@ int write_dbs(const std::vector<Target> &targets, const hb_u128 *ids, uint64_t c
                 for (const std::string &f : paths) (void)::unlink(f.c_str());
         }
     } undo;
-    std::vector<std::string> uuids;
+    std::vector<std::string> uuids, bases;
     for (const Target &t : targets) {
-        const std::string uuid = uuid_v4(), base = t.dir + "/" + uuid;
-        uuids.push_back(uuid);
-        for (const char *ext : {".blobs", ".bid", ".ids", ".blm"}) undo.paths.push_back(base + ext);
+        uuids.push_back(uuid_v4());
+        bases.push_back(t.dir + "/" + uuids.back());
+        for (const char *ext : {".blobs", ".bid", ".ids", ".blm"}) undo.paths.push_back(bases.back() + ext);
+    }
+    // [r6] the fst is built BESIDE the blob files: `.blobs` / `.bid` are page-cache copies behind one inode lock per file (two writers at a
+    // time whatever the team size), the fst is CPU work on the same keys - one after the other they were 0.7 + 3.5 + 1.2..1.8 s at C4
+    // (profiles/r06l_store_phases_C4_then_C3.txt).  A second thread (with an OpenMP team of its own) builds `.ids` of the first target
+    // while this one writes the blob files of all targets; joined before anything is undone or declared complete.
+    struct FstJob {
+        bool ok = true;
+        int code = HB_ERR_IO;
         std::string why;
-        if (!write_blobs(entries, t.values, t.kind, base, &why)) return fail(err, err_len, HB_ERR_IO, "hb_store_write: " + why);
+        double seconds = 0.0;
+    } job;
+    std::thread fst_thread;
+    struct Joiner {
+        std::thread &t;
+        ~Joiner()
+        {
+            if (t.joinable()) t.join();
+        }
+    } joiner{fst_thread}; // (declared after `undo`: it joins before the undo list is walked)
+    if (!targets.empty()) {
+        fst_thread = std::thread([&]() {
+            const double t0 = omp_get_wtime();
+            try {
+                const std::string path = bases[0] + ".ids";
+                if (!(sequential ? fst_sequential(entries, path, &job.why) : fst_parallel(entries, path, &job.why))) {
+                    job.ok = false;
+                    job.code = job.why.find("ascending") != std::string::npos ? HB_ERR_INVALID : HB_ERR_IO;
+                }
+            } catch (const std::bad_alloc &) {
+                job.ok = false;
+                job.code = HB_ERR_NOMEM;
+                job.why = "out of host memory";
+            } catch (const std::exception &e) {
+                job.ok = false;
+                job.code = HB_ERR_INVALID;
+                job.why = e.what();
+            }
+            job.seconds = omp_get_wtime() - t0;
+        });
+    }
+    for (size_t k = 0; k < targets.size(); k++) {
+        std::string why;
+        if (!write_blobs(entries, targets[k].values, targets[k].kind, bases[k], &why)) return fail(err, err_len, HB_ERR_IO, "hb_store_write: " + why);
         lap(".blobs + .bid");
-        if (first_ids.empty()) {
-            if (!(sequential ? fst_sequential(entries, base + ".ids", &why) : fst_parallel(entries, base + ".ids", &why)))
-                return fail(err, err_len, why.find("ascending") != std::string::npos ? HB_ERR_INVALID : HB_ERR_IO, "hb_store_write: " + why);
-            first_ids = base + ".ids";
-            lap(".ids (fst)");
-        } else if (::link(first_ids.c_str(), (base + ".ids").c_str()) != 0 && !copy_file(first_ids, base + ".ids")) {
+    }
+    if (fst_thread.joinable()) fst_thread.join();
+    if (!job.ok) return fail(err, err_len, job.code, "hb_store_write: " + job.why);
+    if (trace) std::fprintf(stderr, "[hb store] %-28s %8.3f s  (beside the blob files; %d threads)\n", ".ids (fst)", job.seconds, hb::host_threads());
+    lap(".ids (fst): waited for");
+    for (size_t k = 0; k < targets.size(); k++) {
+        if (k && ::link((bases[0] + ".ids").c_str(), (bases[k] + ".ids").c_str()) != 0 && !copy_file(bases[0] + ".ids", bases[k] + ".ids")) {
             // same keys, same values 0 .. count-1: the same map - a second NAME for the same bytes where the file system allows it (both
             // databases live under one output directory; segment files are written once and only ever read, replaced as a whole or
             // removed: blob_id_index.rs:43-60 maps them read-only), a copy otherwise (C4: 1.3 GB, 0.4 s)
-            return fail(err, err_len, HB_ERR_IO, "hb_store_write: write failed on " + base + ".ids");
+            return fail(err, err_len, HB_ERR_IO, "hb_store_write: write failed on " + bases[k] + ".ids");
         }
-        lap(".ids copy");
-        if (!write_file(base + ".blm", blm)) return fail(err, err_len, HB_ERR_IO, "hb_store_write: write failed on " + base + ".blm");
+        if (!write_file(bases[k] + ".blm", blm)) return fail(err, err_len, HB_ERR_IO, "hb_store_write: write failed on " + bases[k] + ".blm");
     }
+    lap(".ids link + .blm");
     // Meta { segments: [uuid] } through serde_json::to_string_pretty (lib.rs:292-297); last, so that a database whose
     // meta.json exists is complete
     for (size_t k = 0; k < targets.size(); k++) {
