@@ -67,13 +67,18 @@ def main():
         for did, name, counter, value in rows:
             if "rocclr" in name:
                 continue
-            e = pmc.setdefault(cls_of[did], {}).setdefault(counter, {"dispatches": 0, "sum": 0.0, "max": 0.0})
+            e = pmc.setdefault(cls_of[did], {}).setdefault(counter, {"dispatches": 0, "sum": 0.0, "max": 0.0, "values": []})
             e["dispatches"] += 1
+            e["values"].append(value)
             e["sum"] += value
             e["max"] = max(e["max"], value)  # the largest single dispatch (sweep kernels: the first sweep pass of a run, cf. MaxNs of the trace)
     for k, cs in pmc.items():
         for e in cs.values():
-            e["per_dispatch"] = e["sum"] / e["dispatches"]
+            # [r6] the library warms every kernel with a zero-row launch at load: such a dispatch (counters ~ 0) must not dilute the class
+            # average - launches below 1e-4 of the class' largest one are not counted
+            small = sum(1 for v in e.pop("values") if v < 1e-4 * e["max"])
+            e["warmup_dispatches_ignored"] = small
+            e["per_dispatch"] = e["sum"] / max(e["dispatches"] - small, 1)
         if "FETCH_SIZE" in cs and "WRITE_SIZE" in cs:
             # FETCH_SIZE / WRITE_SIZE are KiB.  Calibration on this access pattern
             # (tools/gather_bench.hip, exactly-once 64-byte quad gathers over 8 GiB): FETCH_SIZE
