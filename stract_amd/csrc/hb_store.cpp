@@ -28,6 +28,7 @@
 #include <random>
 #include <string>
 #include <thread>
+#include <type_traits>
 #include <vector>
 
 #include <fcntl.h>
@@ -271,6 +272,13 @@ public:
     uint64_t count() const { return kSubBase + data.size(); }
     void write(const uint8_t *p, size_t n) { data.insert(data.end(), p, p + n); }
     void write_block(const uint8_t *p, size_t n, uint32_t) { write(p, n); }
+    // n more bytes at the end, to be filled in by the caller (FstWriter::emit_tail)
+    uint8_t *grab(size_t n)
+    {
+        const size_t at = data.size();
+        data.resize(at + n);
+        return data.data() + at;
+    }
     void u8(uint8_t v) { data.push_back(v); }
     void le(uint64_t v, int nbytes)
     {
@@ -305,14 +313,32 @@ public:
         if (len_ && !(prev_.size() == len ? std::memcmp(prev_.data(), key, len) < 0
                                          : std::lexicographical_compare(prev_.begin(), prev_.end(), key, key + len)))
             return false; // out of order / duplicate
-        // common prefix with the unfinished path, and the output already committed along it
+        // common prefix with the unfinished path, and the output already committed along it.  [r6] The part of the previous key below its
+        // branching point is IMPLICIT (tail_on_): nodes depth_ .. L (L = its length) exist only as the bytes prev_[depth_ .. L) - a chain of
+        // one-transition nodes without outputs ending in the final leaf, which is what the tail of a key of a map of hashes always is.  It
+        // is written as bytes (emit_tail) when the next key branches off above it, and turned into stack entries (materialize) only as far as
+        // the next key follows it; before, every key pushed ~12 stack entries that the next key froze again one by one.
+        const size_t L = prev_.size();
         size_t p = 0;
         uint64_t committed = 0;
-        while (p < len && p + 1 < depth_ && stack_[p].last_inp == key[p]) {
-            committed += stack_[p].last_out;
-            p++;
+        if (tail_on_) {
+            while (p < len && p < depth_ && stack_[p].last_inp == key[p]) { // (every explicit node has a pending transition here)
+                committed += stack_[p].last_out;
+                p++;
+            }
+            if (p == depth_)
+                while (p < len && p < L && prev_[p] == key[p]) p++; // along the implicit chain: no outputs
+        } else {
+            while (p < len && p + 1 < depth_ && stack_[p].last_inp == key[p]) {
+                committed += stack_[p].last_out;
+                p++;
+            }
         }
         if (committed > value) return false;
+        if (tail_on_) {
+            if (p >= depth_) materialize(p); // the new key follows the chain down to node p
+            if (tail_on_) attach(emit_tail(), p); // what hangs below the deepest explicit node is complete
+        }
         freeze(p);
         if (p == len) { // the key ends on an existing node (a key that is a prefix of nothing written yet cannot get here)
             stack_[p].node.is_final = true;
@@ -321,12 +347,7 @@ public:
             stack_[p].has_last = true;
             stack_[p].last_inp = key[p];
             stack_[p].last_out = value - committed;
-            for (size_t i = p + 1; i < len; i++) {
-                Unfinished &u = push();
-                u.has_last = true;
-                u.last_inp = key[i];
-            }
-            push().node.is_final = true; // the leaf
+            tail_on_ = true; // nodes p + 1 .. len: implicit (depth_ == p + 1)
         }
         prev_.assign(key, key + len);
         len_++;
@@ -340,6 +361,7 @@ public:
     {
         if (!plen || !keys) return false;
         if (len_ && !std::lexicographical_compare(prev_.begin(), prev_.end(), prefix, prefix + plen)) return false;
+        if (tail_on_) materialize(prev_.size()); // (rare path: the stack as the code below expects it)
         size_t p = 0;
         uint64_t committed = 0;
         while (p < plen && p + 1 < depth_ && stack_[p].last_inp == prefix[p]) {
@@ -370,6 +392,7 @@ public:
     }
     void finish()
     {
+        if (tail_on_) attach(emit_tail(), 0);
         freeze(0);
         const uint64_t root = compile(stack_[0].node);
         w_.le(len_, 8);
@@ -381,6 +404,7 @@ public:
     // length >= 1, so its root has a transition)
     uint64_t finish_sub()
     {
+        if (tail_on_) attach(emit_tail(), 0);
         freeze(0);
         return compile(stack_[0].node);
     }
@@ -415,21 +439,72 @@ private:
         while (depth_ > keep + 1) {
             const uint64_t addr = compile(stack_[depth_ - 1].node);
             depth_--;
-            Unfinished &parent = stack_[depth_ - 1];
-            // a parent that will be frozen in this very call and has nothing but this child (the tail of a key below its
-            // branching point: most nodes of a map of hashes) is written without going through its transition list
-            if (depth_ > keep + 1 && !parent.node.is_final && parent.node.trans.empty()) {
-                const uint64_t a2 = compile_one(parent.last_inp, parent.last_out, addr);
-                parent.has_last = false;
-                depth_--;
-                Unfinished &gp = stack_[depth_ - 1];
-                gp.node.trans.push_back(Trans{gp.last_inp, gp.last_out, a2});
-                gp.has_last = false;
-                continue;
-            }
-            parent.node.trans.push_back(Trans{parent.last_inp, parent.last_out, addr});
-            parent.has_last = false;
+            attach(addr, keep);
         }
+    }
+    // `addr` = the compiled node behind the pending transition of the deepest unfinished node
+    void attach(uint64_t addr, size_t keep)
+    {
+        Unfinished &parent = stack_[depth_ - 1];
+        // a parent that will be frozen in this very call and has nothing but this child (the tail of a key below its
+        // branching point: most nodes of a map of hashes) is written without going through its transition list
+        if (depth_ > keep + 1 && !parent.node.is_final && parent.node.trans.empty()) {
+            const uint64_t a2 = compile_one(parent.last_inp, parent.last_out, addr);
+            parent.has_last = false;
+            depth_--;
+            Unfinished &gp = stack_[depth_ - 1];
+            gp.node.trans.push_back(Trans{gp.last_inp, gp.last_out, a2});
+            gp.has_last = false;
+            return;
+        }
+        parent.node.trans.push_back(Trans{parent.last_inp, parent.last_out, addr});
+        parent.has_last = false;
+    }
+    // the implicit tail (nodes depth_ .. L of the previous key) as bytes, deepest node first: the leaf is the empty final node (address
+    // 0, never written), the node above it a one-transition node pointing at address 0, every node above that a one-transition node
+    // whose target is the node written just before it (StateOneTransNext: two bytes).  Returns the address of node depth_.
+    uint64_t emit_tail()
+    {
+        const size_t L = prev_.size();
+        tail_on_ = false;
+        if (depth_ >= L) return 0; // only the leaf was implicit
+        if constexpr (std::is_same<Sink, MemSink>::value) {
+            // the same bytes compile_one would write, stored in one go: [0x00 target delta][0x10 pack sizes][input][0x80] for the node above the
+            // leaf (StateOneTrans to address 0), then [input][0xC0] (StateOneTransNext) per node above it
+            uint8_t *q = w_.grab(4 + 2 * (L - 1 - depth_));
+            q[0] = 0x00;
+            q[1] = 0x10;
+            q[2] = prev_[L - 1];
+            q[3] = 0x80;
+            q += 4;
+            for (size_t d = L - 1; d-- > depth_;) {
+                q[0] = prev_[d];
+                q[1] = 0xC0;
+                q += 2;
+            }
+            last_addr_ = w_.count() - 1;
+            return last_addr_;
+        } else {
+            uint64_t addr = compile_one(prev_[L - 1], 0, 0);
+            for (size_t d = L - 1; d-- > depth_;) addr = compile_one(prev_[d], 0, addr);
+            return addr;
+        }
+    }
+    // implicit nodes depth_ .. upto become stack entries (upto <= L; node L is the final leaf)
+    void materialize(size_t upto)
+    {
+        const size_t L = prev_.size();
+        while (depth_ <= upto) {
+            const size_t d = depth_;
+            Unfinished &u = push();
+            if (d < L) {
+                u.has_last = true;
+                u.last_inp = prev_[d];
+            } else {
+                u.node.is_final = true;
+            }
+        }
+        if (upto >= L) tail_on_ = false;
     }
     // the unfinished path lives in a pool that only grows: a popped entry keeps its transition vector's capacity
     Unfinished &push()
@@ -504,6 +579,7 @@ private:
     size_t depth_ = 0;
     bytes prev_;
     uint64_t len_ = 0, last_addr_ = 1; // NONE_ADDRESS
+    bool tail_on_ = false;             // the previous key's nodes below depth_ - 1 are implicit (insert)
 };
 
 // ---- bloom::BytesBloomFilter (crates/bloom/src/lib.rs:36-48,132-178) -------------------------------------------------
