@@ -1,8 +1,15 @@
+#!/usr/bin/env python3
+"""Do two builds of the library write the SAME speedy_kv store files?  Four key sets (hashed NodeIDs; small integers; every bincode length
+class around its boundaries; long shared prefixes) x {parallel, sequential} fst build x {other build, this build}: SHA-256 of every segment
+file.  Used in round 6 to show that the rewritten fst writer (implicit key tails, staged writes, cheap CRC combine, fst beside the blob files)
+produces byte-identical files to the build before it.
+usage: HB_OLD_LIB=/path/to/other/libhyperball.so tools/store_compare_builds.py"""
 import os, sys, glob, hashlib, subprocess, json, shutil
-ROOT="/root/repo"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+OLD = os.environ.get("HB_OLD_LIB") or sys.exit("set HB_OLD_LIB to the library to compare with")
 code = r'''
 import sys, os, numpy as np
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.environ["HB_REPO_ROOT"])
 from stract_amd import _lib
 case, out = sys.argv[1], sys.argv[2]
 rng = np.random.default_rng(7)
@@ -33,11 +40,11 @@ _lib.store_harmonic(out, ids, vals, ranks)
 res = {}
 for case in ("hashed", "small", "classes", "dense_prefix"):
     h = {}
-    for tag, lib in (("old", ROOT + "/stract_amd/lib/libhyperball_snap90.so"), ("new", "")):
+    for tag, lib in (("old", OLD), ("new", "")):
         for mode in ("parallel", "sequential"):
             out = "/dev/shm/cmp_%s_%s_%s" % (case, tag, mode)
             shutil.rmtree(out, ignore_errors=True)
-            env = dict(os.environ, HB_LIB_PATH=lib)
+            env = dict(os.environ, HB_LIB_PATH=lib, HB_REPO_ROOT=ROOT)
             if mode == "sequential": env["HB_STORE_FST"] = "sequential"
             subprocess.check_call([sys.executable, "-c", code, case, out], env=env)
             d = {}
