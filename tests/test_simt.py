@@ -102,6 +102,8 @@ def test_bench_multi_rank_control_flow_on_the_interpreter(simt_lib, tmp_path):
     assert set(legs) == {"edge_changed_only", "dest_allgather", "dest_changed_only"}
     assert all(v["same_result_as_edge_partition"] is True for v in legs.values()), legs
     assert d["detail"]["collective"]["ran"] == "edge" and d["cpu_baseline"] is None
+    best = d["best_decomposition"]  # [r6] the fastest leg with the main leg's results, at the top level of every N > 1 line
+    assert best["name"] in set(legs) | {"edge_allreduce"} and best["value"] >= d["value"] and best["unit"] == "GTEPS", best
     # and the script still refuses the interpreted build for anything that would look like a measurement
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--config", "C1", "--steps", "1", "--c4-leg", "off"], capture_output=True, text=True,
                        env=_child_env(simt_lib), cwd=str(tmp_path), timeout=600)
