@@ -33,7 +33,35 @@ struct SweepParams {
     // of the previous pass; all zero = that pass was the loop's last one (harmonic.rs:237-240) and every kernel of this one returns
     // at once, leaving the state exactly as that pass left it.  NULL = an ordinary pass.
     const unsigned long long *guard;
+    // [r6] sweep passes IN PLACE (single rank, fused; hb_api_pass.inc step_local): once the loop is in sweep mode the counters are no longer
+    // double-buffered - p.rd is THE current buffer for every row, a row that changes stores its new value in p.wr (scratch), and the FIRST
+    // kernel of the next pass - the one that enumerates the changed rows anyway - copies those rows from the scratch into p.rd before
+    // anything reads it (apply_src -> apply_dst; NULL in the phase's first pass).  Jacobi order is kept (nothing writes p.rd while a pass
+    // reads it), and the lazy double buffer's carry-over disappears: a row that changed in the previous pass but not in this one used to
+    // be copied to the other buffer - 35.5 M rows x 128 B in the first sweep pass at C4, half of the misses of its node-row launch.
+    uint32_t inplace;
+    const uint4 *apply_src;
+    uint4 *apply_dst;
 };
+
+// the row's counter from the scratch buffer into the current one (one lane per row: the callers enumerate changed rows lane by lane)
+__device__ __forceinline__ void apply_row(const SweepParams &sp, uint64_t row)
+{
+    const uint4 a = sp.apply_src[row * 4 + 0], b = sp.apply_src[row * 4 + 1], c = sp.apply_src[row * 4 + 2], d = sp.apply_src[row * 4 + 3];
+    sp.apply_dst[row * 4 + 0] = a;
+    sp.apply_dst[row * 4 + 1] = b;
+    sp.apply_dst[row * 4 + 2] = c;
+    sp.apply_dst[row * 4 + 3] = d;
+}
+
+// the same as a launch of its own (hb_api_pass.inc flush_pending_apply: before anything outside the sweep passes reads the counters -
+// a pass of another mode, a test's register export): rows whose bit is set in `bits` are copied from src to dst, one quad per row
+__global__ __launch_bounds__(256) void apply_changed_kernel(const uint32_t *bits, const uint4 *src, uint4 *dst, uint64_t n_pad)
+{
+    const int q = threadIdx.x & 3;
+    for (uint64_t row = ((uint64_t)blockIdx.x * 256 + threadIdx.x) >> 2; row < n_pad; row += ((uint64_t)gridDim.x * 256) >> 2)
+        if ((bits[row >> 5] >> (row & 31u)) & 1u) dst[row * 4 + q] = src[row * 4 + q];
+}
 
 // wave-uniform: did the pass whose counters `guard` points at change any node (word 0 of its 64 stripes)?
 __device__ __forceinline__ bool guard_open(const unsigned long long *guard)
@@ -84,6 +112,7 @@ __global__ __launch_bounds__(256) void sweep_collect_kernel(const SweepParams sp
             ch &= ch - 1;
             HB_DBG_ASSERT(base < sp.p.n_pad);
             sp.seeds[base++] = (uint32_t)(w << 5) + (uint32_t)b;
+            if (sp.apply_src) apply_row(sp, (w << 5) + (uint64_t)b); // (in-place phase: the previous pass left this row's new value in the scratch)
         }
     }
 }
@@ -171,6 +200,7 @@ __global__ __launch_bounds__(256) void sweep_seed_small_kernel(const SweepParams
             const int b = __ffs((int)ch) - 1;
             ch &= ch - 1;
             const uint64_t u = (w << 5) + (uint64_t)b;
+            if (sp.apply_src) apply_row(sp, u); // (in-place phase, see SweepParams)
             const uint64_t kb = sp.out_ptr[u], ke = sp.out_ptr[u + 1];
             if (ke - kb > 64) lng |= 1u << b;
             else
@@ -273,7 +303,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void s
         // node rows that no changed source reaches but that changed in the previous pass (lazy double buffer:
         // their counter must be carried over to the other buffer) or whose Kahan state is still moving (the
         // reference adds +0.0 to every node in every pass): cheap path below, no index or counter gathers
-        const uint32_t pw = (REAL && in_range) ? p.bits_rd[w] : 0u;
+        const uint32_t pw = (REAL && in_range && !sp.inplace) ? p.bits_rd[w] : 0u; // (in place: nothing is carried over, SweepParams)
         const uint32_t kw = (REAL && in_range) ? p.kdirty[w] : 0u;
         // ([r5] the same rows as a streaming kernel of their own - 128 rows per wave step, 32 rows' loads in flight - was measured at C4,
         // where the first sweep pass revisits 35 M of them: node-row launch 3.67 -> 3.81 ms, and every later pass pays a scan of three
@@ -477,7 +507,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void s
             if (REAL) {
                 const bool touched = ((__ballot(lane_act) >> qshift) & 0xFull) != 0;
                 cnt_rows += (valid && touched && q == 0);
-                const bool self_prev = valid && ((p.bits_rd[row >> 5] >> (row & 31u)) & 1u);
+                const bool self_prev = valid && !sp.inplace && ((p.bits_rd[row >> 5] >> (row & 31u)) & 1u);
                 const bool kd = valid && ((p.kdirty[row >> 5] >> (row & 31u)) & 1u);
                 if (valid && (changed || self_prev)) p.wr[row * 4 + q] = accv; // lazy double buffer
                 if (changed && q == 0) cnt_out += p.outdeg[row];
@@ -526,7 +556,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void s
                     const bool v = li < total2;
                     ent2[j] = v ? (uint32_t)list[li] : 0u;
                     row2[j] = ((uint64_t)wordof[ent2[j] >> 5] << 5) + (ent2[j] & 31u);
-                    sp2[j] = v && ((p.bits_rd[row2[j] >> 5] >> (row2[j] & 31u)) & 1u);
+                    sp2[j] = v && !sp.inplace && ((p.bits_rd[row2[j] >> 5] >> (row2[j] & 31u)) & 1u);
                     kd2[j] = v && ((p.kdirty[row2[j] >> 5] >> (row2[j] & 31u)) & 1u);
                 }
 #pragma unroll
