@@ -37,7 +37,8 @@ struct SweepParams {
     // double-buffered - p.rd is THE current buffer for every row, a row that changes stores its new value in p.wr (scratch), and the FIRST
     // kernel of the next pass - the one that enumerates the changed rows anyway - copies those rows from the scratch into p.rd before
     // anything reads it (apply_src -> apply_dst; NULL in the phase's first pass).  Jacobi order is kept (nothing writes p.rd while a pass
-    // reads it), and the lazy double buffer's carry-over disappears: a row that changed in the previous pass but not in this one used to
+    // reads it; with more than 4096 changed rows the copy is a launch of its own in front of the pass: apply_changed_kernel), and the lazy
+    // double buffer's carry-over disappears: a row that changed in the previous pass but not in this one used to
     // be copied to the other buffer - 35.5 M rows x 128 B in the first sweep pass at C4, half of the misses of its node-row launch.
     uint32_t inplace;
     const uint4 *apply_src;
@@ -54,21 +55,22 @@ __device__ __forceinline__ void apply_row(const SweepParams &sp, uint64_t row)
     sp.apply_dst[row * 4 + 3] = d;
 }
 
-// the same as a launch of its own (hb_api_pass.inc flush_pending_apply: before anything outside the sweep passes reads the counters -
-// a pass of another mode, a test's register export): rows whose bit is set in `bits` are copied from src to dst, one quad per row
-__global__ __launch_bounds__(256) void apply_changed_kernel(const uint32_t *bits, const uint4 *src, uint4 *dst, uint64_t n_pad)
-{
-    const int q = threadIdx.x & 3;
-    for (uint64_t row = ((uint64_t)blockIdx.x * 256 + threadIdx.x) >> 2; row < n_pad; row += ((uint64_t)gridDim.x * 256) >> 2)
-        if ((bits[row >> 5] >> (row & 31u)) & 1u) dst[row * 4 + q] = src[row * 4 + q];
-}
-
 // wave-uniform: did the pass whose counters `guard` points at change any node (word 0 of its 64 stripes)?
 __device__ __forceinline__ bool guard_open(const unsigned long long *guard)
 {
     if (!guard) return true;
     const unsigned long long v = guard[4 * (threadIdx.x & (kStripes - 1))];
     return __ballot(v != 0ull) != 0ull;
+}
+
+// the same as a launch of its own (hb_api_pass.inc flush_pending_apply: before anything outside the sweep passes reads the counters -
+// a pass of another mode, a test's register export): rows whose bit is set in `bits` are copied from src to dst, one quad per row
+__global__ __launch_bounds__(256) void apply_changed_kernel(const uint32_t *bits, const uint4 *src, uint4 *dst, uint64_t n_pad, const unsigned long long *guard)
+{
+    if (!guard_open(guard)) return; // (a queued pass behind the loop's last one)
+    const int q = threadIdx.x & 3;
+    for (uint64_t row = ((uint64_t)blockIdx.x * 256 + threadIdx.x) >> 2; row < n_pad; row += ((uint64_t)gridDim.x * 256) >> 2)
+        if ((bits[row >> 5] >> (row & 31u)) & 1u) dst[row * 4 + q] = src[row * 4 + q];
 }
 
 __device__ __forceinline__ void touch_set(uint32_t *touch, uint32_t r, uint64_t rows_total)
@@ -112,7 +114,6 @@ __global__ __launch_bounds__(256) void sweep_collect_kernel(const SweepParams sp
             ch &= ch - 1;
             HB_DBG_ASSERT(base < sp.p.n_pad);
             sp.seeds[base++] = (uint32_t)(w << 5) + (uint32_t)b;
-            if (sp.apply_src) apply_row(sp, (w << 5) + (uint64_t)b); // (in-place phase: the previous pass left this row's new value in the scratch)
         }
     }
 }
