@@ -152,14 +152,7 @@ struct hb_ctx {
     bool lean_init = false; // hb_begin left the initial counters / Kahan words / sizes to pass 0 (PassParams::rd_init); cleared by pass 0, or by
                             // ensure_initial_state() when something wants to look at the state before pass 0
     uint64_t t = 0;
-    int cur = 0; // d_bits[cur] = the changed bits the next pass reads; d_regs[rcur] = "old" (rcur == cur outside the in-place sweep phase)
-    // [r6] sweep passes in place (hb_sweep.hip.h SweepParams::inplace): while the phase lasts the register buffers do not swap - d_regs[rcur]
-    // is current for every row, d_regs[rcur ^ 1] is the scratch the changed rows of a pass go to
-    int rcur = 0;
-    bool inplace = false;        // the phase is on (entered by the first in-place sweep pass, left by leave_inplace)
-    bool inplace_pass = false;   // the pass queued / running was launched in place
-    bool pending_apply = false;  // the last finished pass ran in place and changed rows: their new values are still in the scratch
-    uint64_t inplace_since = 0;  // pass index of the phase's first pass (it finds nothing to apply)
+    int cur = 0; // d_regs[cur] = "old"
     bool has_changes = false;
     bool pending_local = false; // between hb_step_local and hb_step_finish
     uint64_t last_changed = 0;
@@ -1054,8 +1047,6 @@ int hb_begin(hb_ctx *c)
         if (c->ksum_len > p.n_pad) // slice padding beyond the rows init_kernel writes (all-reduce mode)
             HB_HIP(hipMemsetAsync(c->d_ksum + p.n_pad, 0, (c->ksum_len - p.n_pad) * sizeof(double), c->stream));
         c->cur = 0;
-        c->rcur = 0;
-        c->inplace = c->inplace_pass = c->pending_apply = false;
         c->t = 0;
         c->lean_init = false;
         if (p.n_pad) {
@@ -1091,8 +1082,6 @@ int hb_begin(hb_ctx *c)
         c->rs.stages = 0;
         c->t = 0;
         c->cur = 0;
-        c->rcur = 0;
-        c->inplace = c->inplace_pass = c->pending_apply = false;
         c->wire_bytes = 0;
         c->has_changes = true; // harmonic.rs:232
         c->last_changed = p.n;

@@ -24,7 +24,6 @@
 //     bit 26  0x4000000 sweep passes: a touched row's sources 8 per round (index / bit word / gather each a round trip) instead of all at once
 //     bit 27  0x8000000 pass 0: the first hub-chunk level through the generic INIT kernel instead of init_level1_kernel (A/B)
 //     bit 28  0x10000000 TIMING PROBE, WRONG RESULTS: the dense fused node rows neither read nor write size[] (16 B per row less state traffic)
-//     bit 29  0x20000000 sweep passes double-buffered as before round 6's in-place phase (carry-over of the rows changed in the previous pass), A/B
 //   hb_options.tune[7]  hottest counters staged in LDS by the level-1 dense launch (0 = off, <= 2048; measured slower, round 2)
 #pragma once
 #include <stdint.h>

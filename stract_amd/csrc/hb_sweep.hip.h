@@ -33,27 +33,7 @@ struct SweepParams {
     // of the previous pass; all zero = that pass was the loop's last one (harmonic.rs:237-240) and every kernel of this one returns
     // at once, leaving the state exactly as that pass left it.  NULL = an ordinary pass.
     const unsigned long long *guard;
-    // [r6] sweep passes IN PLACE (single rank, fused; hb_api_pass.inc step_local): once the loop is in sweep mode the counters are no longer
-    // double-buffered - p.rd is THE current buffer for every row, a row that changes stores its new value in p.wr (scratch), and the FIRST
-    // kernel of the next pass - the one that enumerates the changed rows anyway - copies those rows from the scratch into p.rd before
-    // anything reads it (apply_src -> apply_dst; NULL in the phase's first pass).  Jacobi order is kept (nothing writes p.rd while a pass
-    // reads it; with more than 4096 changed rows the copy is a launch of its own in front of the pass: apply_changed_kernel), and the lazy
-    // double buffer's carry-over disappears: a row that changed in the previous pass but not in this one used to
-    // be copied to the other buffer - 35.5 M rows x 128 B in the first sweep pass at C4, half of the misses of its node-row launch.
-    uint32_t inplace;
-    const uint4 *apply_src;
-    uint4 *apply_dst;
 };
-
-// the row's counter from the scratch buffer into the current one (one lane per row: the callers enumerate changed rows lane by lane)
-__device__ __forceinline__ void apply_row(const SweepParams &sp, uint64_t row)
-{
-    const uint4 a = sp.apply_src[row * 4 + 0], b = sp.apply_src[row * 4 + 1], c = sp.apply_src[row * 4 + 2], d = sp.apply_src[row * 4 + 3];
-    sp.apply_dst[row * 4 + 0] = a;
-    sp.apply_dst[row * 4 + 1] = b;
-    sp.apply_dst[row * 4 + 2] = c;
-    sp.apply_dst[row * 4 + 3] = d;
-}
 
 // wave-uniform: did the pass whose counters `guard` points at change any node (word 0 of its 64 stripes)?
 __device__ __forceinline__ bool guard_open(const unsigned long long *guard)
@@ -61,53 +41,6 @@ __device__ __forceinline__ bool guard_open(const unsigned long long *guard)
     if (!guard) return true;
     const unsigned long long v = guard[4 * (threadIdx.x & (kStripes - 1))];
     return __ballot(v != 0ull) != 0ull;
-}
-
-// the same as a launch of its own (hb_api_pass.inc flush_pending_apply: before anything outside the sweep passes reads the counters -
-// a pass of another mode, a test's register export): rows whose bit is set in `bits` are copied from src to dst, one quad per row
-__global__ __launch_bounds__(256) void apply_changed_kernel(const uint32_t *bits, const uint4 *src, uint4 *dst, uint64_t n_pad, const unsigned long long *guard)
-{
-    // a wave takes 64 words of the bitmap (2048 rows) per step, lists their set bits in LDS and copies the listed rows 16 at a time, one quad
-    // per row (64 contiguous bytes); the scan is 1 bit per row, the copies are the only real traffic.  (A first form tested one bit per QUAD
-    // over all rows: 0.35 ms per launch at C4's 99 M rows whatever had changed - profiles/r06r_*.)
-    __shared__ uint16_t s_list[4][2048];
-    if (!guard_open(guard)) return; // (a queued pass behind the loop's last one)
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, g = lane >> 2, q = lane & 3;
-    uint16_t *list = s_list[wv];
-    const uint64_t words = n_pad >> 5;
-    const uint64_t nwaves = (uint64_t)gridDim.x * 4, wid = (uint64_t)blockIdx.x * 4 + wv;
-    for (uint64_t w0 = wid * 64; w0 < words; w0 += nwaves * 64) { // wave-uniform trip count
-        const uint64_t w = w0 + (uint64_t)lane;
-        uint32_t word = w < words ? bits[w] : 0u;
-        const uint32_t mine = __popc(word);
-        uint32_t incl = mine;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const uint32_t a = __shfl_up(incl, off);
-            if (lane >= off) incl += a;
-        }
-        const uint32_t total = __shfl(incl, 63);
-        if (!total) continue;
-        uint32_t pos = incl - mine;
-        while (word) {
-            const int b = __ffs((int)word) - 1;
-            word &= word - 1;
-            list[pos++] = (uint16_t)((lane << 5) | b);
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        for (uint32_t base = 0; base < total; base += 16) {
-            const uint32_t li = base + (uint32_t)g;
-            if (li < total) {
-                const uint32_t ent = list[li];
-                const uint64_t row = ((w0 + (uint64_t)(ent >> 5)) << 5) + (ent & 31u);
-                dst[row * 4 + q] = src[row * 4 + q];
-            }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier(); // the list is rewritten in the next step
-    }
 }
 
 __device__ __forceinline__ void touch_set(uint32_t *touch, uint32_t r, uint64_t rows_total)
@@ -238,7 +171,6 @@ __global__ __launch_bounds__(256) void sweep_seed_small_kernel(const SweepParams
             const int b = __ffs((int)ch) - 1;
             ch &= ch - 1;
             const uint64_t u = (w << 5) + (uint64_t)b;
-            if (sp.apply_src) apply_row(sp, u); // (in-place phase, see SweepParams)
             const uint64_t kb = sp.out_ptr[u], ke = sp.out_ptr[u + 1];
             if (ke - kb > 64) lng |= 1u << b;
             else
@@ -341,7 +273,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void s
         // node rows that no changed source reaches but that changed in the previous pass (lazy double buffer:
         // their counter must be carried over to the other buffer) or whose Kahan state is still moving (the
         // reference adds +0.0 to every node in every pass): cheap path below, no index or counter gathers
-        const uint32_t pw = (REAL && in_range && !sp.inplace) ? p.bits_rd[w] : 0u; // (in place: nothing is carried over, SweepParams)
+        const uint32_t pw = (REAL && in_range) ? p.bits_rd[w] : 0u;
         const uint32_t kw = (REAL && in_range) ? p.kdirty[w] : 0u;
         // ([r5] the same rows as a streaming kernel of their own - 128 rows per wave step, 32 rows' loads in flight - was measured at C4,
         // where the first sweep pass revisits 35 M of them: node-row launch 3.67 -> 3.81 ms, and every later pass pays a scan of three
@@ -545,7 +477,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void s
             if (REAL) {
                 const bool touched = ((__ballot(lane_act) >> qshift) & 0xFull) != 0;
                 cnt_rows += (valid && touched && q == 0);
-                const bool self_prev = valid && !sp.inplace && ((p.bits_rd[row >> 5] >> (row & 31u)) & 1u);
+                const bool self_prev = valid && ((p.bits_rd[row >> 5] >> (row & 31u)) & 1u);
                 const bool kd = valid && ((p.kdirty[row >> 5] >> (row & 31u)) & 1u);
                 if (valid && (changed || self_prev)) p.wr[row * 4 + q] = accv; // lazy double buffer
                 if (changed && q == 0) cnt_out += p.outdeg[row];
@@ -594,7 +526,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void s
                     const bool v = li < total2;
                     ent2[j] = v ? (uint32_t)list[li] : 0u;
                     row2[j] = ((uint64_t)wordof[ent2[j] >> 5] << 5) + (ent2[j] & 31u);
-                    sp2[j] = v && !sp.inplace && ((p.bits_rd[row2[j] >> 5] >> (row2[j] & 31u)) & 1u);
+                    sp2[j] = v && ((p.bits_rd[row2[j] >> 5] >> (row2[j] & 31u)) & 1u);
                     kd2[j] = v && ((p.kdirty[row2[j] >> 5] >> (row2[j] & 31u)) & 1u);
                 }
 #pragma unroll
